@@ -1,0 +1,85 @@
+"""Building blocks of the EDVR hot path on HIP kernels.
+
+Mirrors the EDVR-relevant part of basicsr/models/archs/arch_util.py (xinntao/EDVR):
+  default_init_weights (:20-48), make_layer (:51-64), ResidualBlockNoBN (:67-95), DCNv2Pack (:232-257).
+Same names, constructor arguments, parameter names and initialisation (including the order in
+which the RNG is consumed, so `torch.manual_seed(s)` builds bit-identical networks).
+"""
+import logging
+
+import torch
+from torch import nn
+from torch.nn import init
+from torch.nn.modules.batchnorm import _BatchNorm
+
+from . import functional as F_
+from .dcn import ModulatedDeformConvPack, modulated_deform_conv
+
+OFFSET_ABSMEAN_LIMIT = 50  # arch_util.py:249
+
+
+def get_root_logger():
+    return logging.getLogger('basicsr')
+
+
+@torch.no_grad()
+def default_init_weights(module_list, scale=1, bias_fill=0, **kwargs):
+    for top in (module_list if isinstance(module_list, list) else [module_list]):
+        for m in top.modules():
+            if isinstance(m, (nn.Conv2d, nn.Linear)):
+                init.kaiming_normal_(m.weight, **kwargs)
+                m.weight.data *= scale
+                if m.bias is not None:
+                    m.bias.data.fill_(bias_fill)
+            elif isinstance(m, _BatchNorm):
+                init.constant_(m.weight, 1)
+                if m.bias is not None:
+                    m.bias.data.fill_(bias_fill)
+
+
+def make_layer(basic_block, num_basic_block, **kwarg):
+    return nn.Sequential(*(basic_block(**kwarg) for _ in range(num_basic_block)))
+
+
+class ResidualBlockNoBN(nn.Module):
+    """x + res_scale * conv2(relu(conv1(x))): two MFMA launches, ReLU and the identity add fused in."""
+
+    def __init__(self, num_feat=64, res_scale=1, pytorch_init=False):
+        super().__init__()
+        self.res_scale = res_scale
+        self.conv1 = nn.Conv2d(num_feat, num_feat, 3, 1, 1, bias=True)
+        self.conv2 = nn.Conv2d(num_feat, num_feat, 3, 1, 1, bias=True)
+        self.relu = nn.ReLU(inplace=True)
+        if not pytorch_init:
+            default_init_weights([self.conv1, self.conv2], 0.1)
+
+    def forward(self, x):
+        if self.res_scale != 1:
+            raise NotImplementedError('edvr_amd fuses the residual add; res_scale != 1 is not used by EDVR')
+        return F_.conv(self.conv2, F_.conv(self.conv1, x, act=F_.ACT_RELU), res1=x)
+
+
+def warn_offset_absmean(value):
+    if value > OFFSET_ABSMEAN_LIMIT:
+        get_root_logger().warning(f'Offset abs mean is {value}, larger than 50.')
+
+
+class DCNv2Pack(ModulatedDeformConvPack):
+    """DCNv2 whose offsets/masks are predicted from a SECOND feature map (arch_util.py:232-257).
+
+    `stats_sink`: when a list is attached (EDVR.forward does), the per-image sums of |offset| are
+    appended as device tensors and the `> 50` warning is evaluated once per forward; standalone use
+    keeps the reference behaviour (check right away, one host sync per call).
+    """
+
+    stats_sink = None
+
+    def forward(self, x, feat, act=F_.ACT_NONE):
+        offset, mask = F_.offset_mask_conv(self.conv_offset, feat)
+        sums = F_.ops.abs_sum_per_image(offset.detach())
+        if self.stats_sink is not None:
+            self.stats_sink.append((sums, offset[0].numel()))
+        else:
+            warn_offset_absmean(float(sums.sum().item()) / offset.numel())
+        return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation,
+                                     self.groups, self.deformable_groups, act)

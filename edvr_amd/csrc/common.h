@@ -1,0 +1,45 @@
+// Internal helpers shared by the HIP translation units of libedvr_amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/edvr_amd.h"
+
+namespace edvr {
+
+void set_error(const char *fmt, ...);
+
+inline int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return EDVR_ERR_LAUNCH;
+  }
+  return EDVR_OK;
+}
+
+inline hipStream_t as_stream(edvr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// internal C++ entry used by dcn.hip for its GEMMs (same as the C ABI, no re-validation of wpk)
+int conv2d_launch(const edvr_conv2d_desc &d, hipStream_t stream);
+
+// C[M,N] (+)= A[M,K] * B[N,K]^T with K contiguous in both (pixel axis); deterministic split-K.
+// ws must hold splits*M*N floats.  Used for dW of DCN (and conv wgrad on explicit columns).
+size_t gemm_nt_ws_elems(int M, int N, int64_t K);
+int gemm_nt_launch(const float *A, const float *B, float *C, int M, int N, int64_t K, int64_t lda, int64_t ldb,
+                   bool accumulate, float *ws, hipStream_t stream);
+
+}  // namespace edvr
+
+#define EDVR_REQUIRE(cond, ...)       \
+  do {                                \
+    if (!(cond)) {                    \
+      ::edvr::set_error(__VA_ARGS__); \
+      return EDVR_ERR_ARG;            \
+    }                                 \
+  } while (0)

@@ -1,0 +1,458 @@
+// dcn.hip - modulated deformable convolution (DCNv2) forward / backward for gfx950.
+//
+// Replaces (paths relative to the reference's basicsr/models/ops/dcn/src/):
+//   modulated_deform_conv_cuda_forward   deform_conv_cuda.cpp:490-569
+//   modulated_deform_conv_cuda_backward  deform_conv_cuda.cpp:571-685
+//   modulated_deformable_im2col / col2im / col2im_coord kernels
+//                                        deform_conv_cuda_kernel.cu:570-767
+// Semantics reproduced exactly (see oracle/dcnv2_oracle_impl.inc for the CPU
+// restatement these kernels are tested against):
+//   * offset channel = g*2K + 2k + {0: dy, 1: dx}, mask channel = g*K + k, column row = c*K + k
+//   * a tap contributes iff -1 < h < H and -1 < w < W (.cu:618); every bilinear corner
+//     outside [0,H-1]x[0,W-1] contributes 0 (.cu:481-491)
+//   * d/d(offset) is the derivative inside the cell [floor p, floor p + 1) (.cu:526-568)
+//
+// Differences in HOW (MI355X-first):
+//   * the whole batch is processed by one launch per stage (the reference loops over the
+//     batch on the host: 2*B launches + an at::zeros per call, cpp:532-543);
+//   * one thread owns one (image, deformable group, tap, pixel): offsets/mask are read and the
+//     bilinear cell is resolved ONCE and reused for the C/dg channels of the group (the reference
+//     re-reads them per channel), lanes run along the pixel axis so every column/offset access
+//     is a coalesced 256-B line;
+//   * the column x weight products run on the fp32 MFMA conv kernel of conv2d.hip (bias fused);
+//   * backward: one fused kernel produces dOffset, dMask, dX and rewrites the dY-columns
+//     buffer in place with the forward columns needed by dW (the reference runs three kernels
+//     and a 25-iteration window scan per column entry, .cu:677-691); dW is a deterministic
+//     split-K MFMA GEMM over the pixel axis.
+#include "common.h"
+
+namespace edvr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct DcnShape {
+  int B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, Ho, Wo;
+  int64_t off_bs, msk_bs;
+};
+
+struct Tap {
+  float w00, w01, w10, w11;  // bilinear corner weights, 0 where the corner is outside the image
+  int o00, o01, o10, o11;    // clamped element offsets inside one channel plane
+  float lh, lw;
+  bool ok00, ok01, ok10, ok11;  // corner inside the image AND tap valid
+};
+
+__device__ __forceinline__ Tap resolve_tap(float h, float w, int H, int W) {
+  Tap t;
+  const bool valid = (h > -1.f) && (w > -1.f) && (h < (float)H) && (w < (float)W);
+  const float fh = floorf(h), fw = floorf(w);
+  const int h0 = (int)fh, w0 = (int)fw, h1 = h0 + 1, w1 = w0 + 1;
+  t.lh = h - fh;
+  t.lw = w - fw;
+  const float hh = 1.f - t.lh, hw = 1.f - t.lw;
+  const bool r0 = valid && h0 >= 0, r1 = valid && h1 <= H - 1;
+  const bool c0 = w0 >= 0, c1 = w1 <= W - 1;
+  t.ok00 = r0 && c0;
+  t.ok01 = r0 && c1;
+  t.ok10 = r1 && c0;
+  t.ok11 = r1 && c1;
+  t.w00 = t.ok00 ? hh * hw : 0.f;
+  t.w01 = t.ok01 ? hh * t.lw : 0.f;
+  t.w10 = t.ok10 ? t.lh * hw : 0.f;
+  t.w11 = t.ok11 ? t.lh * t.lw : 0.f;
+  const int ch0 = min(max(h0, 0), H - 1), ch1 = min(max(h1, 0), H - 1);
+  const int cw0 = min(max(w0, 0), W - 1), cw1 = min(max(w1, 0), W - 1);
+  t.o00 = ch0 * W + cw0;
+  t.o01 = ch0 * W + cw1;
+  t.o10 = ch1 * W + cw0;
+  t.o11 = ch1 * W + cw1;
+  return t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward gather: col[img, c*K + k, p] = mask * bilinear(x[img, c], p + tap + offset)
+__global__ __launch_bounds__(256) void dcn_im2col_kernel(const float *__restrict__ x, const float *__restrict__ offset,
+                                                         const float *__restrict__ mask, float *__restrict__ col,
+                                                         const DcnShape s) {
+  const int K = s.kh * s.kw, P = s.Ho * s.Wo, cpg = s.C / s.dg;
+  const int64_t total = (int64_t)s.B * s.dg * K * P;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int p = (int)(idx % P);
+    const int k = (int)((idx / P) % K);
+    const int g = (int)((idx / ((int64_t)P * K)) % s.dg);
+    const int b = (int)(idx / ((int64_t)P * K * s.dg));
+    const int ho = p / s.Wo, wo = p - ho * s.Wo;
+    const int i = k / s.kw, j = k - i * s.kw;
+    const float *off_b = offset + (int64_t)b * s.off_bs + (int64_t)(g * 2 * K + 2 * k) * P + p;
+    const float dy = off_b[0], dx = off_b[P];
+    const float m = mask[(int64_t)b * s.msk_bs + (int64_t)(g * K + k) * P + p];
+    const Tap t = resolve_tap((float)(ho * s.stride - s.pad + i * s.dil) + dy, (float)(wo * s.stride - s.pad + j * s.dil) + dx, s.H, s.W);
+    const float *xp = x + ((int64_t)b * s.C + (int64_t)g * cpg) * s.H * s.W;
+    float *cp = col + ((int64_t)b * s.C * K + (int64_t)(g * cpg) * K + k) * P + p;
+    const int64_t plane = (int64_t)s.H * s.W;
+    for (int cc = 0; cc < cpg; ++cc) {
+      const float v = t.w00 * xp[t.o00] + t.w01 * xp[t.o01] + t.w10 * xp[t.o10] + t.w11 * xp[t.o11];
+      *cp = v * m;
+      xp += plane;
+      cp += (int64_t)K * P;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward: per (img, g, k, p) reduce over the group's channels.
+//   dcol (in)  : W^T dY, layout (img, c*K + k, p);  rewritten in place with the forward column
+//   dmask, doffset written; dx accumulated with fp32 atomics (dx pre-zeroed by the driver)
+__global__ __launch_bounds__(256) void dcn_bwd_coord_kernel(const float *__restrict__ x, const float *__restrict__ offset,
+                                                            const float *__restrict__ mask, float *__restrict__ dcol,
+                                                            float *__restrict__ dx, float *__restrict__ doffset,
+                                                            float *__restrict__ dmask, const DcnShape s) {
+  const int K = s.kh * s.kw, P = s.Ho * s.Wo, cpg = s.C / s.dg;
+  const int64_t total = (int64_t)s.B * s.dg * K * P;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int p = (int)(idx % P);
+    const int k = (int)((idx / P) % K);
+    const int g = (int)((idx / ((int64_t)P * K)) % s.dg);
+    const int b = (int)(idx / ((int64_t)P * K * s.dg));
+    const int ho = p / s.Wo, wo = p - ho * s.Wo;
+    const int i = k / s.kw, j = k - i * s.kw;
+    const float *off_b = offset + (int64_t)b * s.off_bs + (int64_t)(g * 2 * K + 2 * k) * P + p;
+    const float dy = off_b[0], dxo = off_b[P];
+    const float m = mask[(int64_t)b * s.msk_bs + (int64_t)(g * K + k) * P + p];
+    const Tap t = resolve_tap((float)(ho * s.stride - s.pad + i * s.dil) + dy, (float)(wo * s.stride - s.pad + j * s.dil) + dxo, s.H, s.W);
+    // d(bilinear)/dh and /dw weights per corner (zero where the corner is outside or the tap invalid)
+    const float hh = 1.f - t.lh, hw = 1.f - t.lw;
+    const bool ok00 = t.ok00, ok01 = t.ok01, ok10 = t.ok10, ok11 = t.ok11;
+    const float gy00 = ok00 ? -hw : 0.f, gy01 = ok01 ? -t.lw : 0.f, gy10 = ok10 ? hw : 0.f, gy11 = ok11 ? t.lw : 0.f;
+    const float gx00 = ok00 ? -hh : 0.f, gx01 = ok01 ? hh : 0.f, gx10 = ok10 ? -t.lh : 0.f, gx11 = ok11 ? t.lh : 0.f;
+
+    const int64_t plane = (int64_t)s.H * s.W;
+    const float *xp = x + ((int64_t)b * s.C + (int64_t)g * cpg) * plane;
+    float *gp = dx + ((int64_t)b * s.C + (int64_t)g * cpg) * plane;
+    float *cp = dcol + ((int64_t)b * s.C * K + (int64_t)(g * cpg) * K + k) * P + p;
+    float s_m = 0.f, s_y = 0.f, s_x = 0.f;
+    for (int cc = 0; cc < cpg; ++cc) {
+      const float dc = *cp;
+      const float a00 = xp[t.o00], a01 = xp[t.o01], a10 = xp[t.o10], a11 = xp[t.o11];
+      const float val = t.w00 * a00 + t.w01 * a01 + t.w10 * a10 + t.w11 * a11;
+      s_m += dc * val;
+      s_y += dc * (gy00 * a00 + gy01 * a01 + gy10 * a10 + gy11 * a11);
+      s_x += dc * (gx00 * a00 + gx01 * a01 + gx10 * a10 + gx11 * a11);
+      const float tt = dc * m;
+      if (ok00) unsafeAtomicAdd(gp + t.o00, t.w00 * tt);
+      if (ok01) unsafeAtomicAdd(gp + t.o01, t.w01 * tt);
+      if (ok10) unsafeAtomicAdd(gp + t.o10, t.w10 * tt);
+      if (ok11) unsafeAtomicAdd(gp + t.o11, t.w11 * tt);
+      *cp = val * m;  // forward column, consumed by the dW GEMM
+      xp += plane;
+      gp += plane;
+      cp += (int64_t)K * P;
+    }
+    dmask[((int64_t)b * s.dg * K + g * K + k) * P + p] = s_m;
+    float *dob = doffset + ((int64_t)b * s.dg * 2 * K + g * 2 * K + 2 * k) * P + p;
+    dob[0] = s_y * m;
+    dob[P] = s_x * m;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// row sums: out[r] = sum_{b, p} a[b, r, p]   (db)
+__global__ __launch_bounds__(256) void row_sum_kernel(const float *__restrict__ a, float *__restrict__ out, int nb, int rows,
+                                                      int64_t P, int64_t bstride) {
+  const int r = blockIdx.x;
+  float s = 0.f;
+  for (int b = 0; b < nb; ++b) {
+    const float *row = a + (int64_t)b * bstride + (int64_t)r * P;
+    for (int64_t p = threadIdx.x; p < P; p += 256) s += row[p];
+  }
+  __shared__ float red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[r] = red[0];
+}
+
+// ---------------------------------------------------------------------------------------------
+// C[M,N] (+)= sum_batches A_b[M,K] * B_b[N,K]^T, K contiguous (pixel axis).  fp32 MFMA 32x32x2,
+// 64x64 block tile (4 waves as 2x2), K staged through LDS in chunks of 32, deterministic split-K
+// into ws[split][M][N] followed by gemm_reduce_kernel.
+constexpr int GK = 32;
+struct GemmNT {
+  const float *A, *B;
+  float *ws;
+  int M, N, nb;
+  int64_t K, lda, ldb, a_bs, b_bs;
+  int chunks_per_batch, total_chunks, splits;
+};
+
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT g) {
+  __shared__ float as[64][GK + 1];
+  __shared__ float bs[64][GK + 1];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, j = lane & 31;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64, split = blockIdx.z;
+  const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
+  const int c_begin = (int)((int64_t)g.total_chunks * split / g.splits);
+  const int c_end = (int)((int64_t)g.total_chunks * (split + 1) / g.splits);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int lk = tid & 31, lr = tid >> 5;
+  for (int c = c_begin; c < c_end; ++c) {
+    const int b = c / g.chunks_per_batch;
+    const int64_t k0 = (int64_t)(c - b * g.chunks_per_batch) * GK;
+    const float *Ab = g.A + (int64_t)b * g.a_bs, *Bb = g.B + (int64_t)b * g.b_bs;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int r = lr + it * 8;
+      const bool kok = (k0 + lk) < g.K;
+      as[r][lk] = (kok && (m0 + r) < g.M) ? Ab[(int64_t)(m0 + r) * g.lda + k0 + lk] : 0.f;
+      bs[r][lk] = (kok && (n0 + r) < g.N) ? Bb[(int64_t)(n0 + r) * g.ldb + k0 + lk] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < GK; kk += 2) {
+      const float av = as[wm + j][kk + half];
+      const float bv = bs[wn + j][kk + half];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+  }
+  float *out = g.ws + (int64_t)split * g.M * g.N;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * half, n = n0 + wn + j;
+    if (m < g.M && n < g.N) out[(int64_t)m * g.N + n] = acc[r];
+  }
+}
+
+__global__ void gemm_reduce_kernel(const float *__restrict__ ws, float *__restrict__ C, int64_t mn, int splits, int accumulate) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < mn; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = accumulate ? C[i] : 0.f;
+    for (int k = 0; k < splits; ++k) s += ws[(int64_t)k * mn + i];
+    C[i] = s;
+  }
+}
+
+static int gemm_splits(int M, int N, int64_t total_chunks) {
+  const int tiles = cdiv(M, 64) * cdiv(N, 64);
+  int s = cdiv(1024, tiles);  // ~4 workgroups per CU
+  if (s > total_chunks) s = (int)total_chunks;
+  if (s < 1) s = 1;
+  if (s > 256) s = 256;
+  return s;
+}
+
+static int gemm_nt_batched(const float *A, const float *B, float *C, int M, int N, int64_t K, int64_t lda, int64_t ldb, int nb,
+                           int64_t a_bs, int64_t b_bs, bool accumulate, float *ws, hipStream_t stream) {
+  GemmNT g;
+  g.A = A; g.B = B; g.ws = ws; g.M = M; g.N = N; g.nb = nb; g.K = K; g.lda = lda; g.ldb = ldb; g.a_bs = a_bs; g.b_bs = b_bs;
+  g.chunks_per_batch = (int)cdiv64(K, GK);
+  g.total_chunks = g.chunks_per_batch * nb;
+  g.splits = gemm_splits(M, N, g.total_chunks);
+  dim3 grid(cdiv(N, 64), cdiv(M, 64), g.splits);
+  hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(256), 0, stream, g);
+  int rc = check_launch("gemm_nt_kernel");
+  if (rc) return rc;
+  const int64_t mn = (int64_t)M * N;
+  hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(mn, 256), 2048)), dim3(256), 0, stream, ws, C,
+                     mn, g.splits, accumulate ? 1 : 0);
+  return check_launch("gemm_reduce_kernel");
+}
+
+static size_t gemm_nt_ws_elems_b(int M, int N, int64_t K, int nb) {
+  const int64_t chunks = cdiv64(K, GK) * nb;
+  return (size_t)gemm_splits(M, N, chunks) * M * N;
+}
+
+size_t gemm_nt_ws_elems(int M, int N, int64_t K) { return gemm_nt_ws_elems_b(M, N, K, 1); }
+
+int gemm_nt_launch(const float *A, const float *B, float *C, int M, int N, int64_t K, int64_t lda, int64_t ldb, bool accumulate,
+                   float *ws, hipStream_t stream) {
+  return gemm_nt_batched(A, B, C, M, N, K, lda, ldb, 1, 0, 0, accumulate, ws, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static int fill_shape(DcnShape &s, int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil, int groups,
+                      int dg, int64_t off_bs, int64_t msk_bs) {
+  EDVR_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Co > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0 && dil > 0 && groups > 0 && dg > 0,
+               "dcnv2: non-positive size");
+  EDVR_REQUIRE(C % groups == 0 && Co % groups == 0, "dcnv2: channels (%d -> %d) not divisible by groups %d", C, Co, groups);
+  EDVR_REQUIRE(C % dg == 0, "dcnv2: channels %d not divisible by deformable_groups %d", C, dg);
+  s.B = B; s.C = C; s.H = H; s.W = W; s.Co = Co; s.kh = kh; s.kw = kw; s.stride = stride; s.pad = pad; s.dil = dil;
+  s.groups = groups; s.dg = dg;
+  s.Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1;
+  s.Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
+  EDVR_REQUIRE(s.Ho > 0 && s.Wo > 0, "dcnv2: convolution input is too small (output would be %dx%d)", s.Ho, s.Wo);
+  const int64_t P = (int64_t)s.Ho * s.Wo, K = kh * kw;
+  s.off_bs = off_bs ? off_bs : (int64_t)dg * 2 * K * P;
+  s.msk_bs = msk_bs ? msk_bs : (int64_t)dg * K * P;
+  return EDVR_OK;
+}
+
+struct FwdWs { size_t col, wpk, total; };
+static FwdWs fwd_ws(const DcnShape &s) {
+  const size_t K = (size_t)s.kh * s.kw, P = (size_t)s.Ho * s.Wo;
+  FwdWs w;
+  w.col = 0;
+  size_t off = align_up((size_t)s.B * s.C * K * P * 4, 256);
+  w.wpk = off;
+  off += align_up(edvr_conv2d_packed_weight_elems(s.Co / s.groups, (int)((s.C / s.groups) * K), 1) * 4 * s.groups, 256);
+  w.total = off;
+  return w;
+}
+
+struct BwdWs { size_t col, wpk, gemm, total; };
+static BwdWs bwd_ws(const DcnShape &s) {
+  const size_t K = (size_t)s.kh * s.kw, P = (size_t)s.Ho * s.Wo;
+  const int cig = s.C / s.groups, cog = s.Co / s.groups;
+  BwdWs w;
+  w.col = 0;
+  size_t off = align_up((size_t)s.B * s.C * K * P * 4, 256);
+  w.wpk = off;
+  off += align_up(edvr_conv2d_packed_weight_elems((int)(cig * K), cog, 1) * 4 * s.groups, 256);
+  w.gemm = off;
+  off += align_up(gemm_nt_ws_elems_b(cog, (int)(cig * K), (int64_t)P, s.B) * 4, 256);
+  w.total = off;
+  return w;
+}
+
+}  // namespace edvr
+
+extern "C" {
+
+size_t edvr_dcnv2_fwd_ws_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil, int groups,
+                               int dg) {
+  edvr::DcnShape s;
+  if (edvr::fill_shape(s, B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, 0, 0)) return 0;
+  return edvr::fwd_ws(s).total;
+}
+
+size_t edvr_dcnv2_bwd_ws_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil, int groups,
+                               int dg) {
+  edvr::DcnShape s;
+  if (edvr::fill_shape(s, B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, 0, 0)) return 0;
+  return edvr::bwd_ws(s).total;
+}
+
+int edvr_dcnv2_fwd_f32(const float *x, const float *offset, const float *mask, const float *weight, const float *bias,
+                       float *y, int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil, int groups,
+                       int dg, int64_t offset_bstride, int64_t mask_bstride, int act, void *ws, size_t ws_bytes,
+                       edvr_stream_t stream_) {
+  using namespace edvr;
+  EDVR_REQUIRE(x && offset && mask && weight && y, "dcnv2_fwd: null pointer");
+  DcnShape s;
+  int rc = fill_shape(s, B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, offset_bstride, mask_bstride);
+  if (rc) return rc;
+  const FwdWs wsz = fwd_ws(s);
+  if (!ws || ws_bytes < wsz.total) {
+    set_error("dcnv2_fwd: workspace %zu < required %zu", ws_bytes, wsz.total);
+    return EDVR_ERR_WORKSPACE;
+  }
+  hipStream_t stream = as_stream(stream_);
+  const int K = kh * kw;
+  const int64_t P = (int64_t)s.Ho * s.Wo;
+  float *col = reinterpret_cast<float *>(static_cast<char *>(ws) + wsz.col);
+  float *wpk = reinterpret_cast<float *>(static_cast<char *>(ws) + wsz.wpk);
+  const int cig = C / groups, cog = Co / groups;
+  const size_t wpk_g = edvr_conv2d_packed_weight_elems(cog, cig * K, 1);
+  for (int g = 0; g < groups; ++g) {
+    rc = edvr_conv2d_pack_weight_f32(weight + (size_t)g * cog * cig * K, wpk + g * wpk_g, cog, cig * K, 1, 0, stream_);
+    if (rc) return rc;
+  }
+  const int64_t total = (int64_t)B * dg * K * P;
+  hipLaunchKernelGGL(dcn_im2col_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 1 << 20)), dim3(256), 0, stream, x,
+                     offset, mask, col, s);
+  rc = check_launch("dcn_im2col_kernel");
+  if (rc) return rc;
+  for (int g = 0; g < groups; ++g) {
+    edvr_conv2d_desc d = {};
+    d.x1 = col + (int64_t)g * cig * K * P;
+    d.c1 = cig * K;
+    d.x1_img_stride = (int64_t)C * K * P;
+    d.n = B; d.h = s.Ho; d.w = s.Wo;
+    d.wpk = wpk + g * wpk_g;
+    d.bias = bias ? bias + g * cog : nullptr;
+    d.co = cog; d.ks = 1; d.stride = 1;
+    d.act = act;
+    d.y = y + (int64_t)g * cog * P;
+    d.y_img_stride = (int64_t)Co * P;
+    d.out_mode = EDVR_OUT_NCHW;
+    rc = conv2d_launch(d, stream);
+    if (rc) return rc;
+  }
+  return EDVR_OK;
+}
+
+int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, const float *weight, const float *dy, float *dx,
+                       float *doffset, float *dmask, float *dweight, float *dbias, int B, int C, int H, int W, int Co, int kh,
+                       int kw, int stride, int pad, int dil, int groups, int dg, int64_t offset_bstride, int64_t mask_bstride,
+                       void *ws, size_t ws_bytes, edvr_stream_t stream_) {
+  using namespace edvr;
+  EDVR_REQUIRE(x && offset && mask && weight && dy && dx && doffset && dmask && dweight, "dcnv2_bwd: null pointer");
+  DcnShape s;
+  int rc = fill_shape(s, B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, offset_bstride, mask_bstride);
+  if (rc) return rc;
+  const BwdWs wsz = bwd_ws(s);
+  if (!ws || ws_bytes < wsz.total) {
+    set_error("dcnv2_bwd: workspace %zu < required %zu", ws_bytes, wsz.total);
+    return EDVR_ERR_WORKSPACE;
+  }
+  hipStream_t stream = as_stream(stream_);
+  const int K = kh * kw;
+  const int64_t P = (int64_t)s.Ho * s.Wo;
+  float *col = reinterpret_cast<float *>(static_cast<char *>(ws) + wsz.col);
+  float *wpk = reinterpret_cast<float *>(static_cast<char *>(ws) + wsz.wpk);
+  float *gws = reinterpret_cast<float *>(static_cast<char *>(ws) + wsz.gemm);
+  const int cig = C / groups, cog = Co / groups;
+  // 1. dcol = W^T dY  (1x1 conv over the pixel grid: "input channels" = cog, "output channels" = cig*K)
+  const size_t wpk_g = edvr_conv2d_packed_weight_elems(cig * K, cog, 1);
+  for (int g = 0; g < groups; ++g) {
+    const float *wg = weight + (size_t)g * cog * cig * K;
+    const float *wuse = wg;
+    if ((cog % 16) != 0 || ((cig * K) % 32) != 0) {  // W (cog x cig*K, row-major) is already the packed layout when aligned
+      rc = edvr_conv2d_pack_weight_f32(wg, wpk + g * wpk_g, cig * K, cog, 1, 1, stream_);
+      if (rc) return rc;
+      wuse = wpk + g * wpk_g;
+    }
+    edvr_conv2d_desc d = {};
+    d.x1 = dy + (int64_t)g * cog * P;
+    d.c1 = cog;
+    d.x1_img_stride = (int64_t)Co * P;
+    d.n = B; d.h = s.Ho; d.w = s.Wo;
+    d.wpk = wuse;
+    d.co = cig * K; d.ks = 1; d.stride = 1;
+    d.y = col + (int64_t)g * cig * K * P;
+    d.y_img_stride = (int64_t)C * K * P;
+    rc = conv2d_launch(d, stream);
+    if (rc) return rc;
+  }
+  // 2. dOffset, dMask, dX (+ forward columns in place)
+  if (hipMemsetAsync(dx, 0, (size_t)B * C * H * W * sizeof(float), stream) != hipSuccess) {
+    set_error("dcnv2_bwd: hipMemsetAsync failed");
+    return EDVR_ERR_LAUNCH;
+  }
+  const int64_t total = (int64_t)B * dg * K * P;
+  hipLaunchKernelGGL(dcn_bwd_coord_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 1 << 20)), dim3(256), 0, stream, x,
+                     offset, mask, col, dx, doffset, dmask, s);
+  rc = check_launch("dcn_bwd_coord_kernel");
+  if (rc) return rc;
+  // 3. dW[g] = sum_{b,p} dY[b, g] col[b, g]^T ; db = sum dY
+  for (int g = 0; g < groups; ++g) {
+    rc = gemm_nt_batched(dy + (int64_t)g * cog * P, col + (int64_t)g * cig * K * P, dweight + (size_t)g * cog * cig * K, cog, cig * K, P,
+                         P, P, B, (int64_t)Co * P, (int64_t)C * K * P, false, gws, stream);
+    if (rc) return rc;
+  }
+  if (dbias) {
+    hipLaunchKernelGGL(row_sum_kernel, dim3(Co), dim3(256), 0, stream, dy, dbias, B, Co, P, (int64_t)Co * P);
+    rc = check_launch("row_sum_kernel");
+    if (rc) return rc;
+  }
+  return EDVR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,226 @@
+// elementwise.hip - the HBM-bound glue of the EDVR hot path (gfx950).
+//
+// Replaces stock ATen kernels the reference calls around its convolutions
+// (basicsr/models/archs/edvr_arch.py):
+//   TSA temporal attention      :171-184  (T reductions + cat + sigmoid + expand().contiguous() + mul)
+//   MaxPool2d/AvgPool2d(3,2,1)  :144-145,192-194,199-201  (+ the torch.cat of both)
+//   nn.Upsample(x2, bilinear)   :68-69,109-110,158-159,204,208
+//   feat*sigmoid(attn)*2+add    :210-213
+//   F.interpolate(x4) + add     :417-419
+// All of them are bandwidth-bound: lanes run along the contiguous pixel axis, 16 B per lane
+// where the shape allows, one pass over each operand.
+#include "common.h"
+
+namespace edvr {
+
+__device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + __expf(-v)); }
+
+// ---- TSA temporal attention.  VEC pixels per thread (float4 when hw % 4 == 0).
+template <int VEC>
+__global__ __launch_bounds__(256) void tsa_temporal_kernel(const float *__restrict__ emb, const float *__restrict__ emb_ref,
+                                                           const float *__restrict__ aligned, float *__restrict__ out,
+                                                           float *__restrict__ prob_out, int b, int t, int c, int hw) {
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
+  const int hwv = hw / VEC;
+  const int64_t total = (int64_t)b * t * hwv;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int pv = (int)(idx % hwv);
+    const int ti = (int)((idx / hwv) % t);
+    const int bi = (int)(idx / ((int64_t)hwv * t));
+    const vec_t *e = reinterpret_cast<const vec_t *>(emb + ((int64_t)(bi * t + ti) * c) * hw) + pv;
+    const vec_t *r = reinterpret_cast<const vec_t *>(emb_ref + ((int64_t)bi * c) * hw) + pv;
+    vec_t dot = 0.f;
+    for (int ch = 0; ch < c; ++ch) dot += e[(int64_t)ch * hwv] * r[(int64_t)ch * hwv];
+    vec_t pr;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) pr[v] = sigmoidf(dot[v]);
+    if (prob_out) reinterpret_cast<vec_t *>(prob_out + (int64_t)(bi * t + ti) * hw)[pv] = pr;
+    const vec_t *a = reinterpret_cast<const vec_t *>(aligned + ((int64_t)(bi * t + ti) * c) * hw) + pv;
+    vec_t *o = reinterpret_cast<vec_t *>(out + ((int64_t)(bi * t + ti) * c) * hw) + pv;
+    for (int ch = 0; ch < c; ++ch) o[(int64_t)ch * hwv] = a[(int64_t)ch * hwv] * pr;
+  }
+}
+
+// ---- fused 3x3/s2/p1 max + avg pooling -> cat(max, avg)
+__global__ __launch_bounds__(256) void pool_maxavg_kernel(const float *__restrict__ x, float *__restrict__ y, int n, int c, int h, int w,
+                                                          int ho, int wo) {
+  const int64_t total = (int64_t)n * c * ho * wo;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(idx % wo);
+    const int oy = (int)((idx / wo) % ho);
+    const int ch = (int)((idx / ((int64_t)wo * ho)) % c);
+    const int ni = (int)(idx / ((int64_t)wo * ho * c));
+    const float *src = x + ((int64_t)ni * c + ch) * h * w;
+    float mx = -INFINITY, sm = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int iy = oy * 2 - 1 + dy;
+      if (iy < 0 || iy >= h) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int ix = ox * 2 - 1 + dx;
+        if (ix < 0 || ix >= w) continue;
+        const float v = src[iy * w + ix];
+        mx = fmaxf(mx, v);
+        sm += v;
+      }
+    }
+    const int64_t plane = (int64_t)ho * wo;
+    float *dst = y + ((int64_t)ni * 2 * c) * plane + (int64_t)oy * wo + ox;
+    dst[(int64_t)ch * plane] = mx;
+    dst[(int64_t)(c + ch) * plane] = sm * (1.f / 9.f);  // count_include_pad=True: always / 9
+  }
+}
+
+// ---- bilinear upsampling, align_corners=False: src = (dst + 0.5) / S - 0.5, clamped at 0
+template <int S>
+__device__ __forceinline__ void src_index(int dst, int in, int &i0, int &i1, float &l) {
+  float s = ((float)dst + 0.5f) * (1.f / S) - 0.5f;
+  if (s < 0.f) s = 0.f;
+  i0 = (int)s;
+  i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+  l = s - (float)i0;
+}
+
+template <int S, bool ADD>
+__global__ __launch_bounds__(256) void upsample_kernel(const float *__restrict__ x, float *__restrict__ y, int nc, int h, int w,
+                                                       float scale) {
+  const int ho = h * S, wo = w * S;
+  const int64_t total = (int64_t)nc * ho * wo;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(idx % wo);
+    const int oy = (int)((idx / wo) % ho);
+    const int64_t pl = idx / ((int64_t)wo * ho);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    src_index<S>(oy, h, y0, y1, ly);
+    src_index<S>(ox, w, x0, x1, lx);
+    const float *src = x + pl * h * w;
+    const float v = (1.f - ly) * ((1.f - lx) * src[y0 * w + x0] + lx * src[y0 * w + x1]) +
+                    ly * ((1.f - lx) * src[y1 * w + x0] + lx * src[y1 * w + x1]);
+    if (ADD)
+      y[idx] += v;
+    else
+      y[idx] = v * scale;
+  }
+}
+
+__global__ __launch_bounds__(256) void tsa_combine_kernel(const float *__restrict__ feat, const float *__restrict__ attn,
+                                                          const float *__restrict__ attn_add, float *__restrict__ y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    y[i] = feat[i] * sigmoidf(attn[i]) * 2.f + attn_add[i];
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = a[i] + b[i];
+}
+
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y, float *__restrict__ dz,
+                                                      int64_t total, int c, int64_t hw, int act, int act_from) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ch = (int)((i / hw) % c);
+    float g = dy[i];
+    if (ch >= act_from) {
+      const float v = y[i];
+      if (act == EDVR_ACT_RELU) g = v > 0.f ? g : 0.f;
+      else if (act == EDVR_ACT_LRELU) g = v > 0.f ? g : 0.1f * g;
+      else if (act == EDVR_ACT_SIGMOID) g = g * v * (1.f - v);
+    }
+    dz[i] = g;
+  }
+}
+
+__global__ __launch_bounds__(256) void abs_sum_kernel(const float *__restrict__ x, float *__restrict__ out, int64_t per_img,
+                                                      int64_t img_stride) {
+  const int img = blockIdx.y;
+  const float *src = x + (int64_t)img * img_stride;
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_img; i += (int64_t)gridDim.x * 256) s += fabsf(src[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(out + img, red[0] + red[1] + red[2] + red[3]);
+}
+
+static inline unsigned grid_for(int64_t total) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv64(total, 256), 256 * 16)); }
+
+}  // namespace edvr
+
+extern "C" {
+
+int edvr_tsa_temporal_f32(const float *emb, const float *emb_ref, const float *aligned, float *out, float *prob_out, int b, int t,
+                          int c, int hw, edvr_stream_t stream) {
+  using namespace edvr;
+  EDVR_REQUIRE(emb && emb_ref && aligned && out && b > 0 && t > 0 && c > 0 && hw > 0, "tsa_temporal: bad arguments");
+  if (hw % 4 == 0) {
+    hipLaunchKernelGGL(tsa_temporal_kernel<4>, dim3(grid_for((int64_t)b * t * (hw / 4))), dim3(256), 0, as_stream(stream), emb, emb_ref,
+                       aligned, out, prob_out, b, t, c, hw);
+  } else {
+    hipLaunchKernelGGL(tsa_temporal_kernel<1>, dim3(grid_for((int64_t)b * t * hw)), dim3(256), 0, as_stream(stream), emb, emb_ref,
+                       aligned, out, prob_out, b, t, c, hw);
+  }
+  return check_launch("tsa_temporal_kernel");
+}
+
+int edvr_pool_maxavg_3x3s2_f32(const float *x, float *y, int n, int c, int h, int w, edvr_stream_t stream) {
+  using namespace edvr;
+  EDVR_REQUIRE(x && y && n > 0 && c > 0 && h > 0 && w > 0, "pool_maxavg: bad arguments");
+  const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
+  hipLaunchKernelGGL(pool_maxavg_kernel, dim3(grid_for((int64_t)n * c * ho * wo)), dim3(256), 0, as_stream(stream), x, y, n, c, h, w, ho,
+                     wo);
+  return check_launch("pool_maxavg_kernel");
+}
+
+int edvr_upsample2x_f32(const float *x, float *y, int nc, int h, int w, float scale, edvr_stream_t stream) {
+  using namespace edvr;
+  EDVR_REQUIRE(x && y && nc > 0 && h > 0 && w > 0, "upsample2x: bad arguments");
+  hipLaunchKernelGGL((upsample_kernel<2, false>), dim3(grid_for((int64_t)nc * h * w * 4)), dim3(256), 0, as_stream(stream), x, y, nc, h, w,
+                     scale);
+  return check_launch("upsample_kernel<2>");
+}
+
+int edvr_upsample4x_add_f32(const float *base, float *y, int nc, int h, int w, edvr_stream_t stream) {
+  using namespace edvr;
+  EDVR_REQUIRE(base && y && nc > 0 && h > 0 && w > 0, "upsample4x_add: bad arguments");
+  hipLaunchKernelGGL((upsample_kernel<4, true>), dim3(grid_for((int64_t)nc * h * w * 16)), dim3(256), 0, as_stream(stream), base, y, nc, h,
+                     w, 1.f);
+  return check_launch("upsample_kernel<4>");
+}
+
+int edvr_tsa_combine_f32(const float *feat, const float *attn, const float *attn_add, float *y, int64_t numel, edvr_stream_t stream) {
+  using namespace edvr;
+  EDVR_REQUIRE(feat && attn && attn_add && y && numel > 0, "tsa_combine: bad arguments");
+  hipLaunchKernelGGL(tsa_combine_kernel, dim3(grid_for(numel)), dim3(256), 0, as_stream(stream), feat, attn, attn_add, y, numel);
+  return check_launch("tsa_combine_kernel");
+}
+
+int edvr_add_f32(const float *a, const float *b, float *y, int64_t numel, edvr_stream_t stream) {
+  using namespace edvr;
+  EDVR_REQUIRE(a && b && y && numel > 0, "add: bad arguments");
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(numel)), dim3(256), 0, as_stream(stream), a, b, y, numel);
+  return check_launch("add_kernel");
+}
+
+int edvr_act_bwd_f32(const float *dy, const float *y, float *dz, int n, int c, int64_t hw, int act, int act_from, edvr_stream_t stream) {
+  using namespace edvr;
+  EDVR_REQUIRE(dy && y && dz && n > 0 && c > 0 && hw > 0, "act_bwd: bad arguments");
+  const int64_t total = (int64_t)n * c * hw;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), dy, y, dz, total, c, hw, act, act_from);
+  return check_launch("act_bwd_kernel");
+}
+
+int edvr_abs_sum_f32(const float *x, float *out, int n, int64_t per_img, int64_t img_stride, edvr_stream_t stream) {
+  using namespace edvr;
+  EDVR_REQUIRE(x && out && n > 0 && per_img > 0, "abs_sum: bad arguments");
+  if (hipMemsetAsync(out, 0, sizeof(float) * n, as_stream(stream)) != hipSuccess) {
+    set_error("abs_sum: hipMemsetAsync failed");
+    return EDVR_ERR_LAUNCH;
+  }
+  const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv64(per_img, 256 * 8), 512));
+  hipLaunchKernelGGL(abs_sum_kernel, dim3(gx, n), dim3(256), 0, as_stream(stream), x, out, per_img, img_stride);
+  return check_launch("abs_sum_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,96 @@
+"""Module-level functional layer: nn.Conv2d parameter holders -> fused HIP launches.
+
+`conv(m, x, ...)` runs an nn.Conv2d's parameters through the fp32 MFMA kernel with the
+surrounding elementwise ops of the reference graph fused in (activation, residual adds,
+channel concat of a second input, PixelShuffle).  When gradients are required the same
+launches are recorded as autograd Functions (edvr_amd/autograd.py).
+"""
+import torch
+
+from . import ops
+from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, OUT_NCHW, OUT_PIXEL_SHUFFLE2  # noqa: F401
+
+
+def _conv_geometry(m):
+    ks, st = m.kernel_size, m.stride
+    if (ks[0] != ks[1] or ks[0] not in (1, 3) or st[0] != st[1] or st[0] not in (1, 2) or (ks[0] == 1 and st[0] != 1)
+            or tuple(m.padding) != (ks[0] // 2, ks[0] // 2) or tuple(m.dilation) != (1, 1) or m.groups != 1):
+        raise NotImplementedError(
+            f'edvr_amd conv kernel supports 3x3 (stride 1/2, pad 1) and 1x1 convolutions, dilation 1, groups 1; got {m}')
+    return ks[0], st[0]
+
+
+def _needs_grad(*ts):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+
+
+def conv(m, x, *, x2=None, x2_map=None, act=ACT_NONE, act_from=0, res1=None, res2=None, out_mode=OUT_NCHW):
+    """act(conv(cat(x, x2)) + bias) + res1 + res2 with the parameters of nn.Conv2d `m`."""
+    ks, stride = _conv_geometry(m)
+    if x.dim() != 4:
+        raise ValueError(f'expected a 4-D input, got {tuple(x.shape)}')
+    cin = x.shape[1] + (x2.shape[1] if x2 is not None else 0)
+    if cin != m.in_channels:
+        raise RuntimeError(f'expected {m.in_channels} input channels, got {cin}')
+    ops.require_gpu(x, x2, m.weight)
+    if _needs_grad(x, x2, m.weight, m.bias, res1, res2):
+        from . import autograd as ag
+        return ag.conv(m, x, x2, x2_map, act, act_from, res1, res2, out_mode, ks, stride)
+    wpk = ops.pack_conv_weight(m.weight)
+    bias = m.bias.detach() if m.bias is not None else None
+    return ops.conv2d(x, wpk, bias, m.out_channels, ks, x2=x2, x2_map=x2_map, stride=stride, act=act, act_from=act_from,
+                      res1=res1, res2=res2, out_mode=out_mode)
+
+
+def offset_mask_conv(conv_offset, feat):
+    """conv_offset(feat) -> (offset, mask) as in arch_util.py:244-247 / deform_conv.py:384-387.
+
+    chunk(3) + cat(o1, o2) is channels [0, 2/3) and sigmoid(chunk 3) is channels [2/3, 1): both are
+    returned as zero-copy channel slices of ONE conv output, the sigmoid applied in the conv epilogue.
+    """
+    co = conv_offset.out_channels
+    out = conv(conv_offset, feat, act=ACT_SIGMOID, act_from=2 * co // 3)
+    return out[:, :2 * co // 3], out[:, 2 * co // 3:]
+
+
+def upsample2x(x, scale=1.0):
+    if _needs_grad(x):
+        from . import autograd as ag
+        return ag.Upsample2x.apply(x, scale)
+    return ops.upsample2x(x, scale)
+
+
+def pool_maxavg(x):
+    if _needs_grad(x):
+        from . import autograd as ag
+        return ag.PoolMaxAvg.apply(x)
+    return ops.pool_maxavg(x)
+
+
+def tsa_temporal(emb, emb_ref, aligned):
+    if _needs_grad(emb, emb_ref, aligned):
+        from . import autograd as ag
+        return ag.TsaTemporal.apply(emb, emb_ref, aligned)
+    return ops.tsa_temporal(emb, emb_ref, aligned)
+
+
+def tsa_combine(feat, attn, attn_add):
+    if _needs_grad(feat, attn, attn_add):
+        from . import autograd as ag
+        return ag.TsaCombine.apply(feat, attn, attn_add)
+    return ops.tsa_combine(feat, attn, attn_add)
+
+
+def add(a, b):
+    if _needs_grad(a, b):
+        from . import autograd as ag
+        return ag.Add.apply(a, b)
+    return ops.add(a, b)
+
+
+def upsample4x_add(y, base):
+    """y + bilinear_x4(base)."""
+    if _needs_grad(y, base):
+        from . import autograd as ag
+        return ag.Upsample4xAdd.apply(y, base)
+    return ops.upsample4x_add_(y, base)

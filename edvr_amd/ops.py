@@ -1,0 +1,274 @@
+"""Tensor-level wrappers over the C ABI (no autograd here; see edvr_amd/functional.py).
+
+PyTorch is plumbing only: it owns device memory and the current HIP stream.  Every
+function launches hand-written HIP kernels from libedvr_amd.so on
+``torch.cuda.current_stream()`` and never synchronises.
+"""
+import ctypes
+import weakref
+
+import torch
+
+from . import _lib
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, OUT_NCHW, OUT_PIXEL_SHUFFLE2  # noqa: F401
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def require_gpu(*tensors):
+    """Same refusal as the reference (deform_conv.py:133-134): no CPU path exists."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise NotImplementedError('edvr_amd ops run on the GPU only (HIP/gfx950); got a CPU tensor')
+        if t.dtype != torch.float32:
+            raise NotImplementedError(f'edvr_amd ops are fp32 only; got {t.dtype}')
+
+
+def _plane_contig(t):
+    """(n, c, h, w) whose (c, h, w) block is dense; the image stride may be larger (channel-sliced view)."""
+    n, c, h, w = t.shape
+    return t.stride(3) == 1 and t.stride(2) == w and t.stride(1) == h * w and (n == 1 or t.stride(0) >= c * h * w)
+
+
+def _as_planes(t):
+    return t if _plane_contig(t) else t.contiguous()
+
+
+def _img_stride(t):
+    return t.stride(0) if t.shape[0] > 1 else t.shape[1] * t.shape[2] * t.shape[3]
+
+
+# ------------------------------------------------------------------------------------------------ workspace
+_WS = {}
+
+
+def workspace(nbytes, device):
+    """Grow-only scratch buffer per (device, stream).  288 GB of HBM: keep it resident, never free per call."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = None
+        _WS.pop(key, None)
+        buf = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+# ------------------------------------------------------------------------------------------------ weights
+_PACKED = weakref.WeakKeyDictionary()
+
+
+def pack_conv_weight(weight, transpose_flip=False):
+    """(co, ci, k, k) parameter -> MFMA-friendly [ci_pad][k*k][co_pad] array, cached per parameter version."""
+    require_gpu(weight)
+    key = bool(transpose_flip)
+    slot = _PACKED.get(weight)
+    ver = weight._version
+    if slot is not None and key in slot and slot[key][0] == ver and slot[key][2] == weight.data_ptr():
+        return slot[key][1]
+    L = _lib.lib()
+    w = weight.detach()
+    if not w.is_contiguous():
+        w = w.contiguous()
+    o, i, k, k2 = w.shape
+    assert k == k2, 'square kernels only'
+    co, ci = (i, o) if transpose_flip else (o, i)
+    n = L.edvr_conv2d_packed_weight_elems(co, ci, k)
+    out = torch.empty(n, dtype=torch.float32, device=w.device)
+    _lib.check(L.edvr_conv2d_pack_weight_f32(_ptr(w), _ptr(out), co, ci, k, 1 if transpose_flip else 0, _stream()),
+               'edvr_conv2d_pack_weight_f32')
+    if slot is None:
+        slot = {}
+        _PACKED[weight] = slot
+    slot[key] = (ver, out, weight.data_ptr())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ conv
+def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NONE, act_from=0, res1=None, res2=None,
+           out_mode=OUT_NCHW, out=None):
+    """y = act(conv(cat(x1, x2)) + bias) + res1 + res2 on the fp32 MFMA kernel.
+
+    x2_map = (div, mul, add): image i of x2 is (i // div) * mul + add (broadcast of a reference frame).
+    """
+    require_gpu(x1, x2, wpk, bias, res1, res2)
+    L = _lib.lib()
+    x1 = _as_planes(x1)
+    n, c1, h, w = x1.shape
+    d = _lib.ConvDesc()
+    d.x1, d.c1, d.x1_img_stride = _ptr(x1), c1, _img_stride(x1)
+    if x2 is not None:
+        x2 = _as_planes(x2)
+        d.x2, d.c2, d.x2_img_stride = _ptr(x2), x2.shape[1], _img_stride(x2)
+        assert x2.shape[2:] == x1.shape[2:]
+        if x2_map is not None:
+            d.x2_div, d.x2_mul, d.x2_add = x2_map
+        else:
+            assert x2.shape[0] == n
+    d.n, d.h, d.w = n, h, w
+    d.wpk, d.bias = _ptr(wpk), _ptr(bias)
+    d.co, d.ks, d.stride = co, ks, stride
+    d.act, d.act_from = act, act_from
+    pad = ks // 2
+    ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
+    if out is None:
+        shape = (n, co // 4, 2 * ho, 2 * wo) if out_mode == OUT_PIXEL_SHUFFLE2 else (n, co, ho, wo)
+        out = torch.empty(shape, dtype=torch.float32, device=x1.device)
+    else:
+        assert _plane_contig(out)
+    for name, r in (('res1', res1), ('res2', res2)):
+        if r is not None:
+            r = _as_planes(r)
+            assert tuple(r.shape) == (n, co, ho, wo), f'{name} shape {tuple(r.shape)}'
+            setattr(d, name, _ptr(r))
+            setattr(d, name + '_img_stride', _img_stride(r))
+            if name == 'res1':
+                res1 = r
+            else:
+                res2 = r
+    d.y, d.y_img_stride, d.out_mode = _ptr(out), _img_stride(out), out_mode
+    _lib.check(L.edvr_conv2d_f32(ctypes.byref(d), _stream()), 'edvr_conv2d_f32')
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ DCNv2
+def _dcn_dims(x, weight, stride, pad, dil, groups, dg):
+    B, C, H, W = x.shape
+    Co, cig, kh, kw = weight.shape
+    return [B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg]
+
+
+def _bstride(t):
+    """offset/mask may be channel slices of one conv_offset output: pass their image stride."""
+    return t.stride(0) if t.shape[0] > 1 else 0
+
+
+def dcnv2_forward(x, offset, mask, weight, bias, stride, pad, dil, groups, dg, act=ACT_NONE):
+    require_gpu(x, offset, mask, weight, bias)
+    L = _lib.lib()
+    if not x.is_contiguous() or not weight.is_contiguous():
+        raise RuntimeError('input tensor has to be contiguous')  # deform_conv_cuda.cpp:497-498
+    offset, mask = _as_planes(offset), _as_planes(mask)
+    dims = _dcn_dims(x, weight, stride, pad, dil, groups, dg)
+    B, C, H, W, Co, kh, kw = dims[:7]
+    if C != weight.shape[1] * groups:
+        raise RuntimeError(f'Input shape and kernel channels wont match: ({C} vs {weight.shape[1] * groups}).')
+    Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1
+    Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) // stride + 1
+    if Ho <= 0 or Wo <= 0:
+        raise ValueError(f'convolution input is too small (output would be {Ho}x{Wo})')
+    assert tuple(offset.shape[1:]) == (dg * 2 * kh * kw, Ho, Wo), f'offset shape {tuple(offset.shape)}'
+    assert tuple(mask.shape[1:]) == (dg * kh * kw, Ho, Wo), f'mask shape {tuple(mask.shape)}'
+    y = torch.empty(B, Co, Ho, Wo, dtype=torch.float32, device=x.device)
+    nbytes = L.edvr_dcnv2_fwd_ws_bytes(*dims)
+    ws = workspace(nbytes, x.device)
+    _lib.check(L.edvr_dcnv2_fwd_f32(_ptr(x), _ptr(offset), _ptr(mask), _ptr(weight), _ptr(bias), _ptr(y), *dims,
+                                    _bstride(offset), _bstride(mask), act, _ptr(ws), nbytes, _stream()), 'edvr_dcnv2_fwd_f32')
+    return y
+
+
+def dcnv2_backward(x, offset, mask, weight, dy, with_bias, stride, pad, dil, groups, dg):
+    require_gpu(x, offset, mask, weight, dy)
+    L = _lib.lib()
+    offset, mask = _as_planes(offset), _as_planes(mask)
+    dy = dy.contiguous()
+    dims = _dcn_dims(x, weight, stride, pad, dil, groups, dg)
+    dx = torch.empty_like(x)
+    doff = torch.empty(offset.shape, dtype=torch.float32, device=x.device)
+    dmsk = torch.empty(mask.shape, dtype=torch.float32, device=x.device)
+    dw = torch.empty_like(weight)
+    db = torch.empty(weight.shape[0], dtype=torch.float32, device=x.device) if with_bias else None
+    nbytes = L.edvr_dcnv2_bwd_ws_bytes(*dims)
+    ws = workspace(nbytes, x.device)
+    _lib.check(L.edvr_dcnv2_bwd_f32(_ptr(x), _ptr(offset), _ptr(mask), _ptr(weight), _ptr(dy), _ptr(dx), _ptr(doff), _ptr(dmsk),
+                                    _ptr(dw), _ptr(db), *dims, _bstride(offset), _bstride(mask), _ptr(ws), nbytes, _stream()),
+               'edvr_dcnv2_bwd_f32')
+    return dx, doff, dmsk, dw, db
+
+
+# ------------------------------------------------------------------------------------------------ glue kernels
+def tsa_temporal(emb, emb_ref, aligned, want_prob=False):
+    """emb/aligned (b, t, c, h, w), emb_ref (b, c, h, w) -> aligned * sigmoid(<emb_t, emb_ref>) and optionally prob."""
+    require_gpu(emb, emb_ref, aligned)
+    b, t, c, h, w = aligned.shape
+    emb, emb_ref, aligned = emb.contiguous(), emb_ref.contiguous(), aligned.contiguous()
+    out = torch.empty_like(aligned)
+    prob = torch.empty(b, t, h, w, dtype=torch.float32, device=aligned.device) if want_prob else None
+    _lib.check(_lib.lib().edvr_tsa_temporal_f32(_ptr(emb), _ptr(emb_ref), _ptr(aligned), _ptr(out), _ptr(prob), b, t, c, h * w,
+                                                _stream()), 'edvr_tsa_temporal_f32')
+    return (out, prob) if want_prob else out
+
+
+def pool_maxavg(x):
+    require_gpu(x)
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    y = torch.empty(n, 2 * c, (h - 1) // 2 + 1, (w - 1) // 2 + 1, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().edvr_pool_maxavg_3x3s2_f32(_ptr(x), _ptr(y), n, c, h, w, _stream()), 'edvr_pool_maxavg_3x3s2_f32')
+    return y
+
+
+def upsample2x(x, scale=1.0):
+    require_gpu(x)
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    y = torch.empty(n, c, 2 * h, 2 * w, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().edvr_upsample2x_f32(_ptr(x), _ptr(y), n * c, h, w, float(scale), _stream()), 'edvr_upsample2x_f32')
+    return y
+
+
+def tsa_combine(feat, attn, attn_add):
+    require_gpu(feat, attn, attn_add)
+    feat, attn, attn_add = feat.contiguous(), attn.contiguous(), attn_add.contiguous()
+    y = torch.empty_like(feat)
+    _lib.check(_lib.lib().edvr_tsa_combine_f32(_ptr(feat), _ptr(attn), _ptr(attn_add), _ptr(y), feat.numel(), _stream()),
+               'edvr_tsa_combine_f32')
+    return y
+
+
+def upsample4x_add_(y, base):
+    """y += bilinear_x4(base), in place."""
+    require_gpu(y, base)
+    base = base.contiguous()
+    n, c, h, w = base.shape
+    assert y.is_contiguous() and tuple(y.shape) == (n, c, 4 * h, 4 * w)
+    _lib.check(_lib.lib().edvr_upsample4x_add_f32(_ptr(base), _ptr(y), n * c, h, w, _stream()), 'edvr_upsample4x_add_f32')
+    return y
+
+
+def add(a, b):
+    require_gpu(a, b)
+    a, b = a.contiguous(), b.contiguous()
+    assert a.shape == b.shape
+    y = torch.empty_like(a)
+    _lib.check(_lib.lib().edvr_add_f32(_ptr(a), _ptr(b), _ptr(y), a.numel(), _stream()), 'edvr_add_f32')
+    return y
+
+
+def act_backward(dy, y, act, act_from=0):
+    """dz = dy * act'(.) computed from the activation output y; (n, c, h, w) tensors."""
+    require_gpu(dy, y)
+    dy, y = dy.contiguous(), y.contiguous()
+    n, c = y.shape[:2]
+    dz = torch.empty_like(dy)
+    _lib.check(_lib.lib().edvr_act_bwd_f32(_ptr(dy), _ptr(y), _ptr(dz), n, c, y[0, 0].numel(), act, act_from, _stream()),
+               'edvr_act_bwd_f32')
+    return dz
+
+
+def abs_sum_per_image(x):
+    """sum |x[i]| per image of a (n, c, h, w) tensor (image-strided views allowed)."""
+    require_gpu(x)
+    x = _as_planes(x)
+    n, c, h, w = x.shape
+    out = torch.empty(n, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().edvr_abs_sum_f32(_ptr(x), _ptr(out), n, c * h * w, _img_stride(x), _stream()), 'edvr_abs_sum_f32')
+    return out

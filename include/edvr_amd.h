@@ -1,0 +1,148 @@
+/* edvr_amd.h - C ABI of libedvr_amd.so: the MI355X (gfx950) native EDVR hot path.
+ *
+ * Drop-in boundary.  These entry points are what the reference's FFI for this
+ * path binds; each cites the reference interface it replaces (paths relative to
+ * xinntao/EDVR = BasicSR v1.2.0):
+ *
+ *   edvr_dcnv2_fwd_f32  <- modulated_deform_conv_forward
+ *                          basicsr/models/ops/dcn/src/deform_conv_ext.cpp:106-124
+ *                          (driver deform_conv_cuda.cpp:490-569, kernel .cu:570-633)
+ *   edvr_dcnv2_bwd_f32  <- modulated_deform_conv_backward
+ *                          basicsr/models/ops/dcn/src/deform_conv_ext.cpp:126-147
+ *                          (driver deform_conv_cuda.cpp:571-685, kernels .cu:635-767)
+ *   edvr_conv2d_*       <- the at::conv2d / cuDNN calls under every nn.Conv2d of
+ *                          basicsr/models/archs/edvr_arch.py (:37-66,139-155,230-244,322-353)
+ *                          with the LeakyReLU/ReLU/residual/PixelShuffle/cat that follow them
+ *                          (arch_util.py:92-95, edvr_arch.py:70,157,351,410-411) fused in.
+ *   edvr_tsa_temporal_* <- TSAFusion.forward temporal attention, edvr_arch.py:171-184
+ *   edvr_pool_*, edvr_upsample2x_*, edvr_tsa_combine_*, edvr_upsample4x_add_*
+ *                       <- MaxPool2d/AvgPool2d(3,2,1), nn.Upsample(x2 bilinear) and the
+ *                          elementwise tail of TSAFusion / EDVR.forward
+ *                          (edvr_arch.py:144-145,158-159,190-213,414-419)
+ *
+ * Contract (all entry points):
+ *   - every pointer is a DEVICE pointer to contiguous fp32 unless stated; NCHW;
+ *   - the caller allocates everything (outputs, gradients, workspace), as the
+ *     reference's Python does (deform_conv.py:138-140,154-158);
+ *   - asynchronous on `stream` (a hipStream_t; NULL = default stream), no host
+ *     synchronisation, no allocation, no global state: re-entrant across streams;
+ *   - returns 0 or a negative EDVR_ERR_* code; edvr_last_error() gives the
+ *     message for the calling thread.  Kernel launch failures are returned, not
+ *     printf'd (the reference only prints: deform_conv_cuda_kernel.cu:794-798).
+ *   - there is NO CPU implementation behind this ABI.
+ */
+#ifndef EDVR_AMD_H
+#define EDVR_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EDVR_OK 0
+#define EDVR_ERR_ARG (-1)          /* bad shape / null pointer / mismatched sizes */
+#define EDVR_ERR_UNSUPPORTED (-2)  /* parameter combination not implemented */
+#define EDVR_ERR_LAUNCH (-3)       /* HIP launch error */
+#define EDVR_ERR_WORKSPACE (-4)    /* workspace too small */
+
+typedef void *edvr_stream_t; /* hipStream_t */
+
+const char *edvr_version(void);
+const char *edvr_last_error(void);
+/* Device-capability probe: 0 if the current HIP device is gfx950, else EDVR_ERR_UNSUPPORTED. */
+int edvr_check_device(void);
+
+/* ------------------------------------------------------------------ activations */
+#define EDVR_ACT_NONE 0
+#define EDVR_ACT_RELU 1
+#define EDVR_ACT_LRELU 2 /* negative slope 0.1 (edvr_arch.py:70,157,248,356) */
+#define EDVR_ACT_SIGMOID 3
+
+#define EDVR_OUT_NCHW 0
+#define EDVR_OUT_PIXEL_SHUFFLE2 1 /* y[n, co/4, 2h+(co%4)/2, 2w+co%2]  (nn.PixelShuffle(2)) */
+
+/* ------------------------------------------------------------------ conv2d (fp32 MFMA implicit GEMM)
+ * y = act(conv(cat(x1, x2), W) + bias) + res1 + res2, kernel ks in {1,3}, pad = ks/2,
+ * stride in {1,2}, dilation 1, groups 1.  Weights come pre-packed by
+ * edvr_conv2d_pack_weight_f32 (layout [ci_pad][ks*ks][co_pad], co fastest). */
+typedef struct edvr_conv2d_desc {
+  const float *x1;        /* (n, c1, h, w) */
+  const float *x2;        /* optional second input, concatenated after x1 on the channel axis */
+  int c1, c2;             /* c2 = 0 when x2 == NULL */
+  int64_t x1_img_stride;  /* elements between consecutive images of x1 (>= c1*h*w) */
+  int64_t x2_img_stride;
+  int x2_div, x2_mul, x2_add; /* image map of x2: i2 = (i / x2_div) * x2_mul + x2_add; x2_div = 0 -> i2 = i */
+  int n, h, w;
+  const float *wpk;       /* packed weights */
+  const float *bias;      /* (co) or NULL */
+  int co, ks, stride;
+  int act;                /* EDVR_ACT_*; applied to output channels >= act_from only */
+  int act_from;
+  const float *res1;      /* optional residuals, same shape as the NCHW output (n, co, ho, wo) */
+  const float *res2;
+  int64_t res1_img_stride, res2_img_stride;
+  float *y;
+  int64_t y_img_stride;   /* elements between images of y */
+  int out_mode;           /* EDVR_OUT_* */
+} edvr_conv2d_desc;
+
+size_t edvr_conv2d_packed_weight_elems(int co, int ci, int ks);
+/* w: (co, ci, ks, ks) -> wpk.  transpose_flip != 0 packs the data-gradient kernel instead:
+ * w'(ci, co, ks, ks) with w'[c][o][i][j] = w[o][c][ks-1-i][ks-1-j] (then `co`/`ci` refer to w'). */
+int edvr_conv2d_pack_weight_f32(const float *w, float *wpk, int co, int ci, int ks, int transpose_flip,
+                                edvr_stream_t stream);
+int edvr_conv2d_f32(const edvr_conv2d_desc *d, edvr_stream_t stream);
+
+/* ------------------------------------------------------------------ DCNv2 (modulated deformable conv)
+ * x (B,C,H,W); offset (B, dg*2*kh*kw, Ho, Wo) channel = g*2K + 2k + {0:dy,1:dx};
+ * mask (B, dg*kh*kw, Ho, Wo); weight (Co, C/groups, kh, kw); bias (Co) or NULL; y (B,Co,Ho,Wo).
+ * offset_bstride / mask_bstride: elements between consecutive images of offset / mask
+ * (0 = contiguous), so channel-sliced views of one conv_offset output can be passed without a copy.
+ * act: EDVR_ACT_* applied to y in the GEMM epilogue (EDVR_ACT_NONE = the reference op; PCDAlignment
+ * follows two of its four DCNs with LeakyReLU, edvr_arch.py:103-104,116). */
+size_t edvr_dcnv2_fwd_ws_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil,
+                               int groups, int dg);
+int edvr_dcnv2_fwd_f32(const float *x, const float *offset, const float *mask, const float *weight,
+                       const float *bias, float *y, int B, int C, int H, int W, int Co, int kh, int kw, int stride,
+                       int pad, int dil, int groups, int dg, int64_t offset_bstride, int64_t mask_bstride, int act,
+                       void *ws, size_t ws_bytes, edvr_stream_t stream);
+
+size_t edvr_dcnv2_bwd_ws_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil,
+                               int groups, int dg);
+/* Gradients are OVERWRITTEN (no pre-zeroing needed).  dbias may be NULL.  dx accumulates by fp32
+ * atomics (as the reference's col2im does, .cu:688), so its summation order is not deterministic. */
+int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, const float *weight, const float *dy,
+                       float *dx, float *doffset, float *dmask, float *dweight, float *dbias, int B, int C, int H,
+                       int W, int Co, int kh, int kw, int stride, int pad, int dil, int groups, int dg,
+                       int64_t offset_bstride, int64_t mask_bstride, void *ws, size_t ws_bytes, edvr_stream_t stream);
+
+/* ------------------------------------------------------------------ TSA / PCD glue kernels (HBM-bound) */
+/* Temporal attention (edvr_arch.py:171-184): prob[b,t,p] = sigmoid(sum_c emb[b,t,c,p]*emb_ref[b,c,p]);
+ * out[b,t,c,p] = aligned[b,t,c,p] * prob[b,t,p].  prob_out (b,t,hw) may be NULL. */
+int edvr_tsa_temporal_f32(const float *emb, const float *emb_ref, const float *aligned, float *out, float *prob_out,
+                          int b, int t, int c, int hw, edvr_stream_t stream);
+/* MaxPool2d(3,2,1) and AvgPool2d(3,2,1, count_include_pad) in one pass; y (n, 2c, ho, wo) = cat(max, avg). */
+int edvr_pool_maxavg_3x3s2_f32(const float *x, float *y, int n, int c, int h, int w, edvr_stream_t stream);
+/* nn.Upsample(scale_factor=2, bilinear, align_corners=False); y = scale * up(x). */
+int edvr_upsample2x_f32(const float *x, float *y, int nc, int h, int w, float scale, edvr_stream_t stream);
+/* y = feat * sigmoid(attn) * 2 + attn_add  (edvr_arch.py:210-213). */
+int edvr_tsa_combine_f32(const float *feat, const float *attn, const float *attn_add, float *y, int64_t numel,
+                         edvr_stream_t stream);
+/* y += bilinear x4 (align_corners=False) of base (n, c, h, w); y is (n, c, 4h, 4w)  (edvr_arch.py:417-419). */
+int edvr_upsample4x_add_f32(const float *base, float *y, int nc, int h, int w, edvr_stream_t stream);
+/* y = a + b */
+int edvr_add_f32(const float *a, const float *b, float *y, int64_t numel, edvr_stream_t stream);
+/* dz = dy * act'(.) expressed through the activation OUTPUT y (relu: y>0; lrelu: y>0 ? 1 : 0.1;
+ * sigmoid: y(1-y)); channels < act_from of an (n, c, hw) tensor pass through unchanged. */
+int edvr_act_bwd_f32(const float *dy, const float *y, float *dz, int n, int c, int64_t hw, int act, int act_from,
+                     edvr_stream_t stream);
+/* out[i] = sum |x[i, :per_img]| for each of n images (image stride img_stride) - feeds the
+ * "offset abs mean > 50" warning of arch_util.py:248-253 without a per-call host sync. */
+int edvr_abs_sum_f32(const float *x, float *out, int n, int64_t per_img, int64_t img_stride, edvr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EDVR_AMD_H */

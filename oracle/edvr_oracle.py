@@ -1,0 +1,186 @@
+"""TEST INFRASTRUCTURE ONLY - CPU oracle of the whole EDVR forward, functional style.
+
+A state_dict-driven restatement of the reference network in stock torch ops,
+with the DCNv2 op supplied by oracle/dcn_oracle.py.  It exists because
+/root/reference cannot travel to the GPU box: tests there compare the HIP path
+against THIS, and tests here (tests/test_oracle_edvr.py) pin THIS against the
+reference's own Python imported unchanged (oracle/ref_import.py) and against
+tests/golden/.
+
+Follows (paths relative to /root/reference/basicsr/models/archs/):
+  edvr_arch.py:358-420  EDVR.forward            -> edvr_forward
+  edvr_arch.py:72-117   PCDAlignment.forward    -> pcd_align
+  edvr_arch.py:161-214  TSAFusion.forward       -> tsa_fusion
+  edvr_arch.py:250-269  PredeblurModule.forward -> predeblur
+  arch_util.py:92-95    ResidualBlockNoBN       -> resblock
+  arch_util.py:243-257  DCNv2Pack.forward       -> dcn_pack
+
+`sd` is a state_dict with the reference's key names; `taps`, if given, collects
+named intermediates for parity checks beyond the final output.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import dcn_oracle
+
+
+def _conv(sd, name, x, stride=1, padding=None):
+    w = sd[name + '.weight']
+    pad = (w.shape[-1] // 2) if padding is None else padding
+    return F.conv2d(x, w, sd.get(name + '.bias'), stride, pad)
+
+
+def _lrelu(x):
+    return F.leaky_relu(x, 0.1)
+
+
+def _up2(x):
+    return F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
+
+
+def resblock(sd, name, x):
+    return x + _conv(sd, name + '.conv2', F.relu(_conv(sd, name + '.conv1', x)))
+
+
+def dcn_pack(sd, name, x, feat, dg, dcn, stats=None):
+    out = _conv(sd, name + '.conv_offset', feat)
+    k3 = out.shape[1] // 3
+    offset, mask = out[:, :2 * k3], torch.sigmoid(out[:, 2 * k3:])
+    if stats is not None:
+        stats.append(offset.abs().mean().item())
+    return dcn(x, offset.contiguous(), mask.contiguous(), sd[name + '.weight'], sd.get(name + '.bias'), 1, 1, 1, 1, dg)
+
+
+def pcd_align(sd, pre, nbr, ref, dg, dcn, stats=None):
+    """nbr/ref: [L1, L2, L3] feature lists, each (n, C, h, w)."""
+    up_off = up_feat = feat = None
+    for lv in (3, 2, 1):
+        L = f'l{lv}'
+        off = _lrelu(_conv(sd, f'{pre}offset_conv1.{L}', torch.cat([nbr[lv - 1], ref[lv - 1]], 1)))
+        if lv == 3:
+            off = _lrelu(_conv(sd, f'{pre}offset_conv2.{L}', off))
+        else:
+            off = _lrelu(_conv(sd, f'{pre}offset_conv2.{L}', torch.cat([off, up_off], 1)))
+            off = _lrelu(_conv(sd, f'{pre}offset_conv3.{L}', off))
+        feat = dcn_pack(sd, f'{pre}dcn_pack.{L}', nbr[lv - 1], off, dg, dcn, stats)
+        if lv < 3:
+            feat = _conv(sd, f'{pre}feat_conv.{L}', torch.cat([feat, up_feat], 1))
+        if lv > 1:
+            feat = _lrelu(feat)
+            up_off = _up2(off) * 2
+            up_feat = _up2(feat)
+    off = torch.cat([feat, ref[0]], 1)
+    off = _lrelu(_conv(sd, f'{pre}cas_offset_conv2', _lrelu(_conv(sd, f'{pre}cas_offset_conv1', off))))
+    return _lrelu(dcn_pack(sd, f'{pre}cas_dcnpack', feat, off, dg, dcn, stats))
+
+
+def tsa_fusion(sd, pre, aligned, center, taps=None):
+    b, t, c, h, w = aligned.shape
+    emb_ref = _conv(sd, pre + 'temporal_attn1', aligned[:, center])
+    emb = _conv(sd, pre + 'temporal_attn2', aligned.reshape(-1, c, h, w)).view(b, t, -1, h, w)
+    prob = torch.sigmoid((emb * emb_ref.unsqueeze(1)).sum(2))  # (b, t, h, w)
+    al = (aligned * prob.unsqueeze(2)).reshape(b, t * c, h, w)
+    if taps is not None:
+        taps['tsa_modulated'] = al
+    feat = _lrelu(_conv(sd, pre + 'feat_fusion', al))
+    attn = _lrelu(_conv(sd, pre + 'spatial_attn1', al))
+    pooled = torch.cat([F.max_pool2d(attn, 3, 2, 1), F.avg_pool2d(attn, 3, 2, 1)], 1)
+    attn = _lrelu(_conv(sd, pre + 'spatial_attn2', pooled))
+    lvl = _lrelu(_conv(sd, pre + 'spatial_attn_l1', attn))
+    pooled = torch.cat([F.max_pool2d(lvl, 3, 2, 1), F.avg_pool2d(lvl, 3, 2, 1)], 1)
+    lvl = _lrelu(_conv(sd, pre + 'spatial_attn_l2', pooled))
+    lvl = _up2(_lrelu(_conv(sd, pre + 'spatial_attn_l3', lvl)))
+    attn = _lrelu(_conv(sd, pre + 'spatial_attn3', attn)) + lvl
+    attn = _up2(_lrelu(_conv(sd, pre + 'spatial_attn4', attn)))
+    attn = _conv(sd, pre + 'spatial_attn5', attn)
+    attn_add = _conv(sd, pre + 'spatial_attn_add2', _lrelu(_conv(sd, pre + 'spatial_attn_add1', attn)))
+    return feat * torch.sigmoid(attn) * 2 + attn_add
+
+
+def predeblur(sd, pre, x, hr_in):
+    f1 = _lrelu(_conv(sd, pre + 'conv_first', x))
+    if hr_in:
+        f1 = _lrelu(_conv(sd, pre + 'stride_conv_hr1', f1, 2))
+        f1 = _lrelu(_conv(sd, pre + 'stride_conv_hr2', f1, 2))
+    f2 = _lrelu(_conv(sd, pre + 'stride_conv_l2', f1, 2))
+    f3 = _lrelu(_conv(sd, pre + 'stride_conv_l3', f2, 2))
+    f3 = _up2(resblock(sd, pre + 'resblock_l3', f3))
+    f2 = resblock(sd, pre + 'resblock_l2_1', f2) + f3
+    f2 = _up2(resblock(sd, pre + 'resblock_l2_2', f2))
+    for i in range(2):
+        f1 = resblock(sd, f'{pre}resblock_l1.{i}', f1)
+    f1 = f1 + f2
+    for i in range(2, 5):
+        f1 = resblock(sd, f'{pre}resblock_l1.{i}', f1)
+    return f1
+
+
+def _count(sd, prefix):
+    idx = {int(k[len(prefix):].split('.')[0]) for k in sd if k.startswith(prefix)}
+    return (max(idx) + 1) if idx else 0
+
+
+def edvr_forward(sd, x, center=None, hr_in=False, with_predeblur=False, with_tsa=True, dg=8, dcn=None, taps=None,
+                 stats=None):
+    """x: (b, t, 3, h, w) -> (b, 3, 4h, 4w)  [or (b, 3, h, w) when hr_in]."""
+    dcn = dcn or dcn_oracle.dcnv2_c
+    b, t, c, h, w = x.shape
+    center = t // 2 if center is None else center
+    xc = x[:, center].contiguous()
+    if with_predeblur:
+        f1 = _conv(sd, 'conv_1x1', predeblur(sd, 'predeblur.', x.reshape(-1, c, h, w), hr_in))
+        if hr_in:
+            h, w = h // 4, w // 4
+    else:
+        f1 = _lrelu(_conv(sd, 'conv_first', x.reshape(-1, c, h, w)))
+    for i in range(_count(sd, 'feature_extraction.')):
+        f1 = resblock(sd, f'feature_extraction.{i}', f1)
+    f2 = _lrelu(_conv(sd, 'conv_l2_2', _lrelu(_conv(sd, 'conv_l2_1', f1, 2))))
+    f3 = _lrelu(_conv(sd, 'conv_l3_2', _lrelu(_conv(sd, 'conv_l3_1', f2, 2))))
+    f1 = f1.view(b, t, -1, h, w)
+    f2 = f2.view(b, t, -1, h // 2, w // 2)
+    f3 = f3.view(b, t, -1, h // 4, w // 4)
+    ref = [f1[:, center], f2[:, center], f3[:, center]]
+    aligned = torch.stack(
+        [pcd_align(sd, 'pcd_align.', [f1[:, i], f2[:, i], f3[:, i]], ref, dg, dcn, stats) for i in range(t)], 1)
+    if taps is not None:
+        taps['aligned'] = aligned
+    if with_tsa:
+        feat = tsa_fusion(sd, 'fusion.', aligned, center, taps)
+    else:
+        feat = _conv(sd, 'fusion', aligned.reshape(b, -1, h, w))
+    if taps is not None:
+        taps['fused'] = feat
+    out = feat
+    for i in range(_count(sd, 'reconstruction.')):
+        out = resblock(sd, f'reconstruction.{i}', out)
+    if taps is not None:
+        taps['trunk'] = out
+    out = _lrelu(F.pixel_shuffle(_conv(sd, 'upconv1', out), 2))
+    out = _lrelu(F.pixel_shuffle(_conv(sd, 'upconv2', out), 2))
+    out = _conv(sd, 'conv_last', _lrelu(_conv(sd, 'conv_hr', out)))
+    base = xc if hr_in else F.interpolate(xc, scale_factor=4, mode='bilinear', align_corners=False)
+    return out + base
+
+
+def tensor2img_uint8(t):
+    """basicsr/utils/img_util.py:67,93 restated: clamp [0,1] -> x255 -> round -> uint8 (layout kept CHW)."""
+    return (t.detach().float().clamp(0, 1) * 255.0).round().to(torch.uint8)
+
+
+def psnr_uint8(a, b):
+    """basicsr/metrics/psnr_ssim.py:37-51 restated (crop_border 0, float64 MSE over all elements)."""
+    mse = ((a.to(torch.float64) - b.to(torch.float64)) ** 2).mean().item()
+    if mse == 0:
+        return float('inf')
+    import math
+    return 20.0 * math.log10(255.0 / math.sqrt(mse))
+
+
+def psnr(pred, gt):
+    return psnr_uint8(tensor2img_uint8(pred), tensor2img_uint8(gt))
+
+
+def charbonnier_sum(pred, target, eps=1e-12):
+    """basicsr/models/losses/losses.py:23-25 with reduction='sum'."""
+    return torch.sqrt((pred - target) ** 2 + eps).sum()

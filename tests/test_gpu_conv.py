@@ -1,0 +1,94 @@
+"""-m gpu: the fp32 MFMA conv kernel (through the C ABI) against torch's CPU conv in fp64."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+# fp32 MFMA is a k-ordered fmaf chain: error ~1e-7 * sum|a*b|; tolerance relative to the output scale
+RTOL = 2e-5
+
+
+def _rel(a, ref):
+    return ((a.double().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+CASES = [
+    # n, c1, c2, h, w, co, ks, stride, act, res, out_mode
+    (2, 64, 0, 16, 16, 64, 3, 1, 'lrelu', 0, 0),
+    (1, 128, 0, 45, 80, 128, 3, 1, 'relu', 1, 0),
+    (2, 3, 0, 20, 36, 64, 3, 1, 'lrelu', 0, 0),
+    (1, 64, 64, 23, 41, 64, 3, 1, 'lrelu', 0, 0),
+    (2, 64, 0, 32, 32, 64, 3, 2, 'lrelu', 0, 0),
+    (1, 128, 0, 45, 81, 128, 3, 2, 'none', 0, 0),
+    (1, 320, 0, 24, 40, 64, 1, 1, 'lrelu', 0, 0),
+    (1, 64, 0, 16, 48, 216, 3, 1, 'sigmoid_from', 0, 0),
+    (1, 64, 0, 12, 20, 256, 3, 1, 'lrelu', 0, 1),
+    (1, 64, 0, 40, 72, 3, 3, 1, 'none', 2, 0),
+    (3, 40, 24, 9, 7, 48, 3, 1, 'none', 2, 0),
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_conv2d_matches_fp64(gpu, case):
+    from edvr_amd import ops
+    n, c1, c2, h, w, co, ks, stride, actn, nres, out_mode = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x1 = torch.randn(n, c1, h, w, generator=g)
+    x2 = torch.randn(n, c2, h, w, generator=g) if c2 else None
+    wt = torch.randn(co, c1 + c2, ks, ks, generator=g) * 0.1
+    b = torch.randn(co, generator=g)
+    xin = x1 if x2 is None else torch.cat([x1, x2], 1)
+    ref = F.conv2d(xin.double(), wt.double(), b.double(), stride, ks // 2)
+    act, act_from = {'none': (0, 0), 'relu': (1, 0), 'lrelu': (2, 0), 'sigmoid_from': (3, 2 * co // 3)}[actn]
+    if actn == 'relu':
+        ref = F.relu(ref)
+    elif actn == 'lrelu':
+        ref = F.leaky_relu(ref, 0.1)
+    elif actn == 'sigmoid_from':
+        ref = torch.cat([ref[:, :act_from], torch.sigmoid(ref[:, act_from:])], 1)
+    res = [torch.randn(ref.shape, generator=g) for _ in range(nres)]
+    for r in res:
+        ref = ref + r.double()
+    if out_mode == 1:
+        ref = F.pixel_shuffle(ref, 2)
+    wpk = ops.pack_conv_weight(wt.to(gpu))
+    y = ops.conv2d(x1.to(gpu), wpk, b.to(gpu), co, ks, x2=None if x2 is None else x2.to(gpu), stride=stride, act=act,
+                   act_from=act_from, res1=res[0].to(gpu) if nres > 0 else None, res2=res[1].to(gpu) if nres > 1 else None,
+                   out_mode=out_mode)
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape
+    assert _rel(y, ref) < RTOL
+
+
+def test_conv2d_x2_image_map_and_strided_views(gpu):
+    """cat(nbr, ref[clip centre]) without materialising either: x2 image map + channel-sliced input view."""
+    from edvr_amd import ops
+    g = torch.Generator().manual_seed(5)
+    b, t, c, h, w, ctr = 2, 3, 32, 12, 20, 1
+    feat = torch.randn(b * t, c, h, w, generator=g)
+    wt = torch.randn(48, 2 * c, 3, 3, generator=g) * 0.1
+    ref_in = torch.cat([feat, feat.view(b, t, c, h, w)[:, ctr:ctr + 1].expand(b, t, c, h, w).reshape(b * t, c, h, w)], 1)
+    ref = F.conv2d(ref_in.double(), wt.double(), None, 1, 1)
+    fg = feat.to(gpu)
+    y = ops.conv2d(fg, ops.pack_conv_weight(wt.to(gpu)), None, 48, 3, x2=fg, x2_map=(t, t, ctr))
+    assert _rel(y, ref) < RTOL
+    # channel-sliced view as input (image stride larger than c*h*w)
+    big = torch.randn(2, 96, h, w, generator=g)
+    wt2 = torch.randn(32, 64, 3, 3, generator=g) * 0.1
+    ref2 = F.conv2d(big[:, :64].double(), wt2.double(), None, 1, 1)
+    y2 = ops.conv2d(big.to(gpu)[:, :64], ops.pack_conv_weight(wt2.to(gpu)), None, 32, 3)
+    assert _rel(y2, ref2) < RTOL
+
+
+def test_transpose_flip_pack_is_data_gradient(gpu):
+    """conv with the transpose_flip packing == d/dx of the stride-1 conv."""
+    from edvr_amd import ops
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(1, 24, 10, 14, generator=g, dtype=torch.float64, requires_grad=True)
+    wt = torch.randn(40, 24, 3, 3, generator=g, dtype=torch.float64) * 0.1
+    dy = torch.randn(1, 40, 10, 14, generator=g, dtype=torch.float64)
+    F.conv2d(x, wt, None, 1, 1).backward(dy)
+    wpk = ops.pack_conv_weight(wt.float().to(gpu), transpose_flip=True)
+    dx = ops.conv2d(dy.float().to(gpu), wpk, None, 24, 3)
+    assert _rel(dx, x.grad) < RTOL

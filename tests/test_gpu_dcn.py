@@ -1,0 +1,108 @@
+"""-m gpu: DCNv2 forward/backward through the C ABI against the CPU oracle (fp64 truth)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+FWD_RTOL = 2e-5   # fp32 vs fp64 oracle, relative to max|y|
+BWD_RTOL = 1e-4   # gradients (dX goes through fp32 atomics, order not deterministic)
+
+
+def _mk(B, C, H, W, Co, k, stride, pad, dil, groups, dg, sigma, seed, integer=False, half=False):
+    from oracle import dcn_oracle as O
+    g = torch.Generator().manual_seed(seed)
+    Ho, Wo = O._out_hw(H, W, k, k, stride, pad, dil)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(Co, C // groups, k, k, generator=g) * 0.1
+    b = torch.randn(Co, generator=g)
+    off = torch.randn(B, dg * 2 * k * k, Ho, Wo, generator=g) * sigma
+    if integer:
+        off = off.round()
+    if half:
+        off = off.round() + 0.5
+    m = torch.rand(B, dg * k * k, Ho, Wo, generator=g)
+    dy = torch.randn(B, Co, Ho, Wo, generator=g)
+    return x, off, m, w, b, dy
+
+
+def _rel(a, ref):
+    return ((a.double().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+CASES = [
+    # B, C, H, W, Co, k, stride, pad, dil, groups, dg, sigma, kwargs
+    (2, 64, 16, 16, 64, 3, 1, 1, 1, 1, 8, 1.0, {}),
+    (1, 128, 23, 37, 128, 3, 1, 1, 1, 1, 8, 2.0, {}),
+    (1, 64, 16, 20, 64, 3, 1, 1, 1, 1, 8, 0.0, {}),                 # zero offsets: integer grid (fresh model)
+    (1, 64, 12, 12, 64, 3, 1, 1, 1, 1, 8, 2.0, {'integer': True}),  # integer taps: one-sided derivative
+    (1, 64, 12, 12, 64, 3, 1, 1, 1, 1, 8, 2.0, {'half': True}),
+    (1, 64, 12, 16, 64, 3, 1, 1, 1, 1, 8, 16.0, {}),                # mostly out of bounds
+    (2, 16, 9, 11, 24, 3, 2, 1, 1, 2, 4, 1.5, {}),                  # generic: stride 2, groups 2, dg 4
+    (1, 8, 10, 10, 12, 3, 1, 2, 2, 1, 2, 3.0, {}),                  # dilation 2
+    (1, 12, 7, 9, 10, 1, 1, 0, 1, 1, 3, 1.0, {}),                   # 1x1 kernel, unaligned channel counts
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_dcnv2_forward_backward_vs_oracle(gpu, case):
+    from edvr_amd import ops
+    from oracle import dcn_oracle as O
+    *dims, kw = case
+    B, C, H, W, Co, k, stride, pad, dil, groups, dg, sigma = dims
+    x, off, m, w, b, dy = _mk(*dims, seed=len(str(case)), **kw)
+    cfg = (stride, pad, dil, groups, dg)
+    ref_y = O.c_forward(x.double(), off.double(), m.double(), w.double(), b.double(), *cfg)
+    ref_g = O.c_backward(x.double(), off.double(), m.double(), w.double(), dy.double(), True, *cfg)
+    xg, og, mg, wg, bg, dyg = (t.to(gpu) for t in (x, off, m, w, b, dy))
+    y = ops.dcnv2_forward(xg, og, mg, wg, bg, *cfg)
+    grads = ops.dcnv2_backward(xg, og, mg, wg, dyg, True, *cfg)
+    torch.cuda.synchronize()
+    assert _rel(y, ref_y) < FWD_RTOL
+    for name, a, r in zip(('dx', 'doffset', 'dmask', 'dweight', 'dbias'), grads, ref_g):
+        assert _rel(a, r) < BWD_RTOL, name
+
+
+def test_dcnv2_zero_offset_unit_mask_is_conv2d(gpu):
+    """Independent anchor: zero offsets + unit mask must reduce to an ordinary convolution."""
+    import torch.nn.functional as F
+    from edvr_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 64, 20, 24, generator=g)
+    w = torch.randn(64, 64, 3, 3, generator=g) * 0.1
+    b = torch.randn(64, generator=g)
+    off = torch.zeros(2, 144, 20, 24)
+    m = torch.ones(2, 72, 20, 24)
+    y = ops.dcnv2_forward(*(t.to(gpu) for t in (x, off, m, w, b)), 1, 1, 1, 1, 8)
+    ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
+    assert _rel(y, ref) < FWD_RTOL
+
+
+def test_autograd_function_and_strided_offset_views(gpu):
+    """modulated_deform_conv autograd == oracle autograd; offset/mask given as channel slices of one tensor."""
+    from edvr_amd import modulated_deform_conv
+    from oracle import dcn_oracle as O
+    g = torch.Generator().manual_seed(4)
+    B, C, H, W = 2, 64, 14, 18
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) * 0.1
+    b = torch.randn(C, generator=g)
+    om = torch.randn(B, 216, H, W, generator=g)
+    om[:, 144:] = torch.sigmoid(om[:, 144:])
+    dy = torch.randn(B, C, H, W, generator=g)
+    cpu = [t.double().requires_grad_() for t in (x, om, w, b)]
+    yo = O.dcnv2_torch(cpu[0], cpu[1][:, :144], cpu[1][:, 144:], cpu[2], cpu[3], 1, 1, 1, 1, 8)
+    yo.backward(dy.double())
+    dev = [t.to(gpu).requires_grad_() for t in (x, om, w, b)]
+    y = modulated_deform_conv(dev[0], dev[1][:, :144], dev[1][:, 144:], dev[2], dev[3], 1, 1, 1, 1, 8)
+    y.backward(dy.to(gpu))
+    assert _rel(y.detach(), yo.detach()) < FWD_RTOL
+    for a, r in zip(dev, cpu):
+        assert _rel(a.grad, r.grad) < BWD_RTOL
+
+
+def test_cpu_tensor_is_refused():
+    """Same behaviour as the reference op (deform_conv.py:133-134): no CPU path."""
+    from edvr_amd import modulated_deform_conv
+    x = torch.randn(1, 8, 6, 6)
+    with pytest.raises(NotImplementedError):
+        modulated_deform_conv(x, torch.zeros(1, 18, 6, 6), torch.ones(1, 9, 6, 6), torch.randn(8, 8, 3, 3), None, 1, 1, 1, 1, 1)

@@ -1,0 +1,58 @@
+"""-m gpu: whole-network parity of the HIP EDVR against the CPU oracle on identical weights/inputs."""
+import pytest
+import torch
+
+from util_edvr import CONFIGS, build, oracle_kwargs
+
+pytestmark = pytest.mark.gpu
+
+INTERMEDIATE_RTOL = 2e-4   # fp32 HIP vs fp64 oracle on aligned / fused / trunk features, relative to max|ref|
+PSNR_TOL_DB = 1e-3         # north_star: outputs within 1e-3 dB PSNR (fp32)
+
+
+def _rel(a, ref):
+    return ((a.double().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize('name', list(CONFIGS))
+def test_edvr_forward_matches_oracle(gpu, name):
+    from oracle import edvr_oracle as EO
+    net, x, kwargs = build(name)
+    sd64 = {k: v.double() for k, v in net.state_dict().items()}
+    taps_ref = {}
+    with torch.no_grad():
+        ref = EO.edvr_forward(sd64, x.double(), taps=taps_ref, **oracle_kwargs(kwargs))
+        net = net.to(gpu)
+        net.taps = {}
+        out = net(x.to(gpu))
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape
+    for key in ('aligned', 'fused', 'trunk'):
+        assert _rel(net.taps[key].reshape(taps_ref[key].shape), taps_ref[key]) < INTERMEDIATE_RTOL, key
+    assert _rel(out, ref) < INTERMEDIATE_RTOL
+    gt = torch.rand(ref.shape, generator=torch.Generator().manual_seed(1))
+    p_ours, p_ref = EO.psnr(out.cpu(), gt), EO.psnr(ref.float(), gt)
+    assert abs(p_ours - p_ref) <= PSNR_TOL_DB, (p_ours, p_ref)
+
+
+def test_pcd_and_tsa_public_forward(gpu):
+    """The reference-style entry points: PCDAlignment.forward(nbr_l, ref_l), TSAFusion.forward(aligned)."""
+    from edvr_amd import PCDAlignment, TSAFusion
+    from oracle import edvr_oracle as EO
+    from util_edvr import randomize_offsets
+    torch.manual_seed(3)
+    pcd = randomize_offsets(PCDAlignment(num_feat=64, deformable_groups=8)).eval()
+    tsa = TSAFusion(num_feat=64, num_frame=3, center_frame_idx=1).eval()
+    g = torch.Generator().manual_seed(2)
+    nbr = [torch.randn(2, 64, 32 >> i, 48 >> i, generator=g) for i in range(3)]
+    ref = [torch.randn(2, 64, 32 >> i, 48 >> i, generator=g) for i in range(3)]
+    al = torch.randn(2, 3, 64, 16, 24, generator=g)
+    with torch.no_grad():
+        sd = {'p.' + k: v.double() for k, v in pcd.state_dict().items()}
+        want = EO.pcd_align(sd, 'p.', [t.double() for t in nbr], [t.double() for t in ref], 8, EO.dcn_oracle.dcnv2_c)
+        got = pcd.to(gpu)([t.to(gpu) for t in nbr], [t.to(gpu) for t in ref])
+        assert _rel(got, want) < INTERMEDIATE_RTOL
+        sd = {'f.' + k: v.double() for k, v in tsa.state_dict().items()}
+        want = EO.tsa_fusion(sd, 'f.', al.double(), 1)
+        got = tsa.to(gpu)(al.to(gpu))
+        assert _rel(got, want) < INTERMEDIATE_RTOL

@@ -1,0 +1,59 @@
+"""-m gpu: the bandwidth-bound glue kernels against stock torch ops on the CPU (fp64)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-6  # elementwise fp32 work: a few ulps, relative to max|ref|
+
+
+def _rel(a, ref):
+    return ((a.double().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize('shape', [(2, 5, 64, 16, 16), (1, 7, 128, 9, 20), (1, 3, 8, 5, 7)])
+def test_tsa_temporal(gpu, shape):
+    from edvr_amd import ops
+    b, t, c, h, w = shape
+    g = torch.Generator().manual_seed(1)
+    emb, al = torch.randn(shape, generator=g) * 0.3, torch.randn(shape, generator=g)
+    er = torch.randn(b, c, h, w, generator=g) * 0.3
+    prob = torch.sigmoid((emb.double() * er.double().unsqueeze(1)).sum(2))
+    ref = al.double() * prob.unsqueeze(2)
+    out, p = ops.tsa_temporal(emb.to(gpu), er.to(gpu), al.to(gpu), want_prob=True)
+    assert _rel(out, ref) < 1e-5 and _rel(p, prob) < 1e-5
+
+
+@pytest.mark.parametrize('hw', [(16, 16), (45, 80), (9, 7)])
+def test_pool_maxavg(gpu, hw):
+    from edvr_amd import ops
+    x = torch.randn(2, 6, *hw, generator=torch.Generator().manual_seed(2))
+    ref = torch.cat([F.max_pool2d(x.double(), 3, 2, 1), F.avg_pool2d(x.double(), 3, 2, 1)], 1)
+    assert _rel(ops.pool_maxavg(x.to(gpu)), ref) < TOL
+
+
+@pytest.mark.parametrize('hw', [(8, 8), (45, 80), (5, 3)])
+def test_upsample2x_and_4x_add(gpu, hw):
+    from edvr_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 3, *hw, generator=g)
+    ref2 = F.interpolate(x.double(), scale_factor=2, mode='bilinear', align_corners=False) * 2
+    assert _rel(ops.upsample2x(x.to(gpu), 2.0), ref2) < TOL
+    y = torch.randn(2, 3, 4 * hw[0], 4 * hw[1], generator=g)
+    ref4 = y.double() + F.interpolate(x.double(), scale_factor=4, mode='bilinear', align_corners=False)
+    assert _rel(ops.upsample4x_add_(y.to(gpu), x.to(gpu)), ref4) < TOL
+
+
+def test_combine_add_abs_sum_act_bwd(gpu):
+    from edvr_amd import ops
+    g = torch.Generator().manual_seed(4)
+    a, b, c = (torch.randn(2, 8, 6, 10, generator=g) for _ in range(3))
+    assert _rel(ops.tsa_combine(a.to(gpu), b.to(gpu), c.to(gpu)), a.double() * torch.sigmoid(b.double()) * 2 + c.double()) < 1e-5
+    assert _rel(ops.add(a.to(gpu), b.to(gpu)), a.double() + b.double()) < TOL
+    big = torch.randn(3, 12, 6, 10, generator=g)
+    assert _rel(ops.abs_sum_per_image(big.to(gpu)[:, :8]), big[:, :8].double().abs().sum((1, 2, 3))) < 1e-5
+    y = F.leaky_relu(a, 0.1)
+    assert _rel(ops.act_backward(b.to(gpu), y.to(gpu), ops.ACT_LRELU), torch.where(a > 0, b, 0.1 * b).double()) < TOL
+    s = torch.sigmoid(a)
+    ref = torch.cat([b[:, :5], (b * s * (1 - s))[:, 5:]], 1).double()
+    assert _rel(ops.act_backward(b.to(gpu), s.to(gpu), ops.ACT_SIGMOID, act_from=5), ref) < 1e-5
