@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libedvr_amd.so')
+LIB_PATH = os.environ.get('EDVR_AMD_LIB') or os.path.join(_HERE, 'lib', 'libedvr_amd.so')  # env: A/B kernel variants
 
 c_float_p = ctypes.c_void_p
 i32, i64, f32, sz = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
@@ -33,6 +33,7 @@ PROTOTYPES = {
     'edvr_conv2d_packed_weight_elems': (sz, [i32, i32, i32]),
     'edvr_conv2d_pack_weight_f32': (i32, [vp, vp, i32, i32, i32, i32, vp]),
     'edvr_conv2d_f32': (i32, [ctypes.POINTER(ConvDesc), vp]),
+    'edvr_conv2d_kernel_name': (i32, [ctypes.POINTER(ConvDesc), ctypes.c_char_p, sz]),
     'edvr_dcnv2_fwd_ws_bytes': (sz, [i32] * 12),
     'edvr_dcnv2_fwd_f32': (i32, [vp] * 6 + [i32] * 12 + [i64, i64, i32, vp, sz, vp]),
     'edvr_dcnv2_bwd_ws_bytes': (sz, [i32] * 12),

@@ -26,51 +26,53 @@
 namespace edvr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvArgs {
   edvr_conv2d_desc d;
   int ci, cop, ho, wo, tiles_x, tiles_y;
+  int co_start;  // first output channel of this launch (tail launches cover the last partial 128-block)
 };
 
-__device__ __forceinline__ float apply_act(float v, int act) {
-  switch (act) {
-    case EDVR_ACT_RELU: return v > 0.f ? v : 0.f;
-    case EDVR_ACT_LRELU: return v > 0.f ? v : 0.1f * v;
-    case EDVR_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
-    default: return v;
-  }
-}
+__device__ __forceinline__ float sigmoid_fast(float v) { return __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
 
-template <int KS, int STRIDE>
-struct ConvGeom {
-  static constexpr int CK = (STRIDE == 2) ? 8 : 16;  // input channels staged per chunk
+template <int KS>
+struct ConvChunk {
+  static constexpr int CK = (KS == 1) ? 32 : 8;  // input channels staged per chunk (K per chunk = CK * KS * KS)
 };
+
+#ifndef EDVR_CONV_MINWAVES
+#define EDVR_CONV_MINWAVES 2
+#endif
 
 template <int KS, int STRIDE, int MT, int SW>
-__global__ __launch_bounds__(256) void conv2d_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, EDVR_CONV_MINWAVES) void conv2d_mfma_kernel(const ConvArgs a) {
   constexpr int SH = 32 / SW;        // rows of one 32-pixel subtile
   constexpr int NSUB = 2;            // subtiles per wave
   constexpr int TW = SW;             // output tile width
   constexpr int TH = 4 * NSUB * SH;  // output tile height (4 waves)
   constexpr int IW = (TW - 1) * STRIDE + KS;
   constexpr int IH = (TH - 1) * STRIDE + KS;
-  constexpr int RS = IW;       // LDS row stride (floats)
-  constexpr int CHS = IH * RS; // LDS channel stride
-  constexpr int CK = ConvGeom<KS, STRIDE>::CK;
+  constexpr int RS = IW;        // LDS row stride (floats)
+  constexpr int CHS = IH * RS;  // LDS channel stride
+  constexpr int CK = ConvChunk<KS>::CK;
   constexpr int KK = KS * KS;
   constexpr int PAD = KS / 2;
+  constexpr int MB = 32 * MT;         // output channels of this workgroup
+  constexpr int WROWS = CK * KK;      // weight rows per chunk, each MB floats
+  constexpr int XS_ELEMS = (CK * CHS + 3) / 4 * 4;
 
-  __shared__ float xs[CK * CHS];
+  __shared__ __attribute__((aligned(16))) float smem[XS_ELEMS + WROWS * MB];
+  float *xs = smem;
+  float *wsm = smem + XS_ELEMS;
 
   const edvr_conv2d_desc &d = a.d;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, j = lane & 31;
   const int tile = blockIdx.x;
   const int ty0 = (tile / a.tiles_x) * TH, tx0 = (tile % a.tiles_x) * TW;
-  const int co_blk = blockIdx.y * (32 * MT);
+  const int co_blk = a.co_start + blockIdx.y * MB;
   const int img = blockIdx.z;
-  int mt_count = (d.co - co_blk + 31) / 32;
-  if (mt_count > MT) mt_count = MT;
 
   const float *x1 = d.x1 + (int64_t)img * d.x1_img_stride;
   const float *x2 = nullptr;
@@ -80,13 +82,14 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(const ConvArgs a) {
   }
   const int hw = d.h * d.w;
 
-  // per-lane LDS read bases (floats) of the two subtiles
+  // per-lane LDS read bases (floats): B operand (pixels) of the two subtiles, A operand (weights)
   int bbase[NSUB];
 #pragma unroll
   for (int s = 0; s < NSUB; ++s) {
     const int r = (wave * NSUB + s) * SH + j / SW, c = j % SW;
     bbase[s] = half * CHS + (r * STRIDE) * RS + c * STRIDE;
   }
+  const int abase = half * KK * MB + j;
 
   f32x16 acc[MT][NSUB];
 #pragma unroll
@@ -98,77 +101,161 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(const ConvArgs a) {
 
   const int iy0 = ty0 * STRIDE - PAD, ix0 = tx0 * STRIDE - PAD;
 
-  for (int c0 = 0; c0 < a.ci; c0 += CK) {
-    __syncthreads();
-    // ---- stage CK channels of the input halo tile (zero outside the image / past ci)
-    for (int e = tid; e < CK * CHS; e += 256) {
-      const int ch = e / CHS, rem = e - ch * CHS;
-      const int iy = rem / RS, ix = rem - iy * RS;
-      const int gy = iy0 + iy, gx = ix0 + ix, c = c0 + ch;
-      float v = 0.f;
-      if (c < a.ci && gy >= 0 && gy < d.h && gx >= 0 && gx < d.w) {
-        const float *src = (c < d.c1) ? (x1 + (int64_t)c * hw) : (x2 + (int64_t)(c - d.c1) * hw);
-        v = src[gy * d.w + gx];
-      }
-      xs[e] = v;
+  // ---- software pipeline: the global loads of chunk c+1 are issued into registers BEFORE the MFMA
+  //      block of chunk c and land in LDS after it, so HBM/L2 latency hides under ~18k MFMA cycles.
+  // Every load is unconditional (clamped address, value selected afterwards): a predicated load would
+  // put each one in its own basic block and serialise the stream.
+  constexpr int NXK = (CHS + 255) / 256;          // plane positions per thread (channel index is compile-time)
+  constexpr int V4_PER_ROW = MB / 4;              // float4 per weight row
+  constexpr int ROWS_PER_PASS = 256 / V4_PER_ROW; // weight rows covered by the 256 threads in one pass
+  constexpr int NW = (WROWS + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
+  int xoff[NXK];  // offset inside one channel plane, -1 where the halo leaves the image
+#pragma unroll
+  for (int k = 0; k < NXK; ++k) {
+    const int p = tid + k * 256;
+    const int iy = p / RS, ix = p - iy * RS;
+    const int gy = iy0 + iy, gx = ix0 + ix;
+    xoff[k] = (p < CHS && gy >= 0 && gy < d.h && gx >= 0 && gx < d.w) ? gy * d.w + gx : -1;
+  }
+  const int wrow0 = tid / V4_PER_ROW, wc4 = tid - wrow0 * V4_PER_ROW;
+  const bool w_active = wrow0 < ROWS_PER_PASS;
+  const int woff0 = w_active ? wrow0 * a.cop + wc4 * 4 : 0;
+  float xr[CK * NXK];
+  f32x4 wr[NW];
+  auto prefetch = [&](int c0) {
+    const float *wsrc = d.wpk + (int64_t)c0 * KK * a.cop + co_blk + woff0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const bool ok = (i + 1) * ROWS_PER_PASS <= WROWS || wrow0 + i * ROWS_PER_PASS < WROWS;
+      wr[i] = *reinterpret_cast<const f32x4 *>(wsrc + (ok ? i * ROWS_PER_PASS * a.cop : 0));
     }
-    __syncthreads();
-    // ---- MFMA over (channel pair, tap)
-    const float *wp = d.wpk + ((int64_t)(c0 + half) * KK) * a.cop + co_blk + j;
-#pragma unroll 2
+#pragma unroll
+    for (int ch = 0; ch < CK; ++ch) {
+      const int c = c0 + ch;
+      const bool cok = c < a.ci;
+      const int cc = cok ? c : 0;
+      const float *src = (cc < d.c1) ? (x1 + (int64_t)cc * hw) : (x2 + (int64_t)(cc - d.c1) * hw);
+#pragma unroll
+      for (int k = 0; k < NXK; ++k) {
+        const bool ok = cok && xoff[k] >= 0;
+        const float v = src[ok ? xoff[k] : 0];
+        xr[ch * NXK + k] = ok ? v : 0.f;
+      }
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int row = wrow0 + i * ROWS_PER_PASS;
+      if (w_active && ((i + 1) * ROWS_PER_PASS <= WROWS || row < WROWS))
+        *reinterpret_cast<f32x4 *>(wsm + row * MB + wc4 * 4) = wr[i];
+    }
+#pragma unroll
+    for (int ch = 0; ch < CK; ++ch)
+#pragma unroll
+      for (int k = 0; k < NXK; ++k)
+        if ((k + 1) * 256 <= CHS || tid + k * 256 < CHS) xs[ch * CHS + tid + k * 256] = xr[ch * NXK + k];
+  };
+
+  prefetch(0);
+  commit();
+  __syncthreads();
+  for (int c0 = 0; c0 < a.ci; c0 += CK) {
+    const bool more = (c0 + CK) < a.ci;
+    if (more) prefetch(c0 + CK);
+    // ---- MFMA over (channel pair, tap): branch-free, every operand one ds_read_b32 at base + immediate
+#pragma unroll 1
     for (int cp = 0; cp < CK / 2; ++cp) {
 #pragma unroll
       for (int t = 0; t < KK; ++t) {
         const int kh = t / KS, kw = t % KS;
         float av[MT], bv[NSUB];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) av[m] = (m < mt_count) ? wp[((int64_t)(2 * cp) * KK + t) * a.cop + m * 32] : 0.f;
+        for (int m = 0; m < MT; ++m) av[m] = wsm[abase + (2 * cp * KK + t) * MB + m * 32];
 #pragma unroll
         for (int s = 0; s < NSUB; ++s) bv[s] = xs[bbase[s] + 2 * cp * CHS + kh * RS + kw];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          if (m < mt_count) {
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int s = 0; s < NSUB; ++s) acc[m][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[s], acc[m][s], 0, 0, 0);
-          }
-        }
+          for (int s = 0; s < NSUB; ++s) acc[m][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[s], acc[m][s], 0, 0, 0);
       }
+    }
+    if (more) {
+      __syncthreads();  // every wave is done reading this chunk
+      commit();
+      __syncthreads();
     }
   }
 
-  // ---- epilogue: bias, activation, residuals, store
-  const int64_t plane = (int64_t)a.ho * a.wo;
+  // ---- epilogue on the accumulators: bias, activation (uniform switch hoisted), residuals, store
+  if (d.bias) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co_blk + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float bv = (co < d.co) ? d.bias[co] : 0.f;
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) acc[m][s][r] += bv;
+      }
+  }
+  if (d.act != EDVR_ACT_NONE) {
+    const int rel_from = d.act_from - co_blk - 4 * half;  // activation applies where (m*32 + row(r)) >= rel_from
+#define EDVR_ACT_LOOP(EXPR)                                             \
+  _Pragma("unroll") for (int m = 0; m < MT; ++m)                        \
+  _Pragma("unroll") for (int r = 0; r < 16; ++r) {                      \
+    if (m * 32 + (r & 3) + 8 * (r >> 2) >= rel_from) {                  \
+      _Pragma("unroll") for (int s = 0; s < NSUB; ++s) {                \
+        const float v = acc[m][s][r];                                   \
+        acc[m][s][r] = (EXPR);                                          \
+      }                                                                 \
+    }                                                                   \
+  }
+    if (d.act == EDVR_ACT_LRELU) {
+      EDVR_ACT_LOOP(v > 0.f ? v : 0.1f * v)
+    } else if (d.act == EDVR_ACT_RELU) {
+      EDVR_ACT_LOOP(fmaxf(v, 0.f))
+    } else {
+      EDVR_ACT_LOOP(sigmoid_fast(v))
+    }
+#undef EDVR_ACT_LOOP
+  }
+  // per-image offsets fit 32 bits (co * ho * wo < 2^31); uniform conditions are hoisted out of the store loops
+  const int plane = a.ho * a.wo;
   float *y = d.y + (int64_t)img * d.y_img_stride;
   const float *r1 = d.res1 ? d.res1 + (int64_t)img * d.res1_img_stride : nullptr;
   const float *r2 = d.res2 ? d.res2 + (int64_t)img * d.res2_img_stride : nullptr;
-#pragma unroll
-  for (int s = 0; s < NSUB; ++s) {
-    const int oy = ty0 + (wave * NSUB + s) * SH + j / SW, ox = tx0 + j % SW;
-    const bool pix_ok = (oy < a.ho) && (ox < a.wo);
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      if (m < mt_count) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = co_blk + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (pix_ok && co < d.co) {
-            float v = acc[m][s][r];
-            if (d.bias) v += d.bias[co];
-            if (co >= d.act_from) v = apply_act(v, d.act);
-            const int64_t o = (int64_t)co * plane + (int64_t)oy * a.wo + ox;
-            if (r1) v += r1[o];
-            if (r2) v += r2[o];
-            if (d.out_mode == EDVR_OUT_PIXEL_SHUFFLE2) {
-              const int oc = co >> 2, sy = (co >> 1) & 1, sx = co & 1;
-              y[(int64_t)oc * plane * 4 + (int64_t)(2 * oy + sy) * (2 * a.wo) + 2 * ox + sx] = v;
-            } else {
-              y[o] = v;
-            }
-          }
-        }
-      }
-    }
+  const int co_lane = co_blk + 4 * half;
+#define EDVR_STORE_LOOP(BODY)                                                      \
+  _Pragma("unroll") for (int s = 0; s < NSUB; ++s) {                               \
+    const int oy = ty0 + (wave * NSUB + s) * SH + j / SW, ox = tx0 + j % SW;       \
+    if (oy < a.ho && ox < a.wo) {                                                  \
+      const int pix = oy * a.wo + ox;                                              \
+      _Pragma("unroll") for (int m = 0; m < MT; ++m) {                             \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                           \
+          const int co = co_lane + m * 32 + (r & 3) + 8 * (r >> 2);                \
+          if (co < d.co) {                                                         \
+            float v = acc[m][s][r];                                                \
+            const int o = co * plane + pix;                                        \
+            BODY                                                                   \
+          }                                                                        \
+        }                                                                          \
+      }                                                                            \
+    }                                                                              \
   }
+  if (d.out_mode == EDVR_OUT_PIXEL_SHUFFLE2) {
+    EDVR_STORE_LOOP({
+      (void)o;
+      y[(co >> 2) * plane * 4 + (2 * oy + ((co >> 1) & 1)) * (2 * a.wo) + 2 * ox + (co & 1)] = v;
+    })
+  } else if (r1 && r2) {
+    EDVR_STORE_LOOP({ y[o] = v + r1[o] + r2[o]; })
+  } else if (r1) {
+    EDVR_STORE_LOOP({ y[o] = v + r1[o]; })
+  } else {
+    EDVR_STORE_LOOP({ y[o] = v; })
+  }
+#undef EDVR_STORE_LOOP
 }
 
 __global__ void pack_weight_kernel(const float *__restrict__ w, float *__restrict__ wpk, int co, int ci, int kk, int cop,
@@ -187,29 +274,43 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, float *__restric
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 template <int KS, int STRIDE, int MT, int SW>
-static int launch_one(const ConvArgs &a, hipStream_t stream) {
+static int launch_one(const ConvArgs &a, int co_start, int co_blocks, hipStream_t stream) {
   constexpr int SH = 32 / SW, TH = 8 * SH, TW = SW;
   ConvArgs b = a;
   b.tiles_x = cdiv(a.wo, TW);
   b.tiles_y = cdiv(a.ho, TH);
-  dim3 grid(b.tiles_x * b.tiles_y, cdiv(a.d.co, 32 * MT), a.d.n);
+  b.co_start = co_start;
+  dim3 grid(b.tiles_x * b.tiles_y, co_blocks, a.d.n);
   hipLaunchKernelGGL((conv2d_mfma_kernel<KS, STRIDE, MT, SW>), grid, dim3(256), 0, stream, b);
   return check_launch("conv2d_mfma_kernel");
 }
 
-template <int KS, int STRIDE, int MT>
-static int launch_sw(const ConvArgs &a, hipStream_t stream) {
+static inline bool use_sw16(int ho, int wo) {
   // pick the tile geometry (8x32 or 16x16) that wastes fewer lanes on this output size
-  const int64_t w32 = (int64_t)cdiv(a.ho, 8) * 8 * cdiv(a.wo, 32) * 32;
-  const int64_t w16 = (int64_t)cdiv(a.ho, 16) * 16 * cdiv(a.wo, 16) * 16;
-  return (w16 < w32) ? launch_one<KS, STRIDE, MT, 16>(a, stream) : launch_one<KS, STRIDE, MT, 32>(a, stream);
+  const int64_t w32 = (int64_t)cdiv(ho, 8) * 8 * cdiv(wo, 32) * 32;
+  const int64_t w16 = (int64_t)cdiv(ho, 16) * 16 * cdiv(wo, 16) * 16;
+  return w16 < w32;
+}
+
+template <int KS, int STRIDE, int MT>
+static int launch_sw(const ConvArgs &a, int co_start, int co_blocks, hipStream_t stream) {
+  return use_sw16(a.ho, a.wo) ? launch_one<KS, STRIDE, MT, 16>(a, co_start, co_blocks, stream)
+                              : launch_one<KS, STRIDE, MT, 32>(a, co_start, co_blocks, stream);
 }
 
 template <int KS, int STRIDE>
 static int launch_mt(const ConvArgs &a, hipStream_t stream) {
-  if (a.d.co <= 32) return launch_sw<KS, STRIDE, 1>(a, stream);
-  if (a.d.co <= 64) return launch_sw<KS, STRIDE, 2>(a, stream);
-  return launch_sw<KS, STRIDE, 4>(a, stream);
+  // full 128-channel blocks with MT = 4, then one exact-size tail launch (no masked MFMA work)
+  const int full = a.d.co / 128, rem_tiles = cdiv(a.d.co - full * 128, 32);
+  int rc = EDVR_OK;
+  if (full > 0) rc = launch_sw<KS, STRIDE, 4>(a, 0, full, stream);
+  if (rc || rem_tiles == 0) return rc;
+  switch (rem_tiles) {
+    case 1: return launch_sw<KS, STRIDE, 1>(a, full * 128, 1, stream);
+    case 2: return launch_sw<KS, STRIDE, 2>(a, full * 128, 1, stream);
+    case 3: return launch_sw<KS, STRIDE, 3>(a, full * 128, 1, stream);
+    default: return launch_sw<KS, STRIDE, 4>(a, full * 128, 1, stream);  // 97..127 channels left
+  }
 }
 
 int conv2d_launch(const edvr_conv2d_desc &d, hipStream_t stream) {
@@ -231,6 +332,7 @@ int conv2d_launch(const edvr_conv2d_desc &d, hipStream_t stream) {
   a.ho = (d.h + 2 * pad - d.ks) / d.stride + 1;
   a.wo = (d.w + 2 * pad - d.ks) / d.stride + 1;
   a.tiles_x = a.tiles_y = 0;
+  a.co_start = 0;
   if (d.ks == 3 && d.stride == 1) return launch_mt<3, 1>(a, stream);
   if (d.ks == 3 && d.stride == 2) return launch_mt<3, 2>(a, stream);
   return launch_mt<1, 1>(a, stream);
@@ -241,18 +343,27 @@ int conv2d_launch(const edvr_conv2d_desc &d, hipStream_t stream) {
 extern "C" {
 
 size_t edvr_conv2d_packed_weight_elems(int co, int ci, int ks) {
-  return (size_t)edvr::round_up(ci, 16) * ks * ks * edvr::round_up(co, 32);
+  return (size_t)edvr::round_up(ci, ks == 1 ? 32 : 16) * ks * ks * edvr::round_up(co, 32);
 }
 
 int edvr_conv2d_pack_weight_f32(const float *w, float *wpk, int co, int ci, int ks, int transpose_flip,
                                 edvr_stream_t stream) {
   EDVR_REQUIRE(w && wpk && co > 0 && ci > 0 && ks > 0, "pack_weight: bad arguments");
-  const int cop = edvr::round_up(co, 32), cip = edvr::round_up(ci, 16), kk = ks * ks;
+  const int cop = edvr::round_up(co, 32), cip = edvr::round_up(ci, ks == 1 ? 32 : 16), kk = ks * ks;
   const int64_t total = (int64_t)cip * kk * cop;
   const int blocks = (int)std::min<int64_t>(edvr::cdiv64(total, 256), 4096);
   hipLaunchKernelGGL(edvr::pack_weight_kernel, dim3(blocks), dim3(256), 0, edvr::as_stream(stream), w, wpk, co, ci, kk,
                      cop, cip, transpose_flip);
   return edvr::check_launch("pack_weight_kernel");
+}
+
+int edvr_conv2d_kernel_name(const edvr_conv2d_desc *d, char *buf, size_t buf_len) {
+  EDVR_REQUIRE(d && buf && buf_len > 0, "kernel_name: bad arguments");
+  const int pad = d->ks / 2;
+  const int ho = (d->h + 2 * pad - d->ks) / d->stride + 1, wo = (d->w + 2 * pad - d->ks) / d->stride + 1;
+  const int mt = d->co >= 128 ? 4 : edvr::cdiv(d->co, 32);  // the launch carrying most of the work
+  snprintf(buf, buf_len, "conv2d_mfma_kernel<%d, %d, %d, %d>", d->ks, d->stride, mt, edvr::use_sw16(ho, wo) ? 16 : 32);
+  return EDVR_OK;
 }
 
 int edvr_conv2d_f32(const edvr_conv2d_desc *d, edvr_stream_t stream) {

@@ -414,7 +414,7 @@ int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, c
   for (int g = 0; g < groups; ++g) {
     const float *wg = weight + (size_t)g * cog * cig * K;
     const float *wuse = wg;
-    if ((cog % 16) != 0 || ((cig * K) % 32) != 0) {  // W (cog x cig*K, row-major) is already the packed layout when aligned
+    if ((cog % 32) != 0 || ((cig * K) % 32) != 0) {  // W (cog x cig*K, row-major) is already the packed layout when aligned
       rc = edvr_conv2d_pack_weight_f32(wg, wpk + g * wpk_g, cig * K, cog, 1, 1, stream_);
       if (rc) return rc;
       wuse = wpk + g * wpk_g;

@@ -63,17 +63,21 @@ def workspace(nbytes, device):
 
 
 # ------------------------------------------------------------------------------------------------ weights
-_PACKED = weakref.WeakKeyDictionary()
+_PACKED = {}  # id(parameter) -> (weakref, {transpose_flip: (version, packed, data_ptr)})
 
 
 def pack_conv_weight(weight, transpose_flip=False):
     """(co, ci, k, k) parameter -> MFMA-friendly [ci_pad][k*k][co_pad] array, cached per parameter version."""
     require_gpu(weight)
-    key = bool(transpose_flip)
-    slot = _PACKED.get(weight)
-    ver = weight._version
-    if slot is not None and key in slot and slot[key][0] == ver and slot[key][2] == weight.data_ptr():
-        return slot[key][1]
+    key, wid, ver = bool(transpose_flip), id(weight), weight._version
+    ent = _PACKED.get(wid)
+    if ent is not None and ent[0]() is weight:
+        hit = ent[1].get(key)
+        if hit is not None and hit[0] == ver and hit[2] == weight.data_ptr():
+            return hit[1]
+    else:
+        ent = (weakref.ref(weight, lambda _r, wid=wid: _PACKED.pop(wid, None)), {})
+        _PACKED[wid] = ent
     L = _lib.lib()
     w = weight.detach()
     if not w.is_contiguous():
@@ -85,14 +89,14 @@ def pack_conv_weight(weight, transpose_flip=False):
     out = torch.empty(n, dtype=torch.float32, device=w.device)
     _lib.check(L.edvr_conv2d_pack_weight_f32(_ptr(w), _ptr(out), co, ci, k, 1 if transpose_flip else 0, _stream()),
                'edvr_conv2d_pack_weight_f32')
-    if slot is None:
-        slot = {}
-        _PACKED[weight] = slot
-    slot[key] = (ver, out, weight.data_ptr())
+    ent[1][key] = (ver, out, weight.data_ptr())
     return out
 
 
 # ------------------------------------------------------------------------------------------------ conv
+LAUNCH_HOOK = None  # callable(kernel_name, algorithmic_flops, launch_fn) or None
+
+
 def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NONE, act_from=0, res1=None, res2=None,
            out_mode=OUT_NCHW, out=None):
     """y = act(conv(cat(x1, x2)) + bias) + res1 + res2 on the fp32 MFMA kernel.
@@ -135,7 +139,13 @@ def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NON
             else:
                 res2 = r
     d.y, d.y_img_stride, d.out_mode = _ptr(out), _img_stride(out), out_mode
-    _lib.check(L.edvr_conv2d_f32(ctypes.byref(d), _stream()), 'edvr_conv2d_f32')
+    if LAUNCH_HOOK is not None:  # measurement only (bench.py): brackets the launch with events on this stream
+        buf = ctypes.create_string_buffer(96)
+        L.edvr_conv2d_kernel_name(ctypes.byref(d), buf, 96)
+        flops = 2.0 * n * ho * wo * co * (c1 + d.c2) * ks * ks
+        LAUNCH_HOOK(buf.value.decode(), flops, lambda: _lib.check(L.edvr_conv2d_f32(ctypes.byref(d), _stream()), 'edvr_conv2d_f32'))
+    else:
+        _lib.check(L.edvr_conv2d_f32(ctypes.byref(d), _stream()), 'edvr_conv2d_f32')
     return out
 
 

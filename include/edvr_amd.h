@@ -94,6 +94,9 @@ size_t edvr_conv2d_packed_weight_elems(int co, int ci, int ks);
 int edvr_conv2d_pack_weight_f32(const float *w, float *wpk, int co, int ci, int ks, int transpose_flip,
                                 edvr_stream_t stream);
 int edvr_conv2d_f32(const edvr_conv2d_desc *d, edvr_stream_t stream);
+/* Name of the kernel template instantiation edvr_conv2d_f32 would launch for `d` (as rocprofv3 prints it),
+ * written to buf; returns 0 or EDVR_ERR_*.  Measurement aid only. */
+int edvr_conv2d_kernel_name(const edvr_conv2d_desc *d, char *buf, size_t buf_len);
 
 /* ------------------------------------------------------------------ DCNv2 (modulated deformable conv)
  * x (B,C,H,W); offset (B, dg*2*kh*kw, Ho, Wo) channel = g*2K + 2k + {0:dy,1:dx};

@@ -1,0 +1,11 @@
+#!/bin/bash
+# rocprofv3 kernel stats of the bench command (run on the GPU box via gpurun): scripts/prof_bench.sh NAME [bench args]
+R=${GRAFT_REPO_ROOT:-/root/repo}
+NAME=${1:-prof_bench}; shift
+OUT=$R/gpurun_out/$NAME
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench -- python $R/bench.py --no-cpu-baseline "$@" > $OUT/bench.log 2>&1
+tail -1 $OUT/bench.log
+ls $OUT
+head -40 $OUT/*kernel_stats.csv

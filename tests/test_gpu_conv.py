@@ -26,6 +26,9 @@ CASES = [
     (1, 64, 0, 12, 20, 256, 3, 1, 'lrelu', 0, 1),
     (1, 64, 0, 40, 72, 3, 3, 1, 'none', 2, 0),
     (3, 40, 24, 9, 7, 48, 3, 1, 'none', 2, 0),
+    (1, 32, 0, 16, 16, 108, 3, 1, 'sigmoid_from', 0, 0),   # 97..127 output channels: 4-tile tail launch
+    (1, 48, 0, 10, 12, 100, 1, 1, 'none', 0, 0),
+    (1, 96, 0, 16, 32, 300, 1, 1, 'lrelu', 1, 0),           # 2 full 128-blocks + 2-tile tail, 1x1 with CK=32
 ]
 
 
