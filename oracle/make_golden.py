@@ -1,0 +1,86 @@
+"""TEST INFRASTRUCTURE ONLY - generate tests/golden/*.pt (run in the authoring container).
+
+    python -m oracle.make_golden
+
+Golden vectors come from the REFERENCE ITSELF wherever it can execute here:
+  dcn_*.pt   - inputs + outputs/gradients of the reference's own DCNv2 kernels
+               (deform_conv_cuda_kernel.cu compiled serially for the CPU: oracle/_ref), fp64
+  edvr_*.pt  - seeded input + output of the reference's own Python network (basicsr/models/archs/edvr_arch.py
+               imported unchanged, oracle/ref_import.py) with the DCN op supplied by oracle/_ref
+Small shapes only: the fixtures are committed.
+"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from oracle import dcn_oracle as O, ref_import  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+DCN_CASES = {
+    # name: (B, C, H, W, Co, k, stride, pad, dil, groups, dg, sigma, mode)
+    'edvr_like': (1, 16, 10, 12, 16, 3, 1, 1, 1, 1, 8, 1.5, 'rand'),
+    'zero_offset': (1, 16, 8, 8, 16, 3, 1, 1, 1, 1, 8, 0.0, 'rand'),
+    'integer_taps': (1, 16, 8, 8, 8, 3, 1, 1, 1, 1, 8, 2.0, 'int'),
+    'half_taps': (1, 8, 7, 9, 8, 3, 1, 1, 1, 1, 4, 2.0, 'half'),
+    'out_of_bounds': (1, 8, 6, 6, 8, 3, 1, 1, 1, 1, 2, 8.0, 'rand'),
+    'stride2_groups2': (2, 8, 7, 9, 6, 3, 2, 1, 1, 2, 2, 1.5, 'rand'),
+    'dilation2': (1, 8, 10, 10, 4, 3, 1, 2, 2, 1, 4, 2.0, 'rand'),
+}
+EDVR_CASES = ('M_T5', 'M_noTSA', 'L_deblur_hr')
+
+
+def dcn_case(name):
+    B, C, H, W, Co, k, stride, pad, dil, groups, dg, sigma, mode = DCN_CASES[name]
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    Ho, Wo = O._out_hw(H, W, k, k, stride, pad, dil)
+    dt = torch.float64
+    x = torch.randn(B, C, H, W, generator=g, dtype=dt)
+    w = torch.randn(Co, C // groups, k, k, generator=g, dtype=dt) * 0.1
+    b = torch.randn(Co, generator=g, dtype=dt)
+    off = torch.randn(B, dg * 2 * k * k, Ho, Wo, generator=g, dtype=dt) * sigma
+    if mode == 'int':
+        off = off.round()
+    elif mode == 'half':
+        off = off.round() + 0.5
+    m = torch.rand(B, dg * k * k, Ho, Wo, generator=g, dtype=dt)
+    dy = torch.randn(B, Co, Ho, Wo, generator=g, dtype=dt)
+    cfg = (stride, pad, dil, groups, dg)
+    y = O.ref_forward(x, off, m, w, b, *cfg)
+    dx, doff, dm, dw, db = O.ref_backward(x, off, m, w, dy, True, *cfg)
+    return dict(cfg=cfg, x=x, offset=off, mask=m, weight=w, bias=b, dy=dy, y=y, dx=dx, doffset=doff, dmask=dm,
+                dweight=dw, dbias=db)
+
+
+def edvr_case(name):
+    from util_edvr import CONFIGS, randomize_offsets
+    kwargs, shape = CONFIGS[name]
+    ea, _ = ref_import.load(dcn=lambda *a: O.ref_forward(*a))
+    torch.manual_seed(10)
+    net = randomize_offsets(ea.EDVR(**kwargs)).eval()
+    x = torch.rand(*shape, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        y = net(x)
+    # weights are reproducible from the seed; tests rebuild them and compare `param_checksum`
+    checksum = float(sum(p.double().abs().sum() for p in net.parameters()))
+    return dict(kwargs=kwargs, x=x, y=y, param_checksum=checksum, n_keys=len(net.state_dict()),
+                n_params=sum(p.numel() for p in net.parameters()))
+
+
+def main():
+    assert ref_import.available() and O.have_ref(), 'needs /root/reference and oracle/_ref (make -C oracle ref)'
+    os.makedirs(OUT, exist_ok=True)
+    for name in DCN_CASES:
+        torch.save(dcn_case(name), os.path.join(OUT, f'dcn_{name}.pt'))
+    for name in EDVR_CASES:
+        torch.save(edvr_case(name), os.path.join(OUT, f'edvr_{name}.pt'))
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,64 @@
+"""CPU, world_size 2, gloo: the multi-GPU host logic (clip sharding, gradient all-reduce through DDP)."""
+import os
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from edvr_amd import dist as D
+    r, w = D.init_dist(backend='gloo')
+    assert (r, w) == (rank, world) and D.get_dist_info() == (rank, world)
+    mine = D.shard_indices(11)
+    per = D.shard_batch(7)
+    # gradient averaging: DDP over gloo == mean of per-rank gradients
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, 1, 1), torch.nn.LeakyReLU(0.1), torch.nn.Conv2d(4, 3, 3, 1, 1))
+    ddp = D.wrap_ddp(net)
+    x = torch.rand(2, 3, 8, 8, generator=torch.Generator().manual_seed(100 + rank))
+    ddp(x).square().sum().backward()
+    grads = [p.grad.flatten().tolist() for p in net.parameters()]  # plain lists: tensors cannot outlive the worker
+    m = D.reduce_scalar(float(rank + 1), torch.device('cpu'))
+    q.put((rank, mine, per, grads, m))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_gradient_allreduce():
+    world, port = 2, 29533 + os.getpid() % 1000
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, idx0, per0, g0, m0), (r1, idx1, per1, g1, m1) = got
+    assert sorted(idx0 + idx1) == list(range(11)) and not set(idx0) & set(idx1)  # disjoint, complete
+    assert idx0 == list(range(0, 11, 2)) and idx1 == list(range(1, 11, 2))
+    assert per0 + per1 == 7 and per0 == 4
+    assert m0 == m1 == 1.5
+    # single-process reference: mean over the two ranks' gradients
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, 1, 1), torch.nn.LeakyReLU(0.1), torch.nn.Conv2d(4, 3, 3, 1, 1))
+    acc = None
+    for rank in range(world):
+        net.zero_grad()
+        x = torch.rand(2, 3, 8, 8, generator=torch.Generator().manual_seed(100 + rank))
+        net(x).square().sum().backward()
+        g = [p.grad.clone() for p in net.parameters()]
+        acc = g if acc is None else [a + b for a, b in zip(acc, g)]
+    for a, b0, b1 in zip(acc, g0, g1):
+        assert torch.allclose((a / world).flatten(), torch.tensor(b0), atol=1e-6) and b0 == b1
+
+
+def test_single_process_defaults():
+    from edvr_amd import dist as D
+    assert D.get_dist_info() == (0, 1)
+    assert D.shard_indices(5) == [0, 1, 2, 3, 4] and D.shard_batch(9) == 9
+    net = torch.nn.Linear(2, 2)
+    assert D.wrap_ddp(net) is net

@@ -1,0 +1,73 @@
+"""CPU: host-side contract of the module API (no compute: there is no CPU path)."""
+import pytest
+import torch
+
+from oracle import ref_import
+
+EXPECTED = {  # measured on the instantiated reference classes
+    'M': (dict(num_feat=64, num_reconstruct_block=10), 144, 3300131),
+    'L': (dict(num_feat=128, num_reconstruct_block=40, center_frame_idx=None), 264, 20633827),
+    'L_T7': (dict(num_feat=128, num_frame=7, num_reconstruct_block=40, center_frame_idx=None), 264, 20699363),
+    'L_deblur': (dict(num_feat=128, num_reconstruct_block=40, hr_in=True, with_predeblur=True), None, 23602019),
+}
+
+
+@pytest.mark.parametrize('name', list(EXPECTED))
+def test_state_dict_contract(name):
+    from edvr_amd import EDVR
+    kwargs, n_keys, n_params = EXPECTED[name]
+    net = EDVR(**kwargs)
+    if n_keys is not None:
+        assert len(net.state_dict()) == n_keys
+    assert sum(p.numel() for p in net.parameters()) == n_params
+    names = [n for n, _ in net.named_parameters()]
+    assert any('dcn' in n for n in names) and any(n.startswith('fusion') for n in names)  # LR groups / TSA freeze rely on these
+    assert net.pcd_align.dcn_pack['l3'].conv_offset.weight.shape == (216, kwargs['num_feat'], 3, 3)
+    assert net.pcd_align.cas_dcnpack._version == 2
+    assert net.center_frame_idx == kwargs.get('num_frame', 5) // 2
+
+
+@pytest.mark.skipif(not ref_import.available(), reason='/root/reference not present')
+@pytest.mark.parametrize('kwargs', [dict(num_feat=64, num_reconstruct_block=10),
+                                    dict(num_feat=32, num_frame=3, num_reconstruct_block=2, center_frame_idx=1, with_tsa=False),
+                                    dict(num_feat=32, num_reconstruct_block=2, hr_in=True, with_predeblur=True)])
+def test_same_seed_same_parameters_as_reference(kwargs):
+    """Key names, order, shapes AND initial values equal the reference's classes under the same seed."""
+    from edvr_amd import EDVR
+    ea, _ = ref_import.load()
+    torch.manual_seed(7)
+    ours = EDVR(**kwargs).state_dict()
+    torch.manual_seed(7)
+    theirs = ea.EDVR(**kwargs).state_dict()
+    assert list(ours) == list(theirs)
+    assert all(torch.equal(ours[k], theirs[k]) for k in ours)
+    ea.EDVR(**kwargs).load_state_dict(ours, strict=True)
+
+
+def test_cpu_tensors_are_refused_like_the_reference():
+    from edvr_amd import EDVR, ModulatedDeformConvPack, modulated_deform_conv
+    with pytest.raises(NotImplementedError):  # deform_conv.py:133-134
+        modulated_deform_conv(torch.randn(1, 8, 6, 6), torch.zeros(1, 18, 6, 6), torch.ones(1, 9, 6, 6), torch.randn(8, 8, 3, 3),
+                              None, 1, 1, 1, 1, 1)
+    with pytest.raises(NotImplementedError):
+        EDVR(num_feat=16, num_reconstruct_block=1)(torch.rand(1, 5, 3, 16, 16))
+    with pytest.raises(NotImplementedError):
+        ModulatedDeformConvPack(8, 8, 3, padding=1)(torch.randn(1, 8, 6, 6))
+
+
+def test_input_size_assertions():
+    from edvr_amd import EDVR
+    with pytest.raises(AssertionError):
+        EDVR(num_feat=16, num_reconstruct_block=1)(torch.rand(1, 5, 3, 18, 16))
+    with pytest.raises(AssertionError):
+        EDVR(num_feat=16, num_reconstruct_block=1, hr_in=True, with_predeblur=True)(torch.rand(1, 5, 3, 24, 32))
+
+
+def test_module_attributes_mirror_reference():
+    from edvr_amd import ModulatedDeformConv
+    m = ModulatedDeformConv(8, 12, 3, stride=1, padding=1, dilation=1, groups=1, deformable_groups=2, bias=True)
+    assert (m.in_channels, m.out_channels, m.kernel_size, m.stride, m.padding, m.dilation) == (8, 12, (3, 3), 1, 1, 1)
+    assert m.with_bias and not m.transposed and m.output_padding == (0,)
+    assert m.weight.shape == (12, 8, 3, 3) and torch.all(m.bias == 0)
+    bound = 1.0 / (8 * 9) ** 0.5
+    assert m.weight.abs().max().item() <= bound
