@@ -37,14 +37,25 @@ PROTOTYPES = {
     'edvr_dcnv2_fwd_ws_bytes': (sz, [i32] * 12),
     'edvr_dcnv2_fwd_f32': (i32, [vp] * 6 + [i32] * 12 + [i64, i64, i32, vp, sz, vp]),
     'edvr_dcnv2_bwd_ws_bytes': (sz, [i32] * 12),
-    'edvr_dcnv2_bwd_f32': (i32, [vp] * 10 + [i32] * 12 + [i64, i64, vp, sz, vp]),
+    'edvr_dcnv2_bwd_f32': (i32, [vp] * 10 + [i32] * 12 + [i64, i64, i64, i64, vp, sz, vp]),
     'edvr_tsa_temporal_f32': (i32, [vp] * 5 + [i32] * 4 + [vp]),
     'edvr_pool_maxavg_3x3s2_f32': (i32, [vp, vp, i32, i32, i32, i32, vp]),
     'edvr_upsample2x_f32': (i32, [vp, vp, i32, i32, i32, f32, vp]),
     'edvr_tsa_combine_f32': (i32, [vp, vp, vp, vp, i64, vp]),
     'edvr_upsample4x_add_f32': (i32, [vp, vp, i32, i32, i32, vp]),
     'edvr_add_f32': (i32, [vp, vp, vp, i64, vp]),
-    'edvr_act_bwd_f32': (i32, [vp, vp, vp, i32, i32, i64, i32, i32, vp]),
+    'edvr_act_bwd_f32': (i32, [vp, vp, vp, vp, vp, i32, i32, i64, i32, i32, vp]),
+    'edvr_conv2d_wgrad_ws_bytes': (sz, [i32] * 7),
+    'edvr_conv2d_wgrad_f32': (i32, [vp] * 4 + [i32] * 8 + [i64, i64, i32, i32, i32, i64, i32, vp, sz, vp]),
+    'edvr_channel_sum_f32': (i32, [vp, vp, i32, i32, i64, i64, vp]),
+    'edvr_pixel_unshuffle2_f32': (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    'edvr_zero_stuff2_f32': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    'edvr_frame_reduce_add_f32': (i32, [vp, vp, i32, i32, i32, i64, vp]),
+    'edvr_upsample2x_bwd_f32': (i32, [vp, vp, i32, i32, i32, f32, vp]),
+    'edvr_pool_maxavg_3x3s2_bwd_f32': (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    'edvr_tsa_temporal_bwd_f32': (i32, [vp] * 7 + [i32] * 4 + [vp]),
+    'edvr_tsa_combine_bwd_f32': (i32, [vp] * 5 + [i64, vp]),
+    'edvr_charbonnier_f32': (i32, [vp, vp, vp, vp, i64, f32, f32, vp]),
     'edvr_abs_sum_f32': (i32, [vp, vp, i32, i64, i64, vp]),
 }
 

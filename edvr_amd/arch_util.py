@@ -13,7 +13,7 @@ from torch.nn import init
 from torch.nn.modules.batchnorm import _BatchNorm
 
 from . import functional as F_
-from .dcn import ModulatedDeformConvPack, modulated_deform_conv
+from .dcn import ModulatedDeformConvPack
 
 OFFSET_ABSMEAN_LIMIT = 50  # arch_util.py:249
 
@@ -75,11 +75,11 @@ class DCNv2Pack(ModulatedDeformConvPack):
     stats_sink = None
 
     def forward(self, x, feat, act=F_.ACT_NONE):
-        offset, mask = F_.offset_mask_conv(self.conv_offset, feat)
-        sums = F_.ops.abs_sum_per_image(offset.detach())
+        om = F_.offset_mask_conv(self.conv_offset, feat)
+        offset = om.detach()[:, :2 * om.shape[1] // 3]
+        sums = F_.ops.abs_sum_per_image(offset)
         if self.stats_sink is not None:
             self.stats_sink.append((sums, offset[0].numel()))
         else:
             warn_offset_absmean(float(sums.sum().item()) / offset.numel())
-        return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation,
-                                     self.groups, self.deformable_groups, act)
+        return F_.dcn_from_packed(self, x, om, act)

@@ -1,0 +1,194 @@
+"""Autograd Functions for the fused HIP launches (training path of the EDVR hot path).
+
+Every Function's backward runs hand-written HIP kernels too (dgrad = the forward MFMA kernel on
+transposed/flipped packed weights, wgrad = csrc/wgrad.hip, glue gradients = csrc/backward.hip).
+All are once_differentiable, like the reference's DCN Function (deform_conv.py:149).
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import ops
+from .ops import ACT_NONE, OUT_PIXEL_SHUFFLE2
+
+
+class ConvFn(Function):
+    """y = act(conv(cat(x, x2)) + bias) + res1 + res2 (see ops.conv2d)."""
+
+    @staticmethod
+    def forward(ctx, x, x2, weight, bias, res1, res2, cfg):
+        x2_map, act, act_from, out_mode, ks, stride = cfg
+        wpk = ops.pack_conv_weight(weight)
+        y = ops.conv2d(x, wpk, bias.detach() if bias is not None else None, weight.shape[0], ks, x2=x2, x2_map=x2_map, stride=stride,
+                       act=act, act_from=act_from, res1=res1, res2=res2, out_mode=out_mode)
+        keep_y = act != ACT_NONE
+        ctx.save_for_backward(x, x2, weight, y if keep_y else None, res1 if keep_y else None, res2 if keep_y else None)
+        ctx.cfg = cfg
+        ctx.has = (bias is not None, res1 is not None, res2 is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, x2, weight, y, res1, res2 = ctx.saved_tensors
+        x2_map, act, act_from, out_mode, ks, stride = ctx.cfg
+        has_bias, has_r1, has_r2 = ctx.has
+        need = ctx.needs_input_grad
+        co = weight.shape[0]
+        dres = dy if (has_r1 and need[4]) or (has_r2 and need[5]) else None
+        # gradient w.r.t. the pre-activation conv output z (n, co, ho, wo)
+        if out_mode == OUT_PIXEL_SHUFFLE2:
+            dz = ops.pixel_unshuffle2(ops.act_backward(dy, y, act) if act != ACT_NONE else dy)
+        else:
+            dz = ops.act_backward(dy, y, act, act_from, res1, res2) if act != ACT_NONE else dy
+        db = ops.channel_sum(dz) if (has_bias and need[3]) else None
+        dw = ops.conv2d_wgrad(x, x2, x2_map, dz, co, ks, stride) if need[2] else None
+        dx = dx2 = None
+        if need[0] or (x2 is not None and need[1]):
+            c1 = x.shape[1]
+            z = ops.zero_stuff2(dz, x.shape[2], x.shape[3]) if stride == 2 else dz
+            wt = ops.pack_conv_weight(weight, transpose_flip=True)
+            dcat = ops.conv2d(z, wt, None, weight.shape[1], ks)  # data gradient = stride-1 conv with flipped W^T
+            if need[0]:
+                dx = dcat[:, :c1] if x2 is not None else dcat
+            if x2 is not None and need[1]:
+                d2 = dcat[:, c1:]
+                if x2_map is not None:
+                    div, mul, add = x2_map
+                    assert div == mul, 'image map must address one frame per clip'
+                    dx2 = torch.zeros_like(x2)
+                    ops.frame_reduce_add_(d2, dx2, div, add)  # every frame of a clip read the same reference frame
+                else:
+                    dx2 = d2
+        return dx, dx2, dw, db, (dres if has_r1 else None), (dres if has_r2 else None), None
+
+
+def conv(m, x, x2, x2_map, act, act_from, res1, res2, out_mode, ks, stride):
+    return ConvFn.apply(x, x2, m.weight, m.bias, res1, res2, (x2_map, act, act_from, out_mode, ks, stride))
+
+
+class DcnFromPackedFn(Function):
+    """DCNv2 fed by ONE conv_offset output `om` (n, 3*dg*K, h, w): offset = first 2/3 channels, mask = last third
+    (already sigmoid-ed by the conv epilogue).  Backward writes d(offset) and d(mask) straight into slices of d(om)."""
+
+    @staticmethod
+    def forward(ctx, x, om, weight, bias, cfg):
+        stride, padding, dilation, groups, dg, act = cfg
+        split = 2 * om.shape[1] // 3
+        out = ops.dcnv2_forward(x, om[:, :split], om[:, split:], weight, bias, stride, padding, dilation, groups, dg, act=act)
+        ctx.save_for_backward(x, om, weight, out if act != ACT_NONE else None)
+        ctx.cfg = cfg
+        ctx.with_bias = bias is not None
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, om, weight, out = ctx.saved_tensors
+        stride, padding, dilation, groups, dg, act = ctx.cfg
+        if act != ACT_NONE:
+            dy = ops.act_backward(dy, out, act)
+        split = 2 * om.shape[1] // 3
+        dom = torch.empty_like(om)
+        dx, _, _, dw, db = ops.dcnv2_backward(x, om[:, :split], om[:, split:], weight, dy, ctx.with_bias, stride, padding, dilation,
+                                              groups, dg, doffset=dom[:, :split], dmask=dom[:, split:])
+        return dx, dom, dw, db, None
+
+
+class Upsample2x(Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = scale
+        return ops.upsample2x(x, scale)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        return ops.upsample2x_backward(dy, ctx.scale), None
+
+
+class PoolMaxAvg(Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.pool_maxavg(x)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.pool_maxavg_backward(x, dy)
+
+
+class TsaTemporal(Function):
+    @staticmethod
+    def forward(ctx, emb, emb_ref, aligned):
+        ctx.save_for_backward(emb, emb_ref, aligned)
+        return ops.tsa_temporal(emb, emb_ref, aligned)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        emb, emb_ref, aligned = ctx.saved_tensors
+        return ops.tsa_temporal_backward(emb, emb_ref, aligned, dout)
+
+
+class TsaCombine(Function):
+    @staticmethod
+    def forward(ctx, feat, attn, attn_add):
+        ctx.save_for_backward(feat, attn)
+        return ops.tsa_combine(feat, attn, attn_add)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        feat, attn = ctx.saved_tensors
+        dfeat, dattn = ops.tsa_combine_backward(feat, attn, dy)
+        return dfeat, dattn, dy
+
+
+class Add(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.add(a, b)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        return dy, dy
+
+
+class Upsample4xAdd(Function):
+    """y + bilinear_x4(base); base is the network input (no gradient is propagated to it)."""
+
+    @staticmethod
+    def forward(ctx, y, base):
+        if base.requires_grad:
+            raise NotImplementedError('gradient w.r.t. the input frames is not provided by the x4 base-add kernel')
+        ctx.mark_dirty(y)
+        return ops.upsample4x_add_(y, base)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        return dy, None
+
+
+class CharbonnierSum(Function):
+    """CharbonnierLoss(reduction='sum', eps=1e-12) (losses/losses.py:23-25); forward + gradient in one pass."""
+
+    @staticmethod
+    def forward(ctx, pred, target, eps):
+        loss, dpred = ops.charbonnier(pred, target, eps, want_grad=True)
+        ctx.save_for_backward(dpred)
+        return loss.view(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (dpred,) = ctx.saved_tensors
+        return dpred * g, None, None
+
+
+def charbonnier_loss(pred, target, eps=1e-12):
+    return CharbonnierSum.apply(pred, target, eps)

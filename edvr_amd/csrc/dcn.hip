@@ -32,7 +32,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct DcnShape {
   int B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, Ho, Wo;
-  int64_t off_bs, msk_bs;
+  int64_t off_bs, msk_bs;    // image strides of offset / mask (inputs)
+  int64_t doff_bs, dmsk_bs;  // image strides of doffset / dmask (backward outputs)
 };
 
 struct Tap {
@@ -148,8 +149,8 @@ __global__ __launch_bounds__(256) void dcn_bwd_coord_kernel(const float *__restr
       gp += plane;
       cp += (int64_t)K * P;
     }
-    dmask[((int64_t)b * s.dg * K + g * K + k) * P + p] = s_m;
-    float *dob = doffset + ((int64_t)b * s.dg * 2 * K + g * 2 * K + 2 * k) * P + p;
+    dmask[(int64_t)b * s.dmsk_bs + (int64_t)(g * K + k) * P + p] = s_m;
+    float *dob = doffset + (int64_t)b * s.doff_bs + (int64_t)(g * 2 * K + 2 * k) * P + p;
     dob[0] = s_y * m;
     dob[P] = s_x * m;
   }
@@ -291,6 +292,8 @@ static int fill_shape(DcnShape &s, int B, int C, int H, int W, int Co, int kh, i
   const int64_t P = (int64_t)s.Ho * s.Wo, K = kh * kw;
   s.off_bs = off_bs ? off_bs : (int64_t)dg * 2 * K * P;
   s.msk_bs = msk_bs ? msk_bs : (int64_t)dg * K * P;
+  s.doff_bs = (int64_t)dg * 2 * K * P;
+  s.dmsk_bs = (int64_t)dg * K * P;
   return EDVR_OK;
 }
 
@@ -391,12 +394,14 @@ int edvr_dcnv2_fwd_f32(const float *x, const float *offset, const float *mask, c
 int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, const float *weight, const float *dy, float *dx,
                        float *doffset, float *dmask, float *dweight, float *dbias, int B, int C, int H, int W, int Co, int kh,
                        int kw, int stride, int pad, int dil, int groups, int dg, int64_t offset_bstride, int64_t mask_bstride,
-                       void *ws, size_t ws_bytes, edvr_stream_t stream_) {
+                       int64_t doffset_bstride, int64_t dmask_bstride, void *ws, size_t ws_bytes, edvr_stream_t stream_) {
   using namespace edvr;
   EDVR_REQUIRE(x && offset && mask && weight && dy && dx && doffset && dmask && dweight, "dcnv2_bwd: null pointer");
   DcnShape s;
   int rc = fill_shape(s, B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, offset_bstride, mask_bstride);
   if (rc) return rc;
+  if (doffset_bstride) s.doff_bs = doffset_bstride;
+  if (dmask_bstride) s.dmsk_bs = dmask_bstride;
   const BwdWs wsz = bwd_ws(s);
   if (!ws || ws_bytes < wsz.total) {
     set_error("dcnv2_bwd: workspace %zu < required %zu", ws_bytes, wsz.total);

@@ -115,13 +115,16 @@ __global__ __launch_bounds__(256) void add_kernel(const float *__restrict__ a, c
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = a[i] + b[i];
 }
 
-__global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y, float *__restrict__ dz,
-                                                      int64_t total, int c, int64_t hw, int act, int act_from) {
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y, const float *__restrict__ res1,
+                                                      const float *__restrict__ res2, float *__restrict__ dz, int64_t total, int c,
+                                                      int64_t hw, int act, int act_from) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int ch = (int)((i / hw) % c);
     float g = dy[i];
     if (ch >= act_from) {
-      const float v = y[i];
+      float v = y[i];
+      if (res1) v -= res1[i];  // y = act(z) + res: recover act(z)
+      if (res2) v -= res2[i];
       if (act == EDVR_ACT_RELU) g = v > 0.f ? g : 0.f;
       else if (act == EDVR_ACT_LRELU) g = v > 0.f ? g : 0.1f * g;
       else if (act == EDVR_ACT_SIGMOID) g = g * v * (1.f - v);
@@ -203,11 +206,12 @@ int edvr_add_f32(const float *a, const float *b, float *y, int64_t numel, edvr_s
   return check_launch("add_kernel");
 }
 
-int edvr_act_bwd_f32(const float *dy, const float *y, float *dz, int n, int c, int64_t hw, int act, int act_from, edvr_stream_t stream) {
+int edvr_act_bwd_f32(const float *dy, const float *y, const float *res1, const float *res2, float *dz, int n, int c, int64_t hw, int act,
+                     int act_from, edvr_stream_t stream) {
   using namespace edvr;
   EDVR_REQUIRE(dy && y && dz && n > 0 && c > 0 && hw > 0, "act_bwd: bad arguments");
   const int64_t total = (int64_t)n * c * hw;
-  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), dy, y, dz, total, c, hw, act, act_from);
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), dy, y, res1, res2, dz, total, c, hw, act, act_from);
   return check_launch("act_bwd_kernel");
 }
 

@@ -1,0 +1,212 @@
+// wgrad.hip - weight gradient of the fused conv (implicit GEMM over the pixel axis) for gfx950.
+//
+// Replaces the cuDNN backward-filter calls autograd issues for every nn.Conv2d of the reference's
+// basicsr/models/archs/edvr_arch.py during SRModel.optimize_parameters (sr_model.py:88-112).
+//
+//   dW[co, ci, tap] = sum_{n, pixel} dZ[n, co, pixel] * X[n, ci, pixel*stride + tap - pad]
+//
+// GEMM view on v_mfma_f32_32x32x2_f32:  D[co, ci] (one accumulator tile per tap) += A[co, k] * B[k, ci],
+// k = output pixel.  A = dZ (lane l: co = l&31, pixel pair member l>>5), B = X shifted by the tap.
+// A 256-thread workgroup owns 128 output channels (wave w: co 32w..32w+31) x 32 input channels x all
+// taps (9 accumulator tiles = 144 registers per wave) and walks "strips" of 2 x 32 output pixels:
+// per strip the dZ tile (128 x 64) and the X halo tile (32 ci x 4 x 34) are staged in LDS with odd
+// row strides (conflict-free for both operand patterns), then 32 k-steps x 9 taps of MFMA run with
+// every operand a ds_read_b32 at base + immediate.  The pixel axis is split over workgroups
+// (deterministic split-K: partial tiles go to a workspace, a second kernel reduces them).
+#include "common.h"
+
+namespace edvr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WgradArgs {
+  const float *x1, *x2, *dz;
+  float *ws;  // [splits][co][ci][kk]
+  int c1, c2, n, h, w, co, ho, wo;
+  int64_t x1_img_stride, x2_img_stride, dz_img_stride;
+  int x2_div, x2_mul, x2_add;
+  int strips_x, strips_y, units, splits;
+};
+
+template <int KS, int STRIDE>
+__global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const WgradArgs a) {
+  constexpr int KK = KS * KS, PAD = KS / 2;
+  constexpr int SR = 2, SC = 32, SP = SR * SC;  // strip: 2 rows x 32 cols of output pixels
+  constexpr int IH = (SR - 1) * STRIDE + KS, IW = (SC - 1) * STRIDE + KS;
+  constexpr int RS = IW;
+  constexpr int CHS = (IH * RS) | 1;  // odd channel stride: lanes = channels hit distinct banks
+  constexpr int DZS = SP + 1;         // odd row stride of the dZ tile
+  __shared__ float dzs[128 * DZS];
+  __shared__ float xs[32 * CHS];
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, j = lane & 31;
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 128, split = blockIdx.z;
+  const int ci_total = a.c1 + a.c2;
+  const int u_begin = (int)((int64_t)a.units * split / a.splits), u_end = (int)((int64_t)a.units * (split + 1) / a.splits);
+  const int hw = a.h * a.w, plane = a.ho * a.wo;
+
+  f32x16 acc[KK];
+#pragma unroll
+  for (int t = 0; t < KK; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int abase = (wave * 32 + j) * DZS + half;
+  const int bbase = j * CHS + half * STRIDE;
+
+  for (int u = u_begin; u < u_end; ++u) {
+    const int img = u / (a.strips_x * a.strips_y);
+    const int rem = u - img * (a.strips_x * a.strips_y);
+    const int oy0 = (rem / a.strips_x) * SR, ox0 = (rem % a.strips_x) * SC;
+    const float *dzi = a.dz + (int64_t)img * a.dz_img_stride;
+    const float *x1 = a.x1 + (int64_t)img * a.x1_img_stride;
+    const float *x2 = nullptr;
+    if (a.x2) {
+      const int i2 = a.x2_div > 0 ? (img / a.x2_div) * a.x2_mul + a.x2_add : img;
+      x2 = a.x2 + (int64_t)i2 * a.x2_img_stride;
+    }
+    __syncthreads();
+    // dZ tile: 128 channels x 64 pixels (zero past co / outside the image)
+#pragma unroll 4
+    for (int e = tid; e < 128 * SP; e += 256) {
+      const int c = e / SP, p = e - c * SP;
+      const int oy = oy0 + p / SC, ox = ox0 + p % SC;
+      const bool ok = (co0 + c) < a.co && oy < a.ho && ox < a.wo;
+      const float v = dzi[ok ? (int64_t)(co0 + c) * plane + oy * a.wo + ox : 0];
+      dzs[c * DZS + p] = ok ? v : 0.f;
+    }
+    // X halo tile: 32 channels x IH x IW
+    const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - PAD;
+#pragma unroll 4
+    for (int e = tid; e < 32 * IH * IW; e += 256) {
+      const int c = e / (IH * IW), r2 = e - c * (IH * IW);
+      const int iy = r2 / IW, ix = r2 - iy * IW;
+      const int gy = iy0 + iy, gx = ix0 + ix, cc = ci0 + c;
+      const bool ok = cc < ci_total && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+      const int cs = ok ? cc : 0;
+      const float *src = (cs < a.c1) ? (x1 + (int64_t)cs * hw) : (x2 + (int64_t)(cs - a.c1) * hw);
+      const float v = src[ok ? gy * a.w + gx : 0];
+      xs[c * CHS + iy * RS + ix] = ok ? v : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int q = 0; q < SP / 2; ++q) {
+      const int r = q / (SC / 2), c = 2 * (q % (SC / 2));
+      const float av = dzs[abase + 2 * q];
+#pragma unroll
+      for (int t = 0; t < KK; ++t) {
+        const int kh = t / KS, kw = t % KS;
+        const float bv = xs[bbase + (r * STRIDE + kh) * RS + c * STRIDE + kw];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  // partial tile -> workspace [split][co][ci][kk]
+  float *out = a.ws + (int64_t)split * a.co * ci_total * KK;
+  const int ci = ci0 + j;
+  if (ci < ci_total) {
+#pragma unroll
+    for (int t = 0; t < KK; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (co < a.co) out[((int64_t)co * ci_total + ci) * KK + t] = acc[t][r];
+      }
+  }
+}
+
+__global__ void wgrad_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw, int64_t total, int splits, int accumulate) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = accumulate ? dw[i] : 0.f;
+    for (int k = 0; k < splits; ++k) s += ws[(int64_t)k * total + i];
+    dw[i] = s;
+  }
+}
+
+// out[c] = sum_{n, p} x[n, c, p]
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float *__restrict__ x, float *__restrict__ out, int n, int64_t hw,
+                                                          int64_t img_stride) {
+  const int c = blockIdx.x;
+  float s = 0.f;
+  for (int b = 0; b < n; ++b) {
+    const float *row = x + (int64_t)b * img_stride + (int64_t)c * hw;
+    for (int64_t p = threadIdx.x; p < hw; p += 256) s += row[p];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[c] = red[0] + red[1] + red[2] + red[3];
+}
+
+static int wgrad_splits(int tiles, int units) {
+  int s = cdiv(1536, tiles);  // ~3 workgroups per CU slot pair
+  if (s > units) s = units;
+  if (s > 512) s = 512;
+  return s < 1 ? 1 : s;
+}
+
+}  // namespace edvr
+
+extern "C" {
+
+size_t edvr_conv2d_wgrad_ws_bytes(int n, int ci, int h, int w, int co, int ks, int stride) {
+  const int pad = ks / 2;
+  const int ho = (h + 2 * pad - ks) / stride + 1, wo = (w + 2 * pad - ks) / stride + 1;
+  const int units = n * edvr::cdiv(ho, 2) * edvr::cdiv(wo, 32);
+  const int tiles = edvr::cdiv(ci, 32) * edvr::cdiv(co, 128);
+  return (size_t)edvr::wgrad_splits(tiles, units) * co * ci * ks * ks * sizeof(float);
+}
+
+int edvr_conv2d_wgrad_f32(const float *x1, const float *x2, const float *dz, float *dw, int c1, int c2, int n, int h, int w, int co,
+                          int ks, int stride, int64_t x1_img_stride, int64_t x2_img_stride, int x2_div, int x2_mul, int x2_add,
+                          int64_t dz_img_stride, int accumulate, void *ws, size_t ws_bytes, edvr_stream_t stream_) {
+  using namespace edvr;
+  EDVR_REQUIRE(x1 && dz && dw && ws, "wgrad: null pointer");
+  EDVR_REQUIRE((x2 != nullptr) == (c2 > 0), "wgrad: x2/c2 mismatch");
+  EDVR_REQUIRE(n > 0 && h > 0 && w > 0 && c1 > 0 && co > 0, "wgrad: bad sizes");
+  if (!((ks == 3 && (stride == 1 || stride == 2)) || (ks == 1 && stride == 1))) {
+    set_error("wgrad: unsupported ks=%d stride=%d", ks, stride);
+    return EDVR_ERR_UNSUPPORTED;
+  }
+  WgradArgs a;
+  a.x1 = x1; a.x2 = x2; a.dz = dz; a.ws = static_cast<float *>(ws);
+  a.c1 = c1; a.c2 = c2; a.n = n; a.h = h; a.w = w; a.co = co;
+  const int pad = ks / 2;
+  a.ho = (h + 2 * pad - ks) / stride + 1;
+  a.wo = (w + 2 * pad - ks) / stride + 1;
+  a.x1_img_stride = x1_img_stride; a.x2_img_stride = x2_img_stride; a.dz_img_stride = dz_img_stride;
+  a.x2_div = x2_div; a.x2_mul = x2_mul; a.x2_add = x2_add;
+  a.strips_y = cdiv(a.ho, 2);
+  a.strips_x = cdiv(a.wo, 32);
+  a.units = n * a.strips_x * a.strips_y;
+  const int ci = c1 + c2;
+  const int tiles = cdiv(ci, 32) * cdiv(co, 128);
+  a.splits = wgrad_splits(tiles, a.units);
+  const size_t need = (size_t)a.splits * co * ci * ks * ks * sizeof(float);
+  if (ws_bytes < need) {
+    set_error("wgrad: workspace %zu < required %zu", ws_bytes, need);
+    return EDVR_ERR_WORKSPACE;
+  }
+  hipStream_t stream = as_stream(stream_);
+  dim3 grid(cdiv(ci, 32), cdiv(co, 128), a.splits);
+  if (ks == 3 && stride == 1) hipLaunchKernelGGL((conv2d_wgrad_kernel<3, 1>), grid, dim3(256), 0, stream, a);
+  else if (ks == 3) hipLaunchKernelGGL((conv2d_wgrad_kernel<3, 2>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((conv2d_wgrad_kernel<1, 1>), grid, dim3(256), 0, stream, a);
+  int rc = check_launch("conv2d_wgrad_kernel");
+  if (rc) return rc;
+  const int64_t total = (int64_t)co * ci * ks * ks;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 2048)), dim3(256), 0, stream, a.ws, dw,
+                     total, a.splits, accumulate);
+  return check_launch("wgrad_reduce_kernel");
+}
+
+int edvr_channel_sum_f32(const float *x, float *out, int n, int c, int64_t hw, int64_t img_stride, edvr_stream_t stream) {
+  using namespace edvr;
+  EDVR_REQUIRE(x && out && n > 0 && c > 0 && hw > 0, "channel_sum: bad arguments");
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(c), dim3(256), 0, as_stream(stream), x, out, n, hw, img_stride ? img_stride : (int64_t)c * hw);
+  return check_launch("channel_sum_kernel");
+}
+
+}  // extern "C"

@@ -102,6 +102,4 @@ class ModulatedDeformConvPack(ModulatedDeformConv):
 
     def forward(self, x):
         from . import functional as F_
-        offset, mask = F_.offset_mask_conv(self.conv_offset, x)
-        return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation,
-                                     self.groups, self.deformable_groups)
+        return F_.dcn_from_packed(self, x, F_.offset_mask_conv(self.conv_offset, x))

@@ -43,14 +43,22 @@ def conv(m, x, *, x2=None, x2_map=None, act=ACT_NONE, act_from=0, res1=None, res
 
 
 def offset_mask_conv(conv_offset, feat):
-    """conv_offset(feat) -> (offset, mask) as in arch_util.py:244-247 / deform_conv.py:384-387.
-
-    chunk(3) + cat(o1, o2) is channels [0, 2/3) and sigmoid(chunk 3) is channels [2/3, 1): both are
-    returned as zero-copy channel slices of ONE conv output, the sigmoid applied in the conv epilogue.
-    """
+    """conv_offset(feat) -> ONE tensor `om` (n, 3*dg*K, h, w) as in arch_util.py:244-247 / deform_conv.py:384-387:
+    chunk(3) + cat(o1, o2) is channels [0, 2/3) (offset) and sigmoid(chunk 3) is channels [2/3, 1) (mask), the sigmoid
+    applied in the conv epilogue.  Consumers take zero-copy channel slices."""
     co = conv_offset.out_channels
-    out = conv(conv_offset, feat, act=ACT_SIGMOID, act_from=2 * co // 3)
-    return out[:, :2 * co // 3], out[:, 2 * co // 3:]
+    return conv(conv_offset, feat, act=ACT_SIGMOID, act_from=2 * co // 3)
+
+
+def dcn_from_packed(m, x, om, act=ACT_NONE):
+    """Modulated deformable conv of module `m` (weight/bias/geometry) with offsets+masks packed in `om`."""
+    cfg = (m.stride, m.padding, m.dilation, m.groups, m.deformable_groups)
+    if _needs_grad(x, om, m.weight, m.bias):
+        from . import autograd as ag
+        return ag.DcnFromPackedFn.apply(x, om, m.weight, m.bias, (*cfg, act))
+    split = 2 * om.shape[1] // 3
+    bias = m.bias.detach() if m.bias is not None else None
+    return ops.dcnv2_forward(x, om[:, :split], om[:, split:], m.weight.detach(), bias, *cfg, act=act)
 
 
 def upsample2x(x, scale=1.0):

@@ -185,22 +185,25 @@ def dcnv2_forward(x, offset, mask, weight, bias, stride, pad, dil, groups, dg, a
     return y
 
 
-def dcnv2_backward(x, offset, mask, weight, dy, with_bias, stride, pad, dil, groups, dg):
+def dcnv2_backward(x, offset, mask, weight, dy, with_bias, stride, pad, dil, groups, dg, doffset=None, dmask=None):
+    """Returns (dx, doffset, dmask, dweight, dbias).  `doffset` / `dmask` may be preallocated channel slices of one
+    buffer (image-strided views): the kernels write them in place."""
     require_gpu(x, offset, mask, weight, dy)
     L = _lib.lib()
     offset, mask = _as_planes(offset), _as_planes(mask)
     dy = dy.contiguous()
     dims = _dcn_dims(x, weight, stride, pad, dil, groups, dg)
     dx = torch.empty_like(x)
-    doff = torch.empty(offset.shape, dtype=torch.float32, device=x.device)
-    dmsk = torch.empty(mask.shape, dtype=torch.float32, device=x.device)
+    doff = doffset if doffset is not None else torch.empty(offset.shape, dtype=torch.float32, device=x.device)
+    dmsk = dmask if dmask is not None else torch.empty(mask.shape, dtype=torch.float32, device=x.device)
+    assert _plane_contig(doff) and _plane_contig(dmsk)
     dw = torch.empty_like(weight)
     db = torch.empty(weight.shape[0], dtype=torch.float32, device=x.device) if with_bias else None
     nbytes = L.edvr_dcnv2_bwd_ws_bytes(*dims)
     ws = workspace(nbytes, x.device)
     _lib.check(L.edvr_dcnv2_bwd_f32(_ptr(x), _ptr(offset), _ptr(mask), _ptr(weight), _ptr(dy), _ptr(dx), _ptr(doff), _ptr(dmsk),
-                                    _ptr(dw), _ptr(db), *dims, _bstride(offset), _bstride(mask), _ptr(ws), nbytes, _stream()),
-               'edvr_dcnv2_bwd_f32')
+                                    _ptr(dw), _ptr(db), *dims, _bstride(offset), _bstride(mask), _bstride(doff), _bstride(dmsk),
+                                    _ptr(ws), nbytes, _stream()), 'edvr_dcnv2_bwd_f32')
     return dx, doff, dmsk, dw, db
 
 
@@ -263,15 +266,125 @@ def add(a, b):
     return y
 
 
-def act_backward(dy, y, act, act_from=0):
-    """dz = dy * act'(.) computed from the activation output y; (n, c, h, w) tensors."""
-    require_gpu(dy, y)
+def act_backward(dy, y, act, act_from=0, res1=None, res2=None):
+    """dz = dy * act'(.) computed from the activation output; y = act(z) + res1 + res2 as the fused conv wrote it."""
+    require_gpu(dy, y, res1, res2)
     dy, y = dy.contiguous(), y.contiguous()
+    res1 = res1.contiguous() if res1 is not None else None
+    res2 = res2.contiguous() if res2 is not None else None
     n, c = y.shape[:2]
     dz = torch.empty_like(dy)
-    _lib.check(_lib.lib().edvr_act_bwd_f32(_ptr(dy), _ptr(y), _ptr(dz), n, c, y[0, 0].numel(), act, act_from, _stream()),
-               'edvr_act_bwd_f32')
+    _lib.check(_lib.lib().edvr_act_bwd_f32(_ptr(dy), _ptr(y), _ptr(res1), _ptr(res2), _ptr(dz), n, c, y[0, 0].numel(), act, act_from,
+                                           _stream()), 'edvr_act_bwd_f32')
     return dz
+
+
+def conv2d_wgrad(x1, x2, x2_map, dz, co, ks, stride):
+    """dW (co, c1+c2, ks, ks) of the fused conv, fp32 MFMA implicit GEMM over the pixel axis."""
+    require_gpu(x1, x2, dz)
+    L = _lib.lib()
+    x1, dz = _as_planes(x1), _as_planes(dz)
+    n, c1, h, w = x1.shape
+    c2 = 0
+    if x2 is not None:
+        x2 = _as_planes(x2)
+        c2 = x2.shape[1]
+    div, mul, add = x2_map if x2_map is not None else (0, 0, 0)
+    dw = torch.empty(co, c1 + c2, ks, ks, dtype=torch.float32, device=x1.device)
+    nbytes = L.edvr_conv2d_wgrad_ws_bytes(n, c1 + c2, h, w, co, ks, stride)
+    ws = workspace(nbytes, x1.device)
+    _lib.check(L.edvr_conv2d_wgrad_f32(_ptr(x1), _ptr(x2), _ptr(dz), _ptr(dw), c1, c2, n, h, w, co, ks, stride, _img_stride(x1),
+                                       _img_stride(x2) if x2 is not None else 0, div, mul, add, _img_stride(dz), 0, _ptr(ws), nbytes,
+                                       _stream()), 'edvr_conv2d_wgrad_f32')
+    return dw
+
+
+def channel_sum(x):
+    require_gpu(x)
+    x = _as_planes(x)
+    n, c, h, w = x.shape
+    out = torch.empty(c, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().edvr_channel_sum_f32(_ptr(x), _ptr(out), n, c, h * w, _img_stride(x), _stream()), 'edvr_channel_sum_f32')
+    return out
+
+
+def pixel_unshuffle2(x):
+    require_gpu(x)
+    x = x.contiguous()
+    n, c, h2, w2 = x.shape
+    y = torch.empty(n, 4 * c, h2 // 2, w2 // 2, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().edvr_pixel_unshuffle2_f32(_ptr(x), _ptr(y), n, c, h2 // 2, w2 // 2, _stream()), 'edvr_pixel_unshuffle2_f32')
+    return y
+
+
+def zero_stuff2(dz, H, W):
+    require_gpu(dz)
+    dz = dz.contiguous()
+    n, c, ho, wo = dz.shape
+    z = torch.empty(n, c, H, W, dtype=torch.float32, device=dz.device)
+    _lib.check(_lib.lib().edvr_zero_stuff2_f32(_ptr(dz), _ptr(z), n * c, H, W, ho, wo, _stream()), 'edvr_zero_stuff2_f32')
+    return z
+
+
+def frame_reduce_add_(src, dst, t, center):
+    """dst[b, center] += sum_t src[b, t] for (b*t, c, h, w) tensors."""
+    require_gpu(src, dst)
+    src = src.contiguous()
+    assert dst.is_contiguous() and src.shape == dst.shape and src.shape[0] % t == 0
+    _lib.check(_lib.lib().edvr_frame_reduce_add_f32(_ptr(src), _ptr(dst), src.shape[0] // t, t, center, src[0].numel(), _stream()),
+               'edvr_frame_reduce_add_f32')
+    return dst
+
+
+def upsample2x_backward(dy, scale=1.0):
+    require_gpu(dy)
+    dy = dy.contiguous()
+    n, c, h2, w2 = dy.shape
+    dx = torch.empty(n, c, h2 // 2, w2 // 2, dtype=torch.float32, device=dy.device)
+    _lib.check(_lib.lib().edvr_upsample2x_bwd_f32(_ptr(dy), _ptr(dx), n * c, h2 // 2, w2 // 2, float(scale), _stream()),
+               'edvr_upsample2x_bwd_f32')
+    return dx
+
+
+def pool_maxavg_backward(x, dy):
+    require_gpu(x, dy)
+    x, dy = x.contiguous(), dy.contiguous()
+    n, c, h, w = x.shape
+    dx = torch.empty_like(x)
+    _lib.check(_lib.lib().edvr_pool_maxavg_3x3s2_bwd_f32(_ptr(x), _ptr(dy), _ptr(dx), n, c, h, w, _stream()),
+               'edvr_pool_maxavg_3x3s2_bwd_f32')
+    return dx
+
+
+def tsa_temporal_backward(emb, emb_ref, aligned, dout):
+    require_gpu(emb, emb_ref, aligned, dout)
+    emb, emb_ref, aligned, dout = emb.contiguous(), emb_ref.contiguous(), aligned.contiguous(), dout.contiguous()
+    b, t, c, h, w = aligned.shape
+    d_emb, d_ref, d_al = torch.empty_like(emb), torch.empty_like(emb_ref), torch.empty_like(aligned)
+    _lib.check(_lib.lib().edvr_tsa_temporal_bwd_f32(_ptr(emb), _ptr(emb_ref), _ptr(aligned), _ptr(dout), _ptr(d_emb), _ptr(d_ref),
+                                                    _ptr(d_al), b, t, c, h * w, _stream()), 'edvr_tsa_temporal_bwd_f32')
+    return d_emb, d_ref, d_al
+
+
+def tsa_combine_backward(feat, attn, dy):
+    require_gpu(feat, attn, dy)
+    feat, attn, dy = feat.contiguous(), attn.contiguous(), dy.contiguous()
+    dfeat, dattn = torch.empty_like(feat), torch.empty_like(attn)
+    _lib.check(_lib.lib().edvr_tsa_combine_bwd_f32(_ptr(feat), _ptr(attn), _ptr(dy), _ptr(dfeat), _ptr(dattn), feat.numel(), _stream()),
+               'edvr_tsa_combine_bwd_f32')
+    return dfeat, dattn
+
+
+def charbonnier(pred, target, eps=1e-12, want_grad=True, grad_scale=1.0):
+    """CharbonnierLoss(reduction='sum'): returns (loss (1,) device tensor, dloss/dpred or None) from one pass."""
+    require_gpu(pred, target)
+    pred, target = pred.contiguous(), target.contiguous()
+    assert pred.shape == target.shape
+    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    dpred = torch.empty_like(pred) if want_grad else None
+    _lib.check(_lib.lib().edvr_charbonnier_f32(_ptr(pred), _ptr(target), _ptr(loss), _ptr(dpred), pred.numel(), float(eps),
+                                               float(grad_scale), _stream()), 'edvr_charbonnier_f32')
+    return loss, dpred
 
 
 def abs_sum_per_image(x):

@@ -119,7 +119,10 @@ size_t edvr_dcnv2_bwd_ws_bytes(int B, int C, int H, int W, int Co, int kh, int k
 int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, const float *weight, const float *dy,
                        float *dx, float *doffset, float *dmask, float *dweight, float *dbias, int B, int C, int H,
                        int W, int Co, int kh, int kw, int stride, int pad, int dil, int groups, int dg,
-                       int64_t offset_bstride, int64_t mask_bstride, void *ws, size_t ws_bytes, edvr_stream_t stream);
+                       int64_t offset_bstride, int64_t mask_bstride, int64_t doffset_bstride, int64_t dmask_bstride,
+                       void *ws, size_t ws_bytes, edvr_stream_t stream);
+/* doffset_bstride / dmask_bstride (0 = contiguous): image strides of the two gradient outputs, so both can be
+ * written straight into channel slices of one (B, 3*dg*K, Ho, Wo) buffer = the gradient of conv_offset's output. */
 
 /* ------------------------------------------------------------------ TSA / PCD glue kernels (HBM-bound) */
 /* Temporal attention (edvr_arch.py:171-184): prob[b,t,p] = sigmoid(sum_c emb[b,t,c,p]*emb_ref[b,c,p]);
@@ -139,11 +142,40 @@ int edvr_upsample4x_add_f32(const float *base, float *y, int nc, int h, int w, e
 int edvr_add_f32(const float *a, const float *b, float *y, int64_t numel, edvr_stream_t stream);
 /* dz = dy * act'(.) expressed through the activation OUTPUT y (relu: y>0; lrelu: y>0 ? 1 : 0.1;
  * sigmoid: y(1-y)); channels < act_from of an (n, c, hw) tensor pass through unchanged. */
-int edvr_act_bwd_f32(const float *dy, const float *y, float *dz, int n, int c, int64_t hw, int act, int act_from,
-                     edvr_stream_t stream);
+int edvr_act_bwd_f32(const float *dy, const float *y, const float *res1, const float *res2, float *dz, int n, int c,
+                     int64_t hw, int act, int act_from, edvr_stream_t stream);
+/* res1/res2 (nullable): the fused conv computed y = act(z) + res1 + res2; they are subtracted to recover act(z). */
 /* out[i] = sum |x[i, :per_img]| for each of n images (image stride img_stride) - feeds the
  * "offset abs mean > 50" warning of arch_util.py:248-253 without a per-call host sync. */
 int edvr_abs_sum_f32(const float *x, float *out, int n, int64_t per_img, int64_t img_stride, edvr_stream_t stream);
+
+/* ------------------------------------------------------------------ training: gradients of the fused launches
+ * (what autograd runs under SRModel.optimize_parameters, basicsr/models/sr_model.py:88-112) */
+/* dW (co, c1+c2, ks, ks) (+)= sum_{n,pixel} dz[n,co,pixel] * cat(x1,x2)[n,ci,pixel*stride+tap-pad]; fp32 MFMA implicit GEMM,
+ * deterministic split-K through `ws`.  x2 image map as in edvr_conv2d_desc. */
+size_t edvr_conv2d_wgrad_ws_bytes(int n, int ci, int h, int w, int co, int ks, int stride);
+int edvr_conv2d_wgrad_f32(const float *x1, const float *x2, const float *dz, float *dw, int c1, int c2, int n, int h, int w,
+                          int co, int ks, int stride, int64_t x1_img_stride, int64_t x2_img_stride, int x2_div, int x2_mul,
+                          int x2_add, int64_t dz_img_stride, int accumulate, void *ws, size_t ws_bytes, edvr_stream_t stream);
+/* out[c] = sum_{n,p} x[n,c,p]  (bias gradient); img_stride 0 = contiguous */
+int edvr_channel_sum_f32(const float *x, float *out, int n, int c, int64_t hw, int64_t img_stride, edvr_stream_t stream);
+/* inverse of PixelShuffle(2): x (n, c, 2h, 2w) -> y (n, 4c, h, w) */
+int edvr_pixel_unshuffle2_f32(const float *x, float *y, int n, int c, int h, int w, edvr_stream_t stream);
+/* z (nc, H, W): z[2oy,2ox] = dz[oy,ox] (dz is (nc, ho, wo)), 0 elsewhere - the stride-2 data gradient is the
+ * stride-1 transposed-kernel conv of z */
+int edvr_zero_stuff2_f32(const float *dz, float *z, int nc, int H, int W, int ho, int wo, edvr_stream_t stream);
+/* dst[b, center, :] += sum_t src[b, t, :]   (src, dst: (b, t, chw)) */
+int edvr_frame_reduce_add_f32(const float *src, float *dst, int b, int t, int center, int64_t chw, edvr_stream_t stream);
+int edvr_upsample2x_bwd_f32(const float *dy, float *dx, int nc, int h, int w, float scale, edvr_stream_t stream);
+int edvr_pool_maxavg_3x3s2_bwd_f32(const float *x, const float *dy, float *dx, int n, int c, int h, int w, edvr_stream_t stream);
+int edvr_tsa_temporal_bwd_f32(const float *emb, const float *emb_ref, const float *aligned, const float *dout, float *d_emb,
+                              float *d_emb_ref, float *d_aligned, int b, int t, int c, int hw, edvr_stream_t stream);
+int edvr_tsa_combine_bwd_f32(const float *feat, const float *attn, const float *dy, float *dfeat, float *dattn, int64_t numel,
+                             edvr_stream_t stream);
+/* CharbonnierLoss, reduction 'sum' (basicsr/models/losses/losses.py:23-25): *loss = sum sqrt((p-t)^2 + eps) and, if dpred != NULL,
+ * dpred = grad_scale * (p-t)/sqrt((p-t)^2+eps) in the same pass. */
+int edvr_charbonnier_f32(const float *pred, const float *target, float *loss, float *dpred, int64_t numel, float eps,
+                         float grad_scale, edvr_stream_t stream);
 
 #ifdef __cplusplus
 }
