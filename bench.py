@@ -39,6 +39,11 @@ WORKLOADS = {
     'edvr_m_x4_t5_180x320': dict(net=dict(num_feat=64, num_frame=5, num_reconstruct_block=10, center_frame_idx=2),
                                  shape=(5, 3, 180, 320), batch=4,
                                  desc='EDVR-M x4, 5 frames, 180x320 LR -> 720x1280, batch 4/GPU, inference'),
+    # BASELINE.json configs[3]: EDVR-L training, 5 frames, 64x64 LR crops, 32 clips per GPU (global 256 on 8)
+    'edvr_l_train_t5_64x64': dict(net=dict(num_feat=128, num_frame=5, num_reconstruct_block=40, center_frame_idx=None),
+                                  shape=(5, 3, 64, 64), batch=32,
+                                  desc='EDVR-L x4 training, 5 frames, 64x64 LR crops (256x256 GT), 32 clips/GPU, '
+                                       'Charbonnier(sum) + Adam(4e-4, betas 0.9/0.99), DDP'),
     # BASELINE.json configs[0] (plumbing-sized)
     'edvr_m_x4_t5_64x64': dict(net=dict(num_feat=64, num_frame=5, num_reconstruct_block=10, center_frame_idx=2),
                                shape=(5, 3, 64, 64), batch=1, desc='EDVR-M x4, 5 frames, 64x64 LR crop, batch 1'),
@@ -52,6 +57,8 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='edvr_l_x4_t5_180x320', choices=list(WORKLOADS))
     ap.add_argument('--batch', type=int, default=0, help='clips per GPU (default: the workload\'s)')
+    ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
+                    help='infer: forward clips/s (default).  train: fwd + Charbonnier + bwd + grad all-reduce + Adam')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     return ap.parse_args()
@@ -128,15 +135,35 @@ def main():
     from edvr_amd import _lib
     assert _lib.lib().edvr_check_device() == 0, _lib.lib().edvr_last_error().decode()
 
+    if args.mode == 'train' and not args.workload.startswith('edvr_l_train'):
+        args.workload = 'edvr_l_train_t5_64x64'
     cfg = WORKLOADS[args.workload]
     batch = args.batch or cfg['batch']
     net = build_net(cfg, device)
     # per-rank clips (seed + rank, like train.py:53): generated on the CPU, resident in HBM before timing
     x = torch.rand(batch, *cfg['shape'], generator=torch.Generator().manual_seed(rank)).to(device)
 
-    def step():
-        with torch.no_grad():
-            return net(x)
+    if args.mode == 'train':
+        from edvr_amd import dist as D
+        from edvr_amd.autograd import charbonnier_loss
+        net.train()
+        gt = torch.rand(batch, 3, 4 * cfg['shape'][2], 4 * cfg['shape'][3], generator=torch.Generator().manual_seed(1000 + rank)).to(device)
+        model = D.wrap_ddp(net)  # RCCL gradient all-reduce, bucketed and overlapped with backward
+        dcn = [p for n, p in net.named_parameters() if 'dcn' in n]  # edvr_model.py:21-53 (dcn_lr_mul: 1)
+        rest = [p for n, p in net.named_parameters() if 'dcn' not in n]
+        opt = torch.optim.Adam([{'params': rest, 'lr': 4e-4}, {'params': dcn, 'lr': 4e-4 * 1}], lr=4e-4, betas=(0.9, 0.99))
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            out = model(x)
+            loss = charbonnier_loss(out, gt)
+            loss.backward()
+            opt.step()
+            return loss.detach()
+    else:
+        def step():
+            with torch.no_grad():
+                return net(x)
 
     for _ in range(args.warmup):
         step()
@@ -161,16 +188,24 @@ def main():
     result = None
     if rank == 0:
         clips = batch * world * args.steps
+        if args.mode == 'train':
+            metric = 'EDVR-L x4 training clips/sec (= iters/sec x global batch)'
+        else:
+            metric = 'EDVR-L x4 5-frame 720p clips/sec' if args.workload.startswith('edvr_l') else 'EDVR-M x4 5-frame 720p clips/sec'
         result = {
-            'metric': 'EDVR-L x4 5-frame 720p clips/sec' if args.workload.startswith('edvr_l') else 'EDVR-M x4 5-frame 720p clips/sec',
+            'metric': metric,
             'value': round(clips / elapsed, 4), 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic (uniform [0,1) REDS-shaped clips; random-init weights, '
             'manual_seed 10, conv_offset ~ N(0,0.02)/N(0,0.5) so taps are non-integer)',
             'config': {'workload': cfg['desc'], 'clips_per_gpu': batch, 'global_clips': batch * world,
-                       'parallelism': f'clip-sharded x{world}, no data-path collective'},
+                       'parallelism': (f'DDP x{world}: RCCL gradient all-reduce (82.5 MB fp32)' if args.mode == 'train'
+                                       else f'clip-sharded x{world}, no data-path collective')},
         }
-        if not args.no_roofline:
+        if args.mode == 'train':
+            result['iters_per_sec'] = round(args.steps / elapsed, 4)
+            result['optimizer'] = 'torch.optim.Adam (as the reference; fused Adam is SURVEY 8(f) next)'
+        if not args.no_roofline and args.mode == 'infer':
             per = instrumented_pass(net, x, max(1, min(args.steps, 3)))
             name = max(per, key=lambda k: per[k][2])
             n, flops, secs = per[name]
@@ -183,7 +218,7 @@ def main():
                                      for k, v in sorted(per.items(), key=lambda kv: -kv[1][2])},
                 'conv_time_share_of_step': round(total_conv_s / max(1, min(args.steps, 3)) / (elapsed / args.steps), 3),
             }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and args.mode == 'infer':
             result['cpu_baseline'] = cpu_baseline(cfg)
         print(json.dumps(result), flush=True)
     if dist:

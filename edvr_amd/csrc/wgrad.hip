@@ -28,19 +28,27 @@ struct WgradArgs {
   int strips_x, strips_y, units, splits;
 };
 
-template <int KS, int STRIDE>
-__global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const WgradArgs a) {
+#ifndef EDVR_WGRAD_MINWAVES
+#define EDVR_WGRAD_MINWAVES 1  // 144 accumulator + 49 prefetch registers: needs the 512-register budget (measured 89 vs 64 TF/s)
+#endif
+
+// MW = 32-channel output tiles per workgroup (4, 2 or 1); the 4 waves split into MW co-tiles x NG = 4/MW
+// groups of 32 input channels, so narrow layers (co <= 64) still keep all four SIMDs busy.
+template <int KS, int STRIDE, int MW>
+__global__ __launch_bounds__(256, EDVR_WGRAD_MINWAVES) void conv2d_wgrad_kernel(const WgradArgs a) {
+  constexpr int NG = 4 / MW, COB = 32 * MW, CIB = 32 * NG;
   constexpr int KK = KS * KS, PAD = KS / 2;
   constexpr int SR = 2, SC = 32, SP = SR * SC;  // strip: 2 rows x 32 cols of output pixels
   constexpr int IH = (SR - 1) * STRIDE + KS, IW = (SC - 1) * STRIDE + KS;
   constexpr int RS = IW;
   constexpr int CHS = (IH * RS) | 1;  // odd channel stride: lanes = channels hit distinct banks
   constexpr int DZS = SP + 1;         // odd row stride of the dZ tile
-  __shared__ float dzs[128 * DZS];
-  __shared__ float xs[32 * CHS];
+  __shared__ float dzs[COB * DZS];
+  __shared__ float xs[CIB * CHS];
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, j = lane & 31;
-  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 128, split = blockIdx.z;
+  const int ci0 = blockIdx.x * CIB, co0 = blockIdx.y * COB, split = blockIdx.z;
+  const int wm = wave % MW, wg = wave / MW;
   const int ci_total = a.c1 + a.c2;
   const int u_begin = (int)((int64_t)a.units * split / a.splits), u_end = (int)((int64_t)a.units * (split + 1) / a.splits);
   const int hw = a.h * a.w, plane = a.ho * a.wo;
@@ -51,44 +59,75 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const WgradArgs a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  const int abase = (wave * 32 + j) * DZS + half;
-  const int bbase = j * CHS + half * STRIDE;
+  const int abase = (wm * 32 + j) * DZS + half;
+  const int bbase = (wg * 32 + j) * CHS + half * STRIDE;
 
-  for (int u = u_begin; u < u_end; ++u) {
+  // Register-prefetch pipeline (as in conv2d.hip): the loads of strip u+1 are issued before the MFMA block of
+  // strip u and committed to LDS after it.  All loads unconditional (clamped address + select).
+  constexpr int NDZ = COB * SP / 256;                  // dZ elements per thread per strip
+  constexpr int XE = CIB * IH * IW;                    // X halo elements per strip
+  constexpr int NXE = (XE + 255) / 256;
+  float dzr[NDZ], xr[NXE];
+  // strip-invariant per-thread decomposition
+  const int dz_p = tid % SP, dz_c0 = tid / SP;         // 256 threads cover 4 channels x 64 pixels per pass
+  const int dz_r = dz_p / SC, dz_col = dz_p % SC;
+
+  auto prefetch = [&](int u) {
     const int img = u / (a.strips_x * a.strips_y);
     const int rem = u - img * (a.strips_x * a.strips_y);
     const int oy0 = (rem / a.strips_x) * SR, ox0 = (rem % a.strips_x) * SC;
     const float *dzi = a.dz + (int64_t)img * a.dz_img_stride;
     const float *x1 = a.x1 + (int64_t)img * a.x1_img_stride;
-    const float *x2 = nullptr;
+    const float *x2 = a.x1;
     if (a.x2) {
       const int i2 = a.x2_div > 0 ? (img / a.x2_div) * a.x2_mul + a.x2_add : img;
       x2 = a.x2 + (int64_t)i2 * a.x2_img_stride;
     }
-    __syncthreads();
-    // dZ tile: 128 channels x 64 pixels (zero past co / outside the image)
-#pragma unroll 4
-    for (int e = tid; e < 128 * SP; e += 256) {
-      const int c = e / SP, p = e - c * SP;
-      const int oy = oy0 + p / SC, ox = ox0 + p % SC;
-      const bool ok = (co0 + c) < a.co && oy < a.ho && ox < a.wo;
-      const float v = dzi[ok ? (int64_t)(co0 + c) * plane + oy * a.wo + ox : 0];
-      dzs[c * DZS + p] = ok ? v : 0.f;
+    const int oy = oy0 + dz_r, ox = ox0 + dz_col;
+    const bool pok = oy < a.ho && ox < a.wo;
+    const int poff = pok ? oy * a.wo + ox : 0;
+#pragma unroll
+    for (int i = 0; i < NDZ; ++i) {
+      const int c = co0 + dz_c0 + i * (256 / SP);
+      const bool ok = pok && c < a.co;
+      const float v = dzi[(int64_t)(ok ? c : 0) * plane + poff];
+      dzr[i] = ok ? v : 0.f;
     }
-    // X halo tile: 32 channels x IH x IW
     const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - PAD;
-#pragma unroll 4
-    for (int e = tid; e < 32 * IH * IW; e += 256) {
+#pragma unroll
+    for (int i = 0; i < NXE; ++i) {
+      const int e = tid + i * 256;
       const int c = e / (IH * IW), r2 = e - c * (IH * IW);
       const int iy = r2 / IW, ix = r2 - iy * IW;
       const int gy = iy0 + iy, gx = ix0 + ix, cc = ci0 + c;
-      const bool ok = cc < ci_total && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+      const bool ok = e < XE && cc < ci_total && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
       const int cs = ok ? cc : 0;
       const float *src = (cs < a.c1) ? (x1 + (int64_t)cs * hw) : (x2 + (int64_t)(cs - a.c1) * hw);
       const float v = src[ok ? gy * a.w + gx : 0];
-      xs[c * CHS + iy * RS + ix] = ok ? v : 0.f;
+      xr[i] = ok ? v : 0.f;
     }
-    __syncthreads();
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < NDZ; ++i) dzs[(dz_c0 + i * (256 / SP)) * DZS + dz_p] = dzr[i];
+#pragma unroll
+    for (int i = 0; i < NXE; ++i) {
+      const int e = tid + i * 256;
+      if ((i + 1) * 256 <= XE || e < XE) {
+        const int c = e / (IH * IW), r2 = e - c * (IH * IW);
+        xs[c * CHS + r2] = xr[i];  // RS == IW, so (iy, ix) -> iy*RS + ix == r2
+      }
+    }
+  };
+
+  if (u_begin < u_end) {
+    prefetch(u_begin);
+    commit();
+  }
+  __syncthreads();
+  for (int u = u_begin; u < u_end; ++u) {
+    const bool more = (u + 1) < u_end;
+    if (more) prefetch(u + 1);
 #pragma unroll 4
     for (int q = 0; q < SP / 2; ++q) {
       const int r = q / (SC / 2), c = 2 * (q % (SC / 2));
@@ -100,16 +139,21 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const WgradArgs a)
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
       }
     }
+    if (more) {
+      __syncthreads();
+      commit();
+      __syncthreads();
+    }
   }
   // partial tile -> workspace [split][co][ci][kk]
   float *out = a.ws + (int64_t)split * a.co * ci_total * KK;
-  const int ci = ci0 + j;
+  const int ci = ci0 + wg * 32 + j;
   if (ci < ci_total) {
 #pragma unroll
     for (int t = 0; t < KK; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int co = co0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (co < a.co) out[((int64_t)co * ci_total + ci) * KK + t] = acc[t][r];
       }
   }
@@ -123,25 +167,40 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ ws, float *__restr
   }
 }
 
-// out[c] = sum_{n, p} x[n, c, p]
-__global__ __launch_bounds__(256) void channel_sum_kernel(const float *__restrict__ x, float *__restrict__ out, int n, int64_t hw,
-                                                          int64_t img_stride) {
-  const int c = blockIdx.x;
+// part[chunk][c] = sum over this chunk's (image, pixel) range of x[n, c, p]; then out[c] = sum_chunk part
+__global__ __launch_bounds__(256) void channel_sum_partial_kernel(const float *__restrict__ x, float *__restrict__ part, int n, int c_total,
+                                                                  int64_t hw, int64_t img_stride, int chunks) {
+  const int c = blockIdx.x, chunk = blockIdx.y;
+  const int64_t total = (int64_t)n * hw;
+  const int64_t lo = total * chunk / chunks, hi = total * (chunk + 1) / chunks;
   float s = 0.f;
-  for (int b = 0; b < n; ++b) {
-    const float *row = x + (int64_t)b * img_stride + (int64_t)c * hw;
-    for (int64_t p = threadIdx.x; p < hw; p += 256) s += row[p];
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+    const int64_t b = i / hw, p = i - b * hw;
+    s += x[b * img_stride + (int64_t)c * hw + p];
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
   __shared__ float red[4];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) out[c] = red[0] + red[1] + red[2] + red[3];
+  if (threadIdx.x == 0) part[(int64_t)chunk * c_total + c] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void channel_sum_final_kernel(const float *__restrict__ part, float *__restrict__ out, int c_total, int chunks) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= c_total) return;
+  float s = 0.f;
+  for (int k = 0; k < chunks; ++k) s += part[(int64_t)k * c_total + c];
+  out[c] = s;
+}
+
+static inline int wgrad_mw(int co, int stride) {
+  const int mw = co > 64 ? 4 : (co > 32 ? 2 : 1);
+  return (stride == 2 && mw == 1) ? 2 : mw;  // the stride-2 halo tile of 128 input channels would not fit LDS
 }
 
 static int wgrad_splits(int tiles, int units) {
-  int s = cdiv(1536, tiles);  // ~3 workgroups per CU slot pair
+  int s = cdiv(768, tiles);  // ~1.5 waves of 2 workgroups per CU; fewer splits = less partial-tile traffic
   if (s > units) s = units;
   if (s > 512) s = 512;
   return s < 1 ? 1 : s;
@@ -155,7 +214,8 @@ size_t edvr_conv2d_wgrad_ws_bytes(int n, int ci, int h, int w, int co, int ks, i
   const int pad = ks / 2;
   const int ho = (h + 2 * pad - ks) / stride + 1, wo = (w + 2 * pad - ks) / stride + 1;
   const int units = n * edvr::cdiv(ho, 2) * edvr::cdiv(wo, 32);
-  const int tiles = edvr::cdiv(ci, 32) * edvr::cdiv(co, 128);
+  const int mw = edvr::wgrad_mw(co, stride);
+  const int tiles = edvr::cdiv(ci, 32 * (4 / mw)) * edvr::cdiv(co, 32 * mw);
   return (size_t)edvr::wgrad_splits(tiles, units) * co * ci * ks * ks * sizeof(float);
 }
 
@@ -182,7 +242,8 @@ int edvr_conv2d_wgrad_f32(const float *x1, const float *x2, const float *dz, flo
   a.strips_x = cdiv(a.wo, 32);
   a.units = n * a.strips_x * a.strips_y;
   const int ci = c1 + c2;
-  const int tiles = cdiv(ci, 32) * cdiv(co, 128);
+  const int mw = wgrad_mw(co, stride);
+  const int tiles = cdiv(ci, 32 * (4 / mw)) * cdiv(co, 32 * mw);
   a.splits = wgrad_splits(tiles, a.units);
   const size_t need = (size_t)a.splits * co * ci * ks * ks * sizeof(float);
   if (ws_bytes < need) {
@@ -190,10 +251,17 @@ int edvr_conv2d_wgrad_f32(const float *x1, const float *x2, const float *dz, flo
     return EDVR_ERR_WORKSPACE;
   }
   hipStream_t stream = as_stream(stream_);
-  dim3 grid(cdiv(ci, 32), cdiv(co, 128), a.splits);
-  if (ks == 3 && stride == 1) hipLaunchKernelGGL((conv2d_wgrad_kernel<3, 1>), grid, dim3(256), 0, stream, a);
-  else if (ks == 3) hipLaunchKernelGGL((conv2d_wgrad_kernel<3, 2>), grid, dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL((conv2d_wgrad_kernel<1, 1>), grid, dim3(256), 0, stream, a);
+  dim3 grid(cdiv(ci, 32 * (4 / mw)), cdiv(co, 32 * mw), a.splits);
+#define EDVR_WGRAD_LAUNCH(KS_, ST_)                                                                                   \
+  do {                                                                                                                \
+    if (mw == 4) hipLaunchKernelGGL((conv2d_wgrad_kernel<KS_, ST_, 4>), grid, dim3(256), 0, stream, a);              \
+    else if (mw == 2) hipLaunchKernelGGL((conv2d_wgrad_kernel<KS_, ST_, 2>), grid, dim3(256), 0, stream, a);         \
+    else hipLaunchKernelGGL((conv2d_wgrad_kernel<KS_, 1, 1>), grid, dim3(256), 0, stream, a);                        \
+  } while (0)
+  if (ks == 3 && stride == 1) EDVR_WGRAD_LAUNCH(3, 1);
+  else if (ks == 3) EDVR_WGRAD_LAUNCH(3, 2);  /* mw is never 1 here */
+  else EDVR_WGRAD_LAUNCH(1, 1);
+#undef EDVR_WGRAD_LAUNCH
   int rc = check_launch("conv2d_wgrad_kernel");
   if (rc) return rc;
   const int64_t total = (int64_t)co * ci * ks * ks;
@@ -202,11 +270,19 @@ int edvr_conv2d_wgrad_f32(const float *x1, const float *x2, const float *dz, flo
   return check_launch("wgrad_reduce_kernel");
 }
 
-int edvr_channel_sum_f32(const float *x, float *out, int n, int c, int64_t hw, int64_t img_stride, edvr_stream_t stream) {
+int edvr_channel_sum_f32(const float *x, float *out, int n, int c, int64_t hw, int64_t img_stride, void *ws, size_t ws_bytes,
+                         edvr_stream_t stream) {
   using namespace edvr;
   EDVR_REQUIRE(x && out && n > 0 && c > 0 && hw > 0, "channel_sum: bad arguments");
-  hipLaunchKernelGGL(channel_sum_kernel, dim3(c), dim3(256), 0, as_stream(stream), x, out, n, hw, img_stride ? img_stride : (int64_t)c * hw);
-  return check_launch("channel_sum_kernel");
+  int chunks = (int)std::min<int64_t>(64, std::max<int64_t>(1, (int64_t)n * hw / 4096));
+  if (!ws || ws_bytes < (size_t)chunks * c * sizeof(float)) chunks = 1;  // degrade gracefully: one chunk needs no scratch
+  float *part = chunks > 1 ? static_cast<float *>(ws) : out;
+  hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(c, chunks), dim3(256), 0, as_stream(stream), x, part, n, c, hw,
+                     img_stride ? img_stride : (int64_t)c * hw, chunks);
+  int rc = check_launch("channel_sum_partial_kernel");
+  if (rc || chunks == 1) return rc;
+  hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(c, 256)), dim3(256), 0, as_stream(stream), part, out, c, chunks);
+  return check_launch("channel_sum_final_kernel");
 }
 
 }  // extern "C"

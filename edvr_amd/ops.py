@@ -304,7 +304,10 @@ def channel_sum(x):
     x = _as_planes(x)
     n, c, h, w = x.shape
     out = torch.empty(c, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().edvr_channel_sum_f32(_ptr(x), _ptr(out), n, c, h * w, _img_stride(x), _stream()), 'edvr_channel_sum_f32')
+    nbytes = 64 * c * 4
+    ws = workspace(nbytes, x.device)
+    _lib.check(_lib.lib().edvr_channel_sum_f32(_ptr(x), _ptr(out), n, c, h * w, _img_stride(x), _ptr(ws), nbytes, _stream()),
+               'edvr_channel_sum_f32')
     return out
 
 

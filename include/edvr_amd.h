@@ -157,8 +157,10 @@ size_t edvr_conv2d_wgrad_ws_bytes(int n, int ci, int h, int w, int co, int ks, i
 int edvr_conv2d_wgrad_f32(const float *x1, const float *x2, const float *dz, float *dw, int c1, int c2, int n, int h, int w,
                           int co, int ks, int stride, int64_t x1_img_stride, int64_t x2_img_stride, int x2_div, int x2_mul,
                           int x2_add, int64_t dz_img_stride, int accumulate, void *ws, size_t ws_bytes, edvr_stream_t stream);
-/* out[c] = sum_{n,p} x[n,c,p]  (bias gradient); img_stride 0 = contiguous */
-int edvr_channel_sum_f32(const float *x, float *out, int n, int c, int64_t hw, int64_t img_stride, edvr_stream_t stream);
+/* out[c] = sum_{n,p} x[n,c,p]  (bias gradient); img_stride 0 = contiguous; ws: >= 64*c floats of scratch for the
+ * deterministic two-stage reduction (NULL = single-stage, slower) */
+int edvr_channel_sum_f32(const float *x, float *out, int n, int c, int64_t hw, int64_t img_stride, void *ws, size_t ws_bytes,
+                         edvr_stream_t stream);
 /* inverse of PixelShuffle(2): x (n, c, 2h, 2w) -> y (n, 4c, h, w) */
 int edvr_pixel_unshuffle2_f32(const float *x, float *y, int n, int c, int h, int w, edvr_stream_t stream);
 /* z (nc, H, W): z[2oy,2ox] = dz[oy,ox] (dz is (nc, ho, wo)), 0 elsewhere - the stride-2 data gradient is the
