@@ -73,9 +73,10 @@ class DcnFromPackedFn(Function):
 
     @staticmethod
     def forward(ctx, x, om, weight, bias, cfg):
-        stride, padding, dilation, groups, dg, act = cfg
+        stride, padding, dilation, groups, dg, act, hint = cfg
         split = 2 * om.shape[1] // 3
-        out = ops.dcnv2_forward(x, om[:, :split], om[:, split:], weight, bias, stride, padding, dilation, groups, dg, act=act)
+        out = ops.dcnv2_forward(x, om[:, :split], om[:, split:], weight, bias, stride, padding, dilation, groups, dg, act=act,
+                                halo_hint=hint)
         ctx.save_for_backward(x, om, weight, out if act != ACT_NONE else None)
         ctx.cfg = cfg
         ctx.with_bias = bias is not None
@@ -85,7 +86,7 @@ class DcnFromPackedFn(Function):
     @once_differentiable
     def backward(ctx, dy):
         x, om, weight, out = ctx.saved_tensors
-        stride, padding, dilation, groups, dg, act = ctx.cfg
+        stride, padding, dilation, groups, dg, act, _ = ctx.cfg
         if act != ACT_NONE:
             dy = ops.act_backward(dy, out, act)
         split = 2 * om.shape[1] // 3

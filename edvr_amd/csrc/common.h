@@ -34,6 +34,11 @@ size_t gemm_nt_ws_elems(int M, int N, int64_t K);
 int gemm_nt_launch(const float *A, const float *B, float *C, int M, int N, int64_t K, int64_t lda, int64_t ldb,
                    bool accumulate, float *ws, hipStream_t stream);
 
+// dcn_fused.hip: column-buffer-free DCNv2 forward for the EDVR signature (3x3, stride 1, pad 1, dil 1, groups 1)
+bool dcn_fused_supported(int C, int Co, int kh, int kw, int stride, int pad, int dil, int groups, int dg);
+int dcn_fused_forward(const float *x, const float *offset, const float *mask, const float *wpk, const float *bias, float *y, int B, int C,
+                      int H, int W, int Co, int dg, int64_t off_bs, int64_t msk_bs, int act, int halo, hipStream_t stream);
+
 }  // namespace edvr
 
 #define EDVR_REQUIRE(cond, ...)       \

@@ -47,6 +47,8 @@ struct ConvChunk {
 
 template <int KS, int STRIDE, int MT, int SW>
 __global__ __launch_bounds__(256, EDVR_CONV_MINWAVES) void conv2d_mfma_kernel(const ConvArgs a) {
+  // (measured: giving the 1x1/MT=4 instantiation the 512-register budget instead of spilling is SLOWER, 27 vs 41 TF/s:
+  //  that shape is latency-bound and wants the occupancy)
   constexpr int SH = 32 / SW;        // rows of one 32-pixel subtile
   constexpr int NSUB = 2;            // subtiles per wave
   constexpr int TW = SW;             // output tile width
@@ -189,15 +191,21 @@ __global__ __launch_bounds__(256, EDVR_CONV_MINWAVES) void conv2d_mfma_kernel(co
 
   // ---- epilogue on the accumulators: bias, activation (uniform switch hoisted), residuals, store
   if (d.bias) {
+    // unconditional clamped loads (a predicated load would serialise: one basic block + wait per element)
+    float bvals[MT * 16];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co_blk + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const float bv = (co < d.co) ? d.bias[co] : 0.f;
-#pragma unroll
-        for (int s = 0; s < NSUB; ++s) acc[m][s][r] += bv;
+        bvals[m * 16 + r] = d.bias[co < d.co ? co : d.co - 1];
       }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) acc[m][s][r] += bvals[m * 16 + r];
   }
   if (d.act != EDVR_ACT_NONE) {
     const int rel_from = d.act_from - co_blk - 4 * half;  // activation applies where (m*32 + row(r)) >= rel_from
@@ -253,7 +261,11 @@ __global__ __launch_bounds__(256, EDVR_CONV_MINWAVES) void conv2d_mfma_kernel(co
   } else if (r1) {
     EDVR_STORE_LOOP({ y[o] = v + r1[o]; })
   } else {
+#ifdef EDVR_EXP_NOSTORE
+    EDVR_STORE_LOOP({ if (v == 12345.678f) y[o] = v; })  /* ablation only: keeps the accumulators live */
+#else
     EDVR_STORE_LOOP({ y[o] = v; })
+#endif
   }
 #undef EDVR_STORE_LOOP
 }

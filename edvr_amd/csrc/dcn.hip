@@ -24,6 +24,8 @@
 //     buffer in place with the forward columns needed by dW (the reference runs three kernels
 //     and a 25-iteration window scan per column entry, .cu:677-691); dW is a deterministic
 //     split-K MFMA GEMM over the pixel axis.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace edvr {
@@ -297,14 +299,23 @@ static int fill_shape(DcnShape &s, int B, int C, int H, int W, int Co, int kh, i
   return EDVR_OK;
 }
 
+static bool use_fused(const DcnShape &s) {
+  const char *e = getenv("EDVR_DCN_FUSED");  // "0": force the generic column-buffer path (A/B, tests)
+  if (e && e[0] == '0') return false;
+  return dcn_fused_supported(s.C, s.Co, s.kh, s.kw, s.stride, s.pad, s.dil, s.groups, s.dg);
+}
+
 struct FwdWs { size_t col, wpk, total; };
 static FwdWs fwd_ws(const DcnShape &s) {
+
   const size_t K = (size_t)s.kh * s.kw, P = (size_t)s.Ho * s.Wo;
   FwdWs w;
   w.col = 0;
   size_t off = align_up((size_t)s.B * s.C * K * P * 4, 256);
   w.wpk = off;
-  off += align_up(edvr_conv2d_packed_weight_elems(s.Co / s.groups, (int)((s.C / s.groups) * K), 1) * 4 * s.groups, 256);
+  size_t pk = edvr_conv2d_packed_weight_elems(s.Co / s.groups, (int)((s.C / s.groups) * K), 1) * 4 * s.groups;
+  if (use_fused(s)) pk = std::max(pk, edvr_conv2d_packed_weight_elems(s.Co, s.C, 3) * 4);
+  off += align_up(pk, 256);
   w.total = off;
   return w;
 }
@@ -344,7 +355,7 @@ size_t edvr_dcnv2_bwd_ws_bytes(int B, int C, int H, int W, int Co, int kh, int k
 
 int edvr_dcnv2_fwd_f32(const float *x, const float *offset, const float *mask, const float *weight, const float *bias,
                        float *y, int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil, int groups,
-                       int dg, int64_t offset_bstride, int64_t mask_bstride, int act, void *ws, size_t ws_bytes,
+                       int dg, int64_t offset_bstride, int64_t mask_bstride, int act, int halo_hint, void *ws, size_t ws_bytes,
                        edvr_stream_t stream_) {
   using namespace edvr;
   EDVR_REQUIRE(x && offset && mask && weight && y, "dcnv2_fwd: null pointer");
@@ -361,6 +372,11 @@ int edvr_dcnv2_fwd_f32(const float *x, const float *offset, const float *mask, c
   const int64_t P = (int64_t)s.Ho * s.Wo;
   float *col = reinterpret_cast<float *>(static_cast<char *>(ws) + wsz.col);
   float *wpk = reinterpret_cast<float *>(static_cast<char *>(ws) + wsz.wpk);
+  if (use_fused(s) && halo_hint >= 0) {
+    rc = edvr_conv2d_pack_weight_f32(weight, wpk, Co, C, 3, 0, stream_);
+    if (rc) return rc;
+    return dcn_fused_forward(x, offset, mask, wpk, bias, y, B, C, H, W, Co, dg, s.off_bs, s.msk_bs, act, halo_hint, stream);
+  }
   const int cig = C / groups, cog = Co / groups;
   const size_t wpk_g = edvr_conv2d_packed_weight_elems(cog, cig * K, 1);
   for (int g = 0; g < groups; ++g) {

@@ -252,7 +252,9 @@ class EDVR(nn.Module):
         if not sink:
             return
         import torch
-        sums = torch.stack([s for s, _ in sink]).view(len(sink), b, t).sum(1).cpu()  # (layers, t)
-        for li, (_, per_img) in enumerate(sink):
-            for v in (sums[li] / (b * per_img)).tolist():
+        sums = torch.stack([e[0] for e in sink]).view(len(sink), b, t).sum(1).cpu()  # (layers, t)
+        for li, (_, per_img, module) in enumerate(sink):
+            per_frame = (sums[li] / (b * per_img)).tolist()
+            module.last_offset_absmean = sum(per_frame) / len(per_frame)
+            for v in per_frame:
                 warn_offset_absmean(v)

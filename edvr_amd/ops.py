@@ -161,7 +161,7 @@ def _bstride(t):
     return t.stride(0) if t.shape[0] > 1 else 0
 
 
-def dcnv2_forward(x, offset, mask, weight, bias, stride, pad, dil, groups, dg, act=ACT_NONE):
+def dcnv2_forward(x, offset, mask, weight, bias, stride, pad, dil, groups, dg, act=ACT_NONE, halo_hint=0):
     require_gpu(x, offset, mask, weight, bias)
     L = _lib.lib()
     if not x.is_contiguous() or not weight.is_contiguous():
@@ -181,7 +181,7 @@ def dcnv2_forward(x, offset, mask, weight, bias, stride, pad, dil, groups, dg, a
     nbytes = L.edvr_dcnv2_fwd_ws_bytes(*dims)
     ws = workspace(nbytes, x.device)
     _lib.check(L.edvr_dcnv2_fwd_f32(_ptr(x), _ptr(offset), _ptr(mask), _ptr(weight), _ptr(bias), _ptr(y), *dims,
-                                    _bstride(offset), _bstride(mask), act, _ptr(ws), nbytes, _stream()), 'edvr_dcnv2_fwd_f32')
+                                    _bstride(offset), _bstride(mask), act, halo_hint, _ptr(ws), nbytes, _stream()), 'edvr_dcnv2_fwd_f32')
     return y
 
 

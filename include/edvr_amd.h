@@ -104,13 +104,17 @@ int edvr_conv2d_kernel_name(const edvr_conv2d_desc *d, char *buf, size_t buf_len
  * offset_bstride / mask_bstride: elements between consecutive images of offset / mask
  * (0 = contiguous), so channel-sliced views of one conv_offset output can be passed without a copy.
  * act: EDVR_ACT_* applied to y in the GEMM epilogue (EDVR_ACT_NONE = the reference op; PCDAlignment
- * follows two of its four DCNs with LeakyReLU, edvr_arch.py:103-104,116). */
+ * follows two of its four DCNs with LeakyReLU, edvr_arch.py:103-104,116).
+ * halo_hint: performance hint only (results are identical for every value).  The EDVR signature (3x3, stride 1, pad 1,
+ * dil 1, groups 1, (C/dg) % 8 == 0) runs a fused kernel that stages an input halo of R pixels around each tile in LDS
+ * and falls back to global gathers for taps that leave it: 0 or 3 -> R = 3 (|offset| mostly < 3), 7 -> R = 7,
+ * -1 -> skip the fused kernel (generic column-buffer path; always used for other signatures). */
 size_t edvr_dcnv2_fwd_ws_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil,
                                int groups, int dg);
 int edvr_dcnv2_fwd_f32(const float *x, const float *offset, const float *mask, const float *weight,
                        const float *bias, float *y, int B, int C, int H, int W, int Co, int kh, int kw, int stride,
                        int pad, int dil, int groups, int dg, int64_t offset_bstride, int64_t mask_bstride, int act,
-                       void *ws, size_t ws_bytes, edvr_stream_t stream);
+                       int halo_hint, void *ws, size_t ws_bytes, edvr_stream_t stream);
 
 size_t edvr_dcnv2_bwd_ws_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil,
                                int groups, int dg);

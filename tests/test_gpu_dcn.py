@@ -106,3 +106,19 @@ def test_cpu_tensor_is_refused():
     x = torch.randn(1, 8, 6, 6)
     with pytest.raises(NotImplementedError):
         modulated_deform_conv(x, torch.zeros(1, 18, 6, 6), torch.ones(1, 9, 6, 6), torch.randn(8, 8, 3, 3), None, 1, 1, 1, 1, 1)
+
+
+@pytest.mark.parametrize('sigma', [0.5, 3.0, 12.0])
+def test_fused_kernel_halo_classes_and_generic_path_agree(gpu, sigma):
+    """halo_hint is a performance hint only: R=3, R=7 (fused, LDS halo + global slow path) and -1 (generic column-buffer
+    path) must all match the oracle, whatever the offset magnitude."""
+    from edvr_amd import ops
+    from oracle import dcn_oracle as O
+    x, off, m, w, b, _ = _mk(2, 64, 21, 45, 96, 3, 1, 1, 1, 1, 8, sigma, seed=int(sigma * 10))
+    ref = O.c_forward(x.double(), off.double(), m.double(), w.double(), b.double(), 1, 1, 1, 1, 8)
+    dev = [t.to(gpu) for t in (x, off, m, w, b)]
+    for hint in (3, 7, -1):
+        y = ops.dcnv2_forward(*dev, 1, 1, 1, 1, 8, halo_hint=hint)
+        assert _rel(y, ref) < FWD_RTOL, hint
+    y_act = ops.dcnv2_forward(*dev, 1, 1, 1, 1, 8, act=ops.ACT_LRELU, halo_hint=3)
+    assert _rel(y_act, torch.nn.functional.leaky_relu(ref, 0.1)) < FWD_RTOL
