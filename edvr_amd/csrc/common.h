@@ -34,6 +34,12 @@ size_t gemm_nt_ws_elems(int M, int N, int64_t K);
 int gemm_nt_launch(const float *A, const float *B, float *C, int M, int N, int64_t K, int64_t lda, int64_t ldb,
                    bool accumulate, float *ws, hipStream_t stream);
 
+// winograd.hip: F(2x2,3x3) path of the 3x3 / stride-1 convolution.  U (transformed weights, [ci_pad][16][round_up(co,64)])
+// follows the direct packed layout inside the buffer edvr_conv2d_pack_weight_f32 fills.
+bool winograd_eligible(const edvr_conv2d_desc &d);
+int winograd_launch(const edvr_conv2d_desc &d, const float *U, int cop64, hipStream_t stream);
+int winograd_pack(const float *w, float *U, int co, int ci, int cop64, int cip, int transpose_flip, hipStream_t stream);
+
 // dcn_fused.hip: column-buffer-free DCNv2 forward for the EDVR signature (3x3, stride 1, pad 1, dil 1, groups 1)
 bool dcn_fused_supported(int C, int Co, int kh, int kw, int stride, int pad, int dil, int groups, int dg);
 int dcn_fused_forward(const float *x, const float *offset, const float *mask, const float *wpk, const float *bias, float *y, int B, int C,

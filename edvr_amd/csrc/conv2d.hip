@@ -284,6 +284,9 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, float *__restric
 }
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+static inline size_t direct_packed_elems(int co, int ci, int ks) {
+  return (size_t)round_up(ci, ks == 1 ? 32 : 16) * ks * ks * round_up(co, 32);
+}
 
 template <int KS, int STRIDE, int MT, int SW>
 static int launch_one(const ConvArgs &a, int co_start, int co_blocks, hipStream_t stream) {
@@ -345,6 +348,7 @@ int conv2d_launch(const edvr_conv2d_desc &d, hipStream_t stream) {
   a.wo = (d.w + 2 * pad - d.ks) / d.stride + 1;
   a.tiles_x = a.tiles_y = 0;
   a.co_start = 0;
+  if (winograd_eligible(d)) return winograd_launch(d, d.wpk + direct_packed_elems(d.co, a.ci, 3), round_up(d.co, 64), stream);
   if (d.ks == 3 && d.stride == 1) return launch_mt<3, 1>(a, stream);
   if (d.ks == 3 && d.stride == 2) return launch_mt<3, 2>(a, stream);
   return launch_mt<1, 1>(a, stream);
@@ -355,7 +359,8 @@ int conv2d_launch(const edvr_conv2d_desc &d, hipStream_t stream) {
 extern "C" {
 
 size_t edvr_conv2d_packed_weight_elems(int co, int ci, int ks) {
-  return (size_t)edvr::round_up(ci, ks == 1 ? 32 : 16) * ks * ks * edvr::round_up(co, 32);
+  // direct layout [ci_pad][ks*ks][co_pad32]; for 3x3 kernels followed by the Winograd-transformed weights [ci_pad][16][co_pad64]
+  return edvr::direct_packed_elems(co, ci, ks) + (ks == 3 ? (size_t)edvr::round_up(ci, 16) * 16 * edvr::round_up(co, 64) : 0);
 }
 
 int edvr_conv2d_pack_weight_f32(const float *w, float *wpk, int co, int ci, int ks, int transpose_flip,
@@ -366,13 +371,20 @@ int edvr_conv2d_pack_weight_f32(const float *w, float *wpk, int co, int ci, int 
   const int blocks = (int)std::min<int64_t>(edvr::cdiv64(total, 256), 4096);
   hipLaunchKernelGGL(edvr::pack_weight_kernel, dim3(blocks), dim3(256), 0, edvr::as_stream(stream), w, wpk, co, ci, kk,
                      cop, cip, transpose_flip);
-  return edvr::check_launch("pack_weight_kernel");
+  int rc = edvr::check_launch("pack_weight_kernel");
+  if (rc || ks != 3) return rc;
+  return edvr::winograd_pack(w, wpk + edvr::direct_packed_elems(co, ci, 3), co, ci, edvr::round_up(co, 64), cip, transpose_flip,
+                             edvr::as_stream(stream));
 }
 
 int edvr_conv2d_kernel_name(const edvr_conv2d_desc *d, char *buf, size_t buf_len) {
   EDVR_REQUIRE(d && buf && buf_len > 0, "kernel_name: bad arguments");
   const int pad = d->ks / 2;
   const int ho = (d->h + 2 * pad - d->ks) / d->stride + 1, wo = (d->w + 2 * pad - d->ks) / d->stride + 1;
+  if (edvr::winograd_eligible(*d)) {
+    snprintf(buf, buf_len, "conv3x3_winograd_kernel");
+    return EDVR_OK;
+  }
   const int mt = d->co >= 128 ? 4 : edvr::cdiv(d->co, 32);  // the launch carrying most of the work
   snprintf(buf, buf_len, "conv2d_mfma_kernel<%d, %d, %d, %d>", d->ks, d->stride, mt, edvr::use_sw16(ho, wo) ? 16 : 32);
   return EDVR_OK;

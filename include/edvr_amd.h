@@ -66,7 +66,10 @@ int edvr_check_device(void);
 /* ------------------------------------------------------------------ conv2d (fp32 MFMA implicit GEMM)
  * y = act(conv(cat(x1, x2), W) + bias) + res1 + res2, kernel ks in {1,3}, pad = ks/2,
  * stride in {1,2}, dilation 1, groups 1.  Weights come pre-packed by
- * edvr_conv2d_pack_weight_f32 (layout [ci_pad][ks*ks][co_pad], co fastest). */
+ * edvr_conv2d_pack_weight_f32 (layout [ci_pad][ks*ks][co_pad], co fastest; for 3x3 kernels followed by the
+ * Winograd-transformed weights G g G^T as [ci_pad][16][co_pad64]).  3x3 / stride-1 layers with >= 48 output channels
+ * and w > 16 run as Winograd F(2x2,3x3) on the fp32 MFMA (2.25x fewer multiplies, fp32 throughout; set the
+ * environment variable EDVR_CONV_WINOGRAD=0 to force the direct kernel). */
 typedef struct edvr_conv2d_desc {
   const float *x1;        /* (n, c1, h, w) */
   const float *x2;        /* optional second input, concatenated after x1 on the channel axis */

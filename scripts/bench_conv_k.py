@@ -4,7 +4,7 @@ import torch
 from edvr_amd import ops
 dev = torch.device('cuda')
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-for ci in (32, 64, 128, 256, 512):
+for ci in (16, 32, 64, 128, 256, 512):
     x = torch.randn(n, ci, 180, 320, device=dev); wt = torch.randn(128, ci, 3, 3, device=dev) * 0.05
     wpk = ops.pack_conv_weight(wt)
     for _ in range(2): ops.conv2d(x, wpk, None, 128, 3)
