@@ -210,9 +210,15 @@ def main():
             name = max(per, key=lambda k: per[k][2])
             n, flops, secs = per[name]
             total_conv_s = sum(v[2] for v in per.values())
+            wino = 'winograd' in name
             result['roofline'] = {
                 'bound': 'mfma', 'kernel': name, 'achieved': round(flops / secs / 1e12, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
                 'unit': 'TFLOP/s', 'frac': round(flops / secs / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                # `achieved` counts ALGORITHMIC flops (2*9*Ci*Co per output pixel).  Winograd F(2x2,3x3) issues
+                # 16 instead of 36 multiplies per 2x2 tile and channel pair, so the matrix cores execute achieved/2.25:
+                'algorithm': 'winograd F(2x2,3x3), fp32' if wino else 'direct implicit GEMM, fp32',
+                'mfma_executed_tflops': round(flops / secs / 1e12 / (2.25 if wino else 1.0), 2),
+                'mfma_executed_frac_of_peak': round(flops / secs / 1e12 / (2.25 if wino else 1.0) / PEAK_F32_MFMA_TFLOPS, 4),
                 'launches': n, 'avg_launch_us': round(secs / n * 1e6, 2), 'gflop_per_launch': round(flops / n / 1e9, 3),
                 'all_conv_kernels': {k: {'launches': v[0], 'tflops': round(v[1] / v[2] / 1e12, 2), 'ms': round(v[2] * 1e3, 3)}
                                      for k, v in sorted(per.items(), key=lambda kv: -kv[1][2])},

@@ -21,7 +21,7 @@ class ConvDesc(ctypes.Structure):
         ('x2_div', i32), ('x2_mul', i32), ('x2_add', i32), ('n', i32), ('h', i32), ('w', i32), ('wpk', vp),
         ('bias', vp), ('co', i32), ('ks', i32), ('stride', i32), ('act', i32), ('act_from', i32), ('res1', vp),
         ('res2', vp), ('res1_img_stride', i64), ('res2_img_stride', i64), ('y', vp), ('y_img_stride', i64),
-        ('out_mode', i32),
+        ('out_mode', i32), ('algo', i32),
     ]
 
 
@@ -61,6 +61,7 @@ PROTOTYPES = {
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
 OUT_NCHW, OUT_PIXEL_SHUFFLE2 = 0, 1
+CONV_AUTO, CONV_DIRECT, CONV_WINOGRAD = 0, 1, 2
 
 _lib = None
 

@@ -356,7 +356,10 @@ bool winograd_eligible(const edvr_conv2d_desc &d) {
   if ((d.res2 && !d.res1) || (d.act == EDVR_ACT_SIGMOID && (has_res || d.out_mode != EDVR_OUT_NCHW)) ||
       (d.out_mode != EDVR_OUT_NCHW && has_res))
     return false;
-  return enabled && d.ks == 3 && d.stride == 1 && d.co >= 48 && d.w > 16 && d.h >= 4 && (d.c1 + d.c2) % 16 == 0;
+  if (d.algo == EDVR_CONV_DIRECT) return false;
+  const bool applicable = d.ks == 3 && d.stride == 1 && (d.c1 + d.c2) % 16 == 0;
+  if (d.algo == EDVR_CONV_WINOGRAD) return applicable;  // explicit request: any size the kernel can do
+  return enabled && applicable && d.co >= 48 && d.w > 16 && d.h >= 4;  // auto: only where it beats the direct kernel
 }
 
 int winograd_launch(const edvr_conv2d_desc &d, const float *U, int cop, hipStream_t stream) {

@@ -10,7 +10,8 @@ import weakref
 import torch
 
 from . import _lib
-from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, OUT_NCHW, OUT_PIXEL_SHUFFLE2  # noqa: F401
+from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, CONV_AUTO, CONV_DIRECT, CONV_WINOGRAD, OUT_NCHW,  # noqa: F401
+                   OUT_PIXEL_SHUFFLE2)
 
 
 def _stream():
@@ -95,11 +96,13 @@ def pack_conv_weight(weight, transpose_flip=False):
 
 # ------------------------------------------------------------------------------------------------ conv
 LAUNCH_HOOK = None  # callable(kernel_name, algorithmic_flops, launch_fn) or None
+CONV_ALGO = CONV_AUTO  # default algorithm request of conv2d(); tests flip it to cover both kernels on every shape
 
 
 def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NONE, act_from=0, res1=None, res2=None,
-           out_mode=OUT_NCHW, out=None):
+           out_mode=OUT_NCHW, out=None, algo=None):
     """y = act(conv(cat(x1, x2)) + bias) + res1 + res2 on the fp32 MFMA kernel.
+    algo: CONV_AUTO (default; module-level CONV_ALGO overrides it, used by tests), CONV_DIRECT or CONV_WINOGRAD.
 
     x2_map = (div, mul, add): image i of x2 is (i // div) * mul + add (broadcast of a reference frame).
     """
@@ -139,6 +142,7 @@ def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NON
             else:
                 res2 = r
     d.y, d.y_img_stride, d.out_mode = _ptr(out), _img_stride(out), out_mode
+    d.algo = CONV_ALGO if algo is None else algo
     if LAUNCH_HOOK is not None:  # measurement only (bench.py): brackets the launch with events on this stream
         buf = ctypes.create_string_buffer(96)
         L.edvr_conv2d_kernel_name(ctypes.byref(d), buf, 96)

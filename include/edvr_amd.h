@@ -60,6 +60,10 @@ int edvr_check_device(void);
 #define EDVR_ACT_LRELU 2 /* negative slope 0.1 (edvr_arch.py:70,157,248,356) */
 #define EDVR_ACT_SIGMOID 3
 
+#define EDVR_CONV_AUTO 0
+#define EDVR_CONV_DIRECT 1
+#define EDVR_CONV_WINOGRAD 2
+
 #define EDVR_OUT_NCHW 0
 #define EDVR_OUT_PIXEL_SHUFFLE2 1 /* y[n, co/4, 2h+(co%4)/2, 2w+co%2]  (nn.PixelShuffle(2)) */
 
@@ -89,6 +93,7 @@ typedef struct edvr_conv2d_desc {
   float *y;
   int64_t y_img_stride;   /* elements between images of y */
   int out_mode;           /* EDVR_OUT_* */
+  int algo;               /* EDVR_CONV_AUTO | EDVR_CONV_DIRECT | EDVR_CONV_WINOGRAD (falls back to direct where not applicable) */
 } edvr_conv2d_desc;
 
 size_t edvr_conv2d_packed_weight_elems(int co, int ci, int ks);

@@ -29,12 +29,18 @@ CASES = [
     (1, 32, 0, 16, 16, 108, 3, 1, 'sigmoid_from', 0, 0),   # 97..127 output channels: 4-tile tail launch
     (1, 48, 0, 10, 12, 100, 1, 1, 'none', 0, 0),
     (1, 96, 0, 16, 32, 300, 1, 1, 'lrelu', 1, 0),           # 2 full 128-blocks + 2-tile tail, 1x1 with CK=32
+    (2, 32, 0, 19, 37, 70, 3, 1, 'lrelu', 2, 0),            # winograd: odd sizes, partial tiles, two residuals
+    (1, 16, 16, 10, 50, 64, 3, 1, 'relu', 0, 0),            # winograd: concat input
+    (1, 48, 0, 8, 36, 128, 3, 1, 'lrelu', 0, 1),            # winograd: pixel-shuffle epilogue
+    (1, 32, 0, 9, 33, 216, 3, 1, 'sigmoid_from', 0, 0),     # winograd: sigmoid-from-channel epilogue, odd width
 ]
 
 
+@pytest.mark.parametrize('algo', ['direct', 'winograd'])
 @pytest.mark.parametrize('case', CASES)
-def test_conv2d_matches_fp64(gpu, case):
+def test_conv2d_matches_fp64(gpu, case, algo):
     from edvr_amd import ops
+    algo = {'direct': ops.CONV_DIRECT, 'winograd': ops.CONV_WINOGRAD}[algo]  # winograd falls back where not applicable
     n, c1, c2, h, w, co, ks, stride, actn, nres, out_mode = case
     g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
     x1 = torch.randn(n, c1, h, w, generator=g)
@@ -58,7 +64,7 @@ def test_conv2d_matches_fp64(gpu, case):
     wpk = ops.pack_conv_weight(wt.to(gpu))
     y = ops.conv2d(x1.to(gpu), wpk, b.to(gpu), co, ks, x2=None if x2 is None else x2.to(gpu), stride=stride, act=act,
                    act_from=act_from, res1=res[0].to(gpu) if nres > 0 else None, res2=res[1].to(gpu) if nres > 1 else None,
-                   out_mode=out_mode)
+                   out_mode=out_mode, algo=algo)
     torch.cuda.synchronize()
     assert y.shape == ref.shape
     assert _rel(y, ref) < RTOL

@@ -14,9 +14,12 @@ def _rel(a, ref):
     return ((a.double().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
 
 
+@pytest.mark.parametrize('algo', ['direct', 'winograd'])
 @pytest.mark.parametrize('name', list(CONFIGS))
-def test_edvr_forward_matches_oracle(gpu, name):
+def test_edvr_forward_matches_oracle(gpu, name, algo, monkeypatch):
+    from edvr_amd import ops
     from oracle import edvr_oracle as EO
+    monkeypatch.setattr(ops, 'CONV_ALGO', {'direct': ops.CONV_DIRECT, 'winograd': ops.CONV_WINOGRAD}[algo])
     net, x, kwargs = build(name)
     sd64 = {k: v.double() for k, v in net.state_dict().items()}
     taps_ref = {}

@@ -26,8 +26,17 @@ CONV_CASES = [
 ]
 
 
+@pytest.fixture(params=['direct', 'winograd'])
+def conv_algo(request):
+    """Run the test with conv2d's default algorithm forced to each kernel (Winograd falls back where not applicable)."""
+    from edvr_amd import ops
+    ops.CONV_ALGO = {'direct': ops.CONV_DIRECT, 'winograd': ops.CONV_WINOGRAD}[request.param]
+    yield request.param
+    ops.CONV_ALGO = ops.CONV_AUTO
+
+
 @pytest.mark.parametrize('case', CONV_CASES)
-def test_conv_gradients(gpu, case):
+def test_conv_gradients(gpu, case, conv_algo):
     from edvr_amd import functional as F_
     n, c1, c2, h, w, co, ks, stride, actn, nres, out_mode = case
     g = torch.Generator().manual_seed(11)
@@ -148,7 +157,7 @@ def test_charbonnier(gpu):
 
 
 @pytest.mark.parametrize('name', ['M_T5', 'L_deblur_hr', 'M_noTSA'])
-def test_edvr_parameter_gradients_match_oracle(gpu, name):
+def test_edvr_parameter_gradients_match_oracle(gpu, name, conv_algo):
     """Whole network: d(Charbonnier sum)/d(every parameter), HIP fp32 vs oracle autograd fp64.
     The bound is calibrated per tensor against the fp32 noise floor of the oracle itself (same algorithm in fp32 on the
     CPU vs fp64): ours must be within max(1e-3, 4 x that floor) of the fp64 truth, relative to max|grad|."""
