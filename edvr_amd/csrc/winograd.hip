@@ -92,7 +92,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_winograd_kernel(const WinoArgs
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const bool ok = gy0 + r >= 0 && gy0 + r < d.h && gx0 + c >= 0 && gx0 + c < d.w;
+#ifdef WINO_EXP_ONEADDR
+        p_off[r * 4 + c] = 0;  /* ablation only: every patch load hits one cached line */
+#else
         p_off[r * 4 + c] = ok ? (gy0 + r) * d.w + gx0 + c : 0;
+#endif
         p_mul[r * 4 + c] = ok ? 1.f : 0.f;
       }
   };
@@ -109,49 +113,71 @@ __global__ __launch_bounds__(256, 1) void conv3x3_winograd_kernel(const WinoArgs
   f32x4 ur[2][8];
   float pr[2][2][16];
   const int c_last = ((a.ci - 1) / CK) * CK;
-  // slice g (0..15) of loading chunk c0 into register set S: U vector g (g < 8) and two patch elements
-  auto load_slice = [&](auto SET, int c0, int g) {
-    constexpr int S = decltype(SET)::value;
+  // Pointers of the chunk being loaded (hoisted out of the 16 slices): U slab row base and the two channel planes
+  const float *ld_u = nullptr, *ld_p[2] = {nullptr, nullptr};
+  auto load_begin = [&](int c0) {
     c0 = c0 <= c_last ? c0 : c_last;
-    if (g < 8) ur[S][g] = *reinterpret_cast<const f32x4 *>(u_src0 + ((int64_t)c0 * 16 + (int64_t)g * 16) * a.cop);
-    const int k = g >> 3, e0 = (g & 7) * 2;
-    const int c = c0 + p_ch_u + k;
-    const int cc = c < a.ci ? c : a.ci - 1;  // channels past ci meet all-zero U rows: any finite data works
-    const float *src = (cc < d.c1) ? (x1 + (int64_t)cc * hw) : (x2 + (int64_t)(cc - d.c1) * hw);
-    pr[S][k][e0] = src[p_off[e0]];  // raw; the 0/1 mask is applied at transform time
-    pr[S][k][e0 + 1] = src[p_off[e0 + 1]];
-  };
-  auto load_set = [&](auto SET, int c0) {
+    ld_u = u_src0 + (int64_t)c0 * 16 * a.cop;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) load_slice(SET, c0, g);
-  };
-  float tt[16];  // B^T d of the patch being committed
-  auto transform_rows = [&](auto SET, int k) {
-    constexpr int S = decltype(SET)::value;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float d0 = pr[S][k][0 * 4 + c] * p_mul[0 * 4 + c], d1 = pr[S][k][1 * 4 + c] * p_mul[1 * 4 + c];
-      const float d2 = pr[S][k][2 * 4 + c] * p_mul[2 * 4 + c], d3 = pr[S][k][3 * 4 + c] * p_mul[3 * 4 + c];
-      tt[0 * 4 + c] = d0 - d2;
-      tt[1 * 4 + c] = d1 + d2;
-      tt[2 * 4 + c] = d2 - d1;
-      tt[3 * 4 + c] = d1 - d3;
+    for (int k = 0; k < 2; ++k) {
+      const int c = c0 + p_ch_u + k;
+      const int cc = c < a.ci ? c : a.ci - 1;  // channels past ci meet all-zero U rows: any finite data works
+      ld_p[k] = (cc < d.c1) ? (x1 + (int64_t)cc * hw) : (x2 + (int64_t)(cc - d.c1) * hw);
     }
   };
-  // element xi = r*4 + c of (B^T d) B from the row r of tt
-  auto v_elem = [&](int xi) {
-    const int r = xi >> 2, c = xi & 3;
-    return c == 0 ? tt[r * 4 + 0] - tt[r * 4 + 2] : c == 1 ? tt[r * 4 + 1] + tt[r * 4 + 2] : c == 2 ? tt[r * 4 + 2] - tt[r * 4 + 1] : tt[r * 4 + 1] - tt[r * 4 + 3];
+  // slice g (0..15) of loading into register set S: U vector g (g < 8) and two patch elements (raw; the 0/1 border
+  // mask is applied at transform time)
+  auto load_slice = [&](auto SET, int g) {
+    constexpr int S = decltype(SET)::value;
+#ifdef WINO_EXP_NOULOAD
+    if (g < 8) ur[S][g] = f32x4{1.f, 2.f, 3.f, 4.f};  /* ablation only */
+#else
+    if (g < 8) ur[S][g] = *reinterpret_cast<const f32x4 *>(ld_u + (int64_t)g * 16 * a.cop);
+#endif
+    const int k = g >> 3, e0 = (g & 7) * 2;
+    pr[S][k][e0] = ld_p[k][p_off[e0]];
+    pr[S][k][e0 + 1] = ld_p[k][p_off[e0 + 1]];
   };
-  // slice g (0..15) of committing register set S into LDS pair `dst` (0/1)
+  auto load_set = [&](auto SET, int c0) {
+    load_begin(c0);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) load_slice(SET, g);
+  };
+  // Commit schedule over the 16 MFMA groups (balanced, <= 12 VALU + 3 LDS writes per group):
+  //   g 0-3 : column g of B^T d for patch 0            g 4-7 : column g-4 for patch 1, v[0..7] of patch 0
+  //   g 8-11: v[8..15] of patch 0, v[0..7] of patch 1  g 12-15: v[8..15] of patch 1        U vector g for g < 8
+  float tt[2][16];  // B^T d of the two patches being committed
+  auto transform_col = [&](auto SET, int k, int c) {
+    constexpr int S = decltype(SET)::value;
+    const float d0 = pr[S][k][0 * 4 + c] * p_mul[0 * 4 + c], d1 = pr[S][k][1 * 4 + c] * p_mul[1 * 4 + c];
+    const float d2 = pr[S][k][2 * 4 + c] * p_mul[2 * 4 + c], d3 = pr[S][k][3 * 4 + c] * p_mul[3 * 4 + c];
+    tt[k][0 * 4 + c] = d0 - d2;
+    tt[k][1 * 4 + c] = d1 + d2;
+    tt[k][2 * 4 + c] = d2 - d1;
+    tt[k][3 * 4 + c] = d1 - d3;
+  };
+  // element xi = r*4 + c of (B^T d) B from row r of tt[k]
+  auto v_elem = [&](int k, int xi) {
+    const int r = xi >> 2, c = xi & 3;
+    const float *t = tt[k] + r * 4;
+    return c == 0 ? t[0] - t[2] : c == 1 ? t[1] + t[2] : c == 2 ? t[2] - t[1] : t[1] - t[3];
+  };
   auto commit_slice = [&](auto SET, int dst, int g) {
     constexpr int S = decltype(SET)::value;
     float *Us = smem + dst * 2 * SLAB, *Vs = Us + SLAB;
     if (g < 8) *reinterpret_cast<f32x4 *>(Us + (tid + g * 256) * 4) = ur[S][g];
-    if ((g & 7) == 0) transform_rows(SET, g >> 3);
-    const int k = g >> 3, x0 = (g & 7) * 2;
-    Vs[((p_ch + k) * 16 + x0) * 64 + p_tile] = v_elem(x0);
-    Vs[((p_ch + k) * 16 + x0 + 1) * 64 + p_tile] = v_elem(x0 + 1);
+    if (g < 4) transform_col(SET, 0, g);
+    else if (g < 8) transform_col(SET, 1, g - 4);
+    if (g >= 4 && g < 12) {  // patch 0: two values per group
+      const int x0 = (g - 4) * 2;
+      Vs[(p_ch * 16 + x0) * 64 + p_tile] = v_elem(0, x0);
+      Vs[(p_ch * 16 + x0 + 1) * 64 + p_tile] = v_elem(0, x0 + 1);
+    }
+    if (g >= 8) {  // patch 1
+      const int x0 = (g - 8) * 2;
+      Vs[((p_ch + 1) * 16 + x0) * 64 + p_tile] = v_elem(1, x0);
+      Vs[((p_ch + 1) * 16 + x0 + 1) * 64 + p_tile] = v_elem(1, x0 + 1);
+    }
   };
   const int abase = half * 16 * 64 + wm * 32 + j;  // A operand (U): channel `half` of the pair, this wave's co tile
   const int bbase = half * 16 * 64 + wn * 32 + j;  // B operand (V): this wave's tile group
@@ -161,6 +187,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_winograd_kernel(const WinoArgs
     const float *Us = smem + P * 2 * SLAB, *Vs = Us + SLAB;
     // 16 groups (channel pair cp = g >> 2, positions xi = 4*(g & 3) .. +3) of 4 MFMAs; operands of group g+1 are fetched
     // before the MFMAs of group g; slice g of the loads (chunk k+2) and of the commit (chunk k+1) issue in their shadow
+    load_begin(c0 + 2 * CK);  // chunk k+2 -> the register set freed by the previous iteration
     float av[2][4], bv[2][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -170,7 +197,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_winograd_kernel(const WinoArgs
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       const int cur = g & 1, nxt = cur ^ 1;
-      if (g + 1 < 16) {
+      if (g + 1 < 16) {  // (fetching two groups ahead instead of one measured no gain)
         const int cpn = (g + 1) >> 2, x0n = ((g + 1) & 3) * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -181,10 +208,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_winograd_kernel(const WinoArgs
       const int x0 = (g & 3) * 4;
 #pragma unroll
       for (int i = 0; i < 4; ++i) mfma_acc(acc[x0 + i], av[cur][i], bv[cur][i]);
-      load_slice(PAR, c0 + 2 * CK, g);  // chunk k+2 -> the register set freed by the previous iteration
+      load_slice(PAR, g);
       commit_slice(Other{}, 1 - P, g);
     }
-    __syncthreads();
+    // LDS-only barrier: __syncthreads() would also wait vmcnt(0), i.e. for the chunk k+2 loads issued a few cycles ago
+    // (full memory latency exposed every chunk).  Those loads target registers and need no cross-wave ordering.
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
