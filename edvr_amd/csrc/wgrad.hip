@@ -128,7 +128,10 @@ __global__ __launch_bounds__(256, EDVR_WGRAD_MINWAVES) void conv2d_wgrad_kernel(
   for (int u = u_begin; u < u_end; ++u) {
     const bool more = (u + 1) < u_end;
     if (more) prefetch(u + 1);
-#pragma unroll 4
+#ifndef EDVR_WGRAD_QUNROLL
+#define EDVR_WGRAD_QUNROLL 32
+#endif
+#pragma unroll EDVR_WGRAD_QUNROLL
     for (int q = 0; q < SP / 2; ++q) {
       const int r = q / (SC / 2), c = 2 * (q % (SC / 2));
       const float av = dzs[abase + 2 * q];
