@@ -76,12 +76,12 @@ def instrumented_pass(net, x, steps):
     from edvr_amd import ops
     records = []
 
-    def hook(name, flops, launch):
+    def hook(name, flops, launch, nbytes):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         launch()
         e1.record()
-        records.append((name, flops, e0, e1))
+        records.append((name, flops, e0, e1, nbytes))
 
     ops.LAUNCH_HOOK = hook
     try:
@@ -92,12 +92,28 @@ def instrumented_pass(net, x, steps):
     finally:
         ops.LAUNCH_HOOK = None
     per = {}
-    for name, flops, e0, e1 in records:
-        d = per.setdefault(name, [0, 0.0, 0.0])
+    for name, flops, e0, e1, nbytes in records:
+        d = per.setdefault(name, [0, 0.0, 0.0, 0.0])
         d[0] += 1
         d[1] += flops
         d[2] += e0.elapsed_time(e1) * 1e-3
+        d[3] += nbytes
     return per
+
+
+def measured_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this same command
+    (scripts/prof_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate --pmc passes, calibrated on known-size copies as
+    MI355X_MICROARCH.md's HBM section prescribes).  PMC collection serialises kernels, so it is not redone inside the timed run."""
+    path = os.path.join(ROOT, 'profiles', 'r1', f'traffic_{workload}.json')
+    if not os.path.exists(path):
+        return None, None
+    rep = json.load(open(path))
+    base = kernel.split('<')[0]
+    for k, v in rep['kernels'].items():
+        if k.split('<')[0].endswith(base) and v.get('hbm_bytes_per_launch'):
+            return v, os.path.relpath(path, ROOT)
+    return None, None
 
 
 def cpu_baseline(cfg):
@@ -208,12 +224,17 @@ def main():
         if not args.no_roofline and args.mode == 'infer':
             per = instrumented_pass(net, x, max(1, min(args.steps, 3)))
             name = max(per, key=lambda k: per[k][2])
-            n, flops, secs = per[name]
+            n, flops, secs, nbytes = per[name]
             total_conv_s = sum(v[2] for v in per.values())
+            tr, tr_src = measured_traffic(args.workload, name) if batch == cfg['batch'] else (None, None)
             wino = 'winograd' in name
             result['roofline'] = {
                 'bound': 'mfma', 'kernel': name, 'achieved': round(flops / secs / 1e12, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': round(flops / secs / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                'unit': 'TFLOP/s', 'frac': round(flops / secs / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                'traffic': round(tr['hbm_bytes_per_launch']) if tr else None,
+                'traffic_detail': ({'unit': 'bytes per launch (average over the launches of this kernel in one step)',
+                                    'fetch': round(tr['fetch_bytes_per_launch']), 'write': round(tr['write_bytes_per_launch']),
+                                    'algorithmic': round(nbytes / n), 'source': tr_src} if tr else None),
                 # `achieved` counts ALGORITHMIC flops (2*9*Ci*Co per output pixel).  Winograd F(2x2,3x3) issues
                 # 16 instead of 36 multiplies per 2x2 tile and channel pair, so the matrix cores execute achieved/2.25:
                 'algorithm': 'winograd F(2x2,3x3), fp32' if wino else 'direct implicit GEMM, fp32',

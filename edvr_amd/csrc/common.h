@@ -45,6 +45,24 @@ bool dcn_fused_supported(int C, int Co, int kh, int kw, int stride, int pad, int
 int dcn_fused_forward(const float *x, const float *offset, const float *mask, const float *wpk, const float *bias, float *y, int B, int C,
                       int H, int W, int Co, int dg, int64_t off_bs, int64_t msk_bs, int act, int halo, hipStream_t stream);
 
+// XCD-aware workgroup order.  The dispatcher deals consecutive workgroups round-robin to the 8 XCDs (workgroup L runs on
+// XCD L % 8), each with its own 4 MB L2, so spatially adjacent tiles - which share 128-byte lines and halo rows - land on
+// eight different L2s and each re-fetches the shared lines from the fabric.  xcd_remap gives XCD x one contiguous range of
+// the logical tile order instead (a bijection on [0, total)), so the tiles in flight on one L2 are neighbours.
+__device__ inline int xcd_remap(int linear, int total) {
+  const int q = total >> 3, rem = total & 7, xcd = linear & 7;
+  return xcd * q + (xcd < rem ? xcd : rem) + (linear >> 3);
+}
+// (tile, y-block, image) of this workgroup of a dim3(tiles, yblocks, images) grid under the XCD-aware order, tile fastest
+__device__ inline void xcd_block_index(int &bx, int &by, int &bz) {
+  const int gx = gridDim.x, gy = gridDim.y;
+  const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  const int lg = xcd_remap(lin, gx * gy * (int)gridDim.z);
+  bx = lg % gx;
+  by = (lg / gx) % gy;
+  bz = lg / (gx * gy);
+}
+
 }  // namespace edvr
 
 #define EDVR_REQUIRE(cond, ...)       \

@@ -71,10 +71,10 @@ __global__ __launch_bounds__(256, EDVR_CONV_MINWAVES) void conv2d_mfma_kernel(co
   const edvr_conv2d_desc &d = a.d;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, j = lane & 31;
-  const int tile = blockIdx.x;
+  int tile = blockIdx.x, blk_y = blockIdx.y, img = blockIdx.z;
+  if constexpr (KS > 1) xcd_block_index(tile, blk_y, img);  // neighbouring tiles share one XCD's L2 (common.h); 1x1 has no halo
   const int ty0 = (tile / a.tiles_x) * TH, tx0 = (tile % a.tiles_x) * TW;
-  const int co_blk = a.co_start + blockIdx.y * MB;
-  const int img = blockIdx.z;
+  const int co_blk = a.co_start + blk_y * MB;
 
   const float *x1 = d.x1 + (int64_t)img * d.x1_img_stride;
   const float *x2 = nullptr;

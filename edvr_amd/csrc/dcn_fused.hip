@@ -58,10 +58,10 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_fwd_kernel(const DcnFusedArg
   float *wsm = smem + XS_ELEMS;
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, j = lane & 31;
-  const int tile = blockIdx.x;
+  int tile, blk_y, img;
+  xcd_block_index(tile, blk_y, img);  // neighbouring tiles share one XCD's L2 (common.h)
   const int ty0 = (tile / a.tiles_x) * TH, tx0 = (tile % a.tiles_x) * TW;
-  const int co_blk = a.co_start + blockIdx.y * MB;
-  const int img = blockIdx.z;
+  const int co_blk = a.co_start + blk_y * MB;
   const int P = a.H * a.W, cpg = a.C / a.dg;
   const float *x = a.x + (int64_t)img * a.C * P;
   const float *off_b = a.offset + (int64_t)img * a.off_bs;

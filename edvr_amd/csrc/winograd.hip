@@ -219,9 +219,20 @@ __global__ __launch_bounds__(256, 1) void conv3x3_winograd_kernel(const WinoArgs
   using S1 = std::integral_constant<int, 1>;
   // Persistent workgroups: with 128 KB of LDS only one workgroup fits a CU; each walks items = (image, spatial tile,
   // 64-channel block), channel block fastest so the co-blocks of one tile run back to back and share its input via L2.
-  setup(blockIdx.x);
+  // XCD-aware walk: workgroup b runs on XCD b % 8, each XCD with its own 4 MB L2.  Handing every XCD one CONTIGUOUS
+  // range of items keeps the workgroups that share input lines (the co-blocks of a tile, the x/y-neighbouring tiles whose
+  // 128-byte lines and halo rows overlap) on one L2 at the same time; a plain `item = b + k*grid` walk spreads them over
+  // all 8 L2s and every one of them re-fetches the lines from the fabric (measured 7.2x the output bytes, now ~1.6x).
+  const int n_xcd = gridDim.x < 8 ? 1 : 8;
+  const int xcd = n_xcd == 1 ? 0 : (int)blockIdx.x % 8, xcd_rank = n_xcd == 1 ? (int)blockIdx.x : (int)blockIdx.x / 8;
+  const int xcd_wgs = n_xcd == 1 ? (int)gridDim.x : ((int)gridDim.x - xcd + 7) / 8;
+  const int chunk = (a.items + n_xcd - 1) / n_xcd;
+  const int item_end = min(a.items, (xcd + 1) * chunk);
+  const int item_first = xcd * chunk + xcd_rank;
+  if (item_first >= item_end) return;
+  setup(item_first);
   load_set(S0{}, 0);
-  for (int item = blockIdx.x; item < a.items; item += gridDim.x) {
+  for (int item = item_first; item < item_end; item += xcd_wgs) {
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi)
 #pragma unroll
@@ -240,8 +251,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_winograd_kernel(const WinoArgs
     // geometry of the item being finished; then set up the NEXT item and issue its first loads ahead of the stores
     const int e_img = img, e_ty0 = ty0, e_tx0 = tx0, e_co_blk = co_blk;
     {
-      const int next = item + (int)gridDim.x;
-      setup(next < a.items ? next : item);
+      const int next = item + xcd_wgs;
+      setup(next < item_end ? next : item);
       load_set(S0{}, 0);
     }
 

@@ -95,7 +95,7 @@ def pack_conv_weight(weight, transpose_flip=False):
 
 
 # ------------------------------------------------------------------------------------------------ conv
-LAUNCH_HOOK = None  # callable(kernel_name, algorithmic_flops, launch_fn) or None
+LAUNCH_HOOK = None  # callable(kernel_name, algorithmic_flops, launch_fn, algorithmic_bytes) or None
 CONV_ALGO = CONV_AUTO  # default algorithm request of conv2d(); tests flip it to cover both kernels on every shape
 
 
@@ -147,7 +147,10 @@ def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NON
         buf = ctypes.create_string_buffer(96)
         L.edvr_conv2d_kernel_name(ctypes.byref(d), buf, 96)
         flops = 2.0 * n * ho * wo * co * (c1 + d.c2) * ks * ks
-        LAUNCH_HOOK(buf.value.decode(), flops, lambda: _lib.check(L.edvr_conv2d_f32(ctypes.byref(d), _stream()), 'edvr_conv2d_f32'))
+        # algorithmic HBM bytes: every input / residual / output element once, plus the weights
+        nbytes = 4.0 * (n * (c1 + d.c2) * h * w + n * co * ho * wo * (1 + (res1 is not None) + (res2 is not None))
+                        + co * (c1 + d.c2) * ks * ks)
+        LAUNCH_HOOK(buf.value.decode(), flops, lambda: _lib.check(L.edvr_conv2d_f32(ctypes.byref(d), _stream()), 'edvr_conv2d_f32'), nbytes)
     else:
         _lib.check(L.edvr_conv2d_f32(ctypes.byref(d), _stream()), 'edvr_conv2d_f32')
     return out
