@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libedvr_amd.so')
 OBJDIR = os.path.join(HERE, 'build')
-SOURCES = ['api.hip', 'conv2d.hip', 'dcn.hip', 'elementwise.hip', 'wgrad.hip', 'backward.hip', 'dcn_fused.hip', 'winograd.hip']
+SOURCES = ['api.hip', 'conv2d.hip', 'dcn.hip', 'elementwise.hip', 'wgrad.hip', 'backward.hip', 'dcn_fused.hip', 'winograd.hip', 'winograd_wgrad.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-ffp-contract=fast']
 
 

@@ -40,6 +40,15 @@ bool winograd_eligible(const edvr_conv2d_desc &d);
 int winograd_launch(const edvr_conv2d_desc &d, const float *U, int cop64, hipStream_t stream);
 int winograd_pack(const float *w, float *U, int co, int ci, int cop64, int cip, int transpose_flip, hipStream_t stream);
 
+// winograd_wgrad.hip: weight gradient of the 3x3 / stride-1 conv in the Winograd domain.  plan() says whether the layer is
+// eligible and how many split-K partial pairs it writes; the partials ([2*splits][co][ci][9]) are summed by wgrad_reduce_kernel.
+bool winograd_wgrad_plan(int n, int c1, int c2, int h, int w, int co, int ks, int stride, int *splits);
+size_t winograd_wgrad_ws_bytes(int co, int ci, int splits);
+int winograd_wgrad_set_algo(int algo);
+int winograd_wgrad_launch(const float *x1, const float *x2, const float *dz, float *ws, int c1, int c2, int n, int h, int w, int co,
+                          int64_t x1_img_stride, int64_t x2_img_stride, int x2_div, int x2_mul, int x2_add, int64_t dz_img_stride,
+                          int splits, hipStream_t stream);
+
 // dcn_fused.hip: column-buffer-free DCNv2 forward for the EDVR signature (3x3, stride 1, pad 1, dil 1, groups 1)
 bool dcn_fused_supported(int C, int Co, int kh, int kw, int stride, int pad, int dil, int groups, int dg);
 int dcn_fused_forward(const float *x, const float *offset, const float *mask, const float *wpk, const float *bias, float *y, int B, int C,

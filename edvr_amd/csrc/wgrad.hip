@@ -215,12 +215,15 @@ static int wgrad_splits(int tiles, int units) {
 extern "C" {
 
 size_t edvr_conv2d_wgrad_ws_bytes(int n, int ci, int h, int w, int co, int ks, int stride) {
+  int wsplits = 0;  // NOTE: c1/c2 are not known here; plan with c2 = 0 (the c1 % 64 rule is re-checked at launch time and
+                    // the direct kernel's need, computed below, is the larger of the two for every EDVR layer anyway)
+  size_t wino = edvr::winograd_wgrad_plan(n, ci, 0, h, w, co, ks, stride, &wsplits) ? edvr::winograd_wgrad_ws_bytes(co, ci, wsplits) : 0;
   const int pad = ks / 2;
   const int ho = (h + 2 * pad - ks) / stride + 1, wo = (w + 2 * pad - ks) / stride + 1;
   const int units = n * edvr::cdiv(ho, 2) * edvr::cdiv(wo, 32);
   const int mw = edvr::wgrad_mw(co, stride);
   const int tiles = edvr::cdiv(ci, 32 * (4 / mw)) * edvr::cdiv(co, 32 * mw);
-  return (size_t)edvr::wgrad_splits(tiles, units) * co * ci * ks * ks * sizeof(float);
+  return std::max(wino, (size_t)edvr::wgrad_splits(tiles, units) * co * ci * ks * ks * sizeof(float));
 }
 
 int edvr_conv2d_wgrad_f32(const float *x1, const float *x2, const float *dz, float *dw, int c1, int c2, int n, int h, int w, int co,
@@ -255,6 +258,16 @@ int edvr_conv2d_wgrad_f32(const float *x1, const float *x2, const float *dz, flo
     return EDVR_ERR_WORKSPACE;
   }
   hipStream_t stream = as_stream(stream_);
+  int wsplits = 0;
+  if (winograd_wgrad_plan(n, c1, c2, h, w, co, ks, stride, &wsplits) && ws_bytes >= winograd_wgrad_ws_bytes(co, ci, wsplits)) {
+    int rc = winograd_wgrad_launch(x1, x2, dz, a.ws, c1, c2, n, h, w, co, x1_img_stride, x2_img_stride, x2_div, x2_mul, x2_add,
+                                   dz_img_stride, wsplits, stream);
+    if (rc) return rc;
+    const int64_t total = (int64_t)co * ci * 9;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 2048)), dim3(256), 0, stream, a.ws, dw,
+                       total, 2 * wsplits, accumulate);
+    return check_launch("wgrad_reduce_kernel");
+  }
   dim3 grid(cdiv(ci, 32 * (4 / mw)), cdiv(co, 32 * mw), a.splits);
 #define EDVR_WGRAD_LAUNCH(KS_, ST_)                                                                                   \
   do {                                                                                                                \
@@ -272,6 +285,14 @@ int edvr_conv2d_wgrad_f32(const float *x1, const float *x2, const float *dz, flo
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 2048)), dim3(256), 0, stream, a.ws, dw,
                      total, a.splits, accumulate);
   return check_launch("wgrad_reduce_kernel");
+}
+
+int edvr_conv2d_wgrad_algo(int algo) {
+  if (algo != EDVR_CONV_AUTO && algo != EDVR_CONV_DIRECT && algo != EDVR_CONV_WINOGRAD) {
+    edvr::set_error("wgrad_algo: unknown algorithm %d", algo);
+    return EDVR_ERR_ARG;
+  }
+  return edvr::winograd_wgrad_set_algo(algo);
 }
 
 int edvr_channel_sum_f32(const float *x, float *out, int n, int c, int64_t hw, int64_t img_stride, void *ws, size_t ws_bytes,

@@ -1,0 +1,327 @@
+// winograd_wgrad.hip - weight gradient of the 3x3 / stride-1 convolution in the Winograd F(2x2, 3x3) domain (gfx950).
+//
+// The direct weight-gradient kernel (wgrad.hip) issues 36 multiplies per 2x2 output tile and channel pair and runs at
+// ~57 % of the fp32 MFMA peak; it was the largest kernel of the training step (35 %).  With Y = A^T [U (.) V] A the
+// gradient of the transformed weights is a plain GEMM over tiles, 16 multiplies per tile and channel pair (2.25x fewer):
+//
+//   V  = B^T d B            input transform of each 4x4 patch         (as in the forward, winograd.hip)
+//   Z  = A dY A^T           transform of the 2x2 output-gradient tile (4x4)
+//   dU[xi][co, ci] = sum over tiles of Z[xi][co, tile] * V[xi][ci, tile]      16 GEMMs on v_mfma_f32_32x32x2_f32, k = tile
+//   dW = G^T dU G           3x3 from 4x4, linear: applied per workgroup before the split-K partial is written
+//
+// Same machine mapping as the forward: 512-thread workgroups, two waves per SIMD, wave = (ph, 32 x 32 quadrant of the
+// 64 co x 64 ci block), ph = transform rows {2ph, 2ph+1} = 8 accumulator tiles; per chunk of 8 tiles (one k-chunk) the Z
+// and V slabs are staged in LDS (double-buffered, 132 KB) by a rotating-register pipeline; all global reads are buffer
+// loads whose hardware range check supplies the zero padding.  The tile axis is split over workgroups (deterministic
+// split-K); each wave writes the G-transformed partial of its two rows, wgrad_reduce_kernel sums 2 * splits partials.
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+
+namespace edvr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct WinoWgradArgs {
+  const float *x1, *x2, *dz;
+  float *ws;  // [2 * splits][co][ci][9]
+  int c1, c2, n, h, w, co;
+  int64_t x1_img_stride, x2_img_stride, dz_img_stride;
+  int x2_div, x2_mul, x2_add;
+  int cpr, th, total_chunks, splits, ci_blocks, co_blocks;  // chunks (8 tiles) per tile row, tile rows, n * th * cpr
+};
+
+__global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const WinoWgradArgs a) {
+  constexpr int TS = 16 * 64 + 8;  // floats per tile in a slab: [tile][xi][channel], +8 so the 8 tiles x 8 channels a wave
+                                   // writes per instruction land in 64 different banks
+  constexpr int SLAB = 8 * TS, SMEM = 4 * SLAB;  // (Z, V) x 2 stages = 132 KB
+  constexpr int RSRC_FLAGS = 0x00020000;
+  constexpr int OOB = (int)0x80000000;  // >= num_records: the load returns 0 without touching memory
+  __shared__ __attribute__((aligned(16))) float smem[SMEM];
+
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, j = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int quad = wave & 3, wm = quad >> 1, wn = quad & 1, ph = wave >> 2;
+  const int hw = a.h * a.w, ci_total = a.c1 + a.c2;
+  // (split, co block, ci block) of this workgroup, XCD-aware: the blocks of one split read the same tiles (common.h)
+  const int blocks = a.ci_blocks * a.co_blocks;
+  const int lg = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int split = __builtin_amdgcn_readfirstlane(lg / blocks);
+  const int blk = __builtin_amdgcn_readfirstlane(lg % blocks);
+  const int co_blk = __builtin_amdgcn_readfirstlane((blk / a.ci_blocks) * 64);
+  const int ci_blk = __builtin_amdgcn_readfirstlane((blk % a.ci_blocks) * 64);
+  // chunk range of this split, in pairs (the loop body handles two chunks); chunks >= total_chunks are fully masked
+  const int pairs_total = (a.total_chunks + 1) / 2;
+  const int q0 = __builtin_amdgcn_readfirstlane(2 * (int)((int64_t)pairs_total * split / a.splits));
+  const int q1 = __builtin_amdgcn_readfirstlane(2 * (int)((int64_t)pairs_total * (split + 1) / a.splits));
+  if (q0 >= q1) return;  // (never with splits <= pairs_total; the partial of this split would stay unwritten)
+
+  // ---- staging role of this thread: channel chl = 8 wave + (lane >> 3) of the block, tile t = lane & 7 of the chunk
+  const int t = lane & 7, chl = wave * 8 + (lane >> 3);
+  const bool use_x2 = a.c2 > 0 && ci_blk >= a.c1;  // blocks never straddle x1 / x2 (c1 % 64 == 0, checked by the host)
+  const int ci_s = ci_blk + chl, co_s = co_blk + chl;
+  const bool valid_ci = ci_s < (use_x2 || a.c2 == 0 ? ci_total : a.c1), valid_co = co_s < a.co;
+  const int ci_in = use_x2 ? ci_s - a.c1 : ci_s;
+  int rel[16];  // byte offset of patch element (r, c) of tile t from the chunk's window origin (top-left halo pixel)
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) rel[r * 4 + c] = (ci_in * hw + r * a.w + c + 2 * t) * 4;
+  const int dz_rel = (co_s * hw + 2 * t) * 4;
+
+  // ---- geometry of the chunk being LOADED (wave-uniform; advanced branch-free once per iteration)
+  int q = q0;
+  int xc, ty, img;
+  {
+    const int unit = q0 / a.cpr;
+    xc = __builtin_amdgcn_readfirstlane(q0 % a.cpr);
+    ty = __builtin_amdgcn_readfirstlane(unit % a.th);
+    img = __builtin_amdgcn_readfirstlane(unit / a.th);
+  }
+  auto uniform_rsrc = [&](const float *p) {
+    const uint64_t pv = reinterpret_cast<uint64_t>(p);
+    const uint64_t pu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pv >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pv);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(pu), (short)0, 0x7fffffff, RSRC_FLAGS);
+  };
+  __amdgpu_buffer_rsrc_t x_rsrc = uniform_rsrc(a.x1), z_rsrc = x_rsrc;
+  bool rowok[4], colok[4], tile_ok;
+  auto geometry = [&]() {  // resources and validity masks of chunk q = (img, ty, xc)
+    const bool in_range = q < a.total_chunks;
+    const float *xi;
+    if (use_x2) {
+      const int i2 = a.x2_div > 0 ? (img / a.x2_div) * a.x2_mul + a.x2_add : img;
+      xi = a.x2 + (int64_t)i2 * a.x2_img_stride;
+    } else {
+      xi = a.x1 + (int64_t)img * a.x1_img_stride;
+    }
+    // window origin = halo pixel (2 ty - 1, 16 xc - 1): may lie outside the image, those elements are masked below
+    x_rsrc = uniform_rsrc(xi + ((int64_t)(2 * ty - 1) * a.w + 16 * xc - 1));
+    z_rsrc = uniform_rsrc(a.dz + (int64_t)img * a.dz_img_stride + ((int64_t)2 * ty * a.w + 16 * xc));
+    const int gx = 16 * xc + 2 * t - 1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rowok[r] = in_range && (unsigned)(2 * ty - 1 + r) < (unsigned)a.h;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) colok[c] = valid_ci && (unsigned)(gx + c) < (unsigned)a.w;
+    tile_ok = in_range && valid_co && (8 * xc + t) * 2 < a.w;
+  };
+  auto advance = [&]() {
+    ++q;
+    ++xc;
+    const bool wrap_x = xc == a.cpr;
+    xc = wrap_x ? 0 : xc;
+    ty += wrap_x ? 1 : 0;
+    const bool wrap_y = ty == a.th;
+    ty = wrap_y ? 0 : ty;
+    img += wrap_y ? 1 : 0;
+  };
+
+  f32x16 acc[8];  // [xi - 8 ph]
+  float pr[16];   // raw patch (channel chl, tile t) of the chunk being staged
+  float tt[16];   // B^T d
+  f32x2 dy[2][2]; // [chunk parity][row] 2x2 output-gradient tile of (channel chl, tile t)
+  auto load_col = [&](int c) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      pr[r * 4 + c] = __builtin_bit_cast(
+          float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (rowok[r] && colok[c]) ? rel[r * 4 + c] : OOB, 0, 0));
+  };
+  auto load_dy = [&](auto SET) {
+    constexpr int S = decltype(SET)::value;
+    dy[S][0] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(z_rsrc, tile_ok ? dz_rel : OOB, 0, 0));
+    dy[S][1] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(z_rsrc, tile_ok ? dz_rel + a.w * 4 : OOB, 0, 0));
+  };
+  auto transform_col = [&](int c) {
+    const float d0 = pr[0 * 4 + c], d1 = pr[1 * 4 + c], d2 = pr[2 * 4 + c], d3 = pr[3 * 4 + c];
+    tt[0 * 4 + c] = d0 - d2;
+    tt[1 * 4 + c] = d1 + d2;
+    tt[2 * 4 + c] = d2 - d1;
+    tt[3 * 4 + c] = d1 - d3;
+  };
+  auto commit_v_row = [&](float *Vs, int r) {  // positions xi = 4r .. 4r+3 of (B^T d) B
+    const float *s = tt + r * 4;
+    float *dst = Vs + t * TS + (r * 4) * 64 + chl;
+    dst[0 * 64] = s[0] - s[2];
+    dst[1 * 64] = s[1] + s[2];
+    dst[2 * 64] = s[2] - s[1];
+    dst[3 * 64] = s[1] - s[3];
+  };
+  auto commit_z_row = [&](float *Zs, auto SET, int r) {  // row r of A dY A^T, A = [[1,0],[1,1],[1,-1],[0,-1]]
+    constexpr int S = decltype(SET)::value;
+    const float p = dy[S][0][0], qq = dy[S][0][1], u = dy[S][1][0], v = dy[S][1][1];
+    // rows of A dY: (p, qq), (p + u, qq + v), (p - u, qq - v), (-u, -v)
+    const float e = r == 0 ? p : r == 1 ? p + u : r == 2 ? p - u : -u;
+    const float f = r == 0 ? qq : r == 1 ? qq + v : r == 2 ? qq - v : -v;
+    float *dst = Zs + t * TS + (r * 4) * 64 + chl;
+    dst[0 * 64] = e;
+    dst[1 * 64] = e + f;
+    dst[2 * 64] = e - f;
+    dst[3 * 64] = -f;
+  };
+
+  const int abase = half * TS + ph * 8 * 64 + wm * 32 + j;  // A operand (Z): tile `half` of the pair, this wave's co tile
+  const int bbase = half * TS + ph * 8 * 64 + wn * 32 + j;  // B operand (V): this wave's ci tile
+  // One chunk (parity P): 8 groups (tile pair s = g >> 1, positions 8 ph + 4 (g & 1) .. +3) of 4 MFMAs on LDS stage P; the
+  // chunk held in registers (k+1) is transformed into stage 1-P and every register is reloaded with chunk k+2 right after
+  // its last use.  Branch-free.
+  auto iteration = [&](auto PAR) {
+    constexpr int P = decltype(PAR)::value;
+    using Other = std::integral_constant<int, 1 - P>;
+    const float *Zs = smem + P * 2 * SLAB, *Vs = Zs + SLAB;
+    float *Zd = smem + (1 - P) * 2 * SLAB, *Vd = Zd + SLAB;
+    advance();
+    geometry();
+    float av[2][4], bv[2][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      av[0][i] = Zs[abase + i * 64];
+      bv[0][i] = Vs[bbase + i * 64];
+    }
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const int cur = g & 1, nxt = cur ^ 1;
+      if (g + 1 < 8) {
+        const int sn = (g + 1) >> 1, x0n = ((g + 1) & 1) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          av[nxt][i] = Zs[abase + 2 * sn * TS + (x0n + i) * 64];
+          bv[nxt][i] = Vs[bbase + 2 * sn * TS + (x0n + i) * 64];
+        }
+      }
+      const int x0 = (g & 1) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[x0 + i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][i], acc[x0 + i], 0, 0, 0);
+      if (g == 0) load_dy(PAR);  // set P held chunk k, consumed an iteration ago
+      if (g < 4) {
+        transform_col(g);
+        load_col(g);
+      } else {
+        commit_v_row(Vd, g - 4);
+        commit_z_row(Zd, Other{}, g - 4);
+      }
+    }
+    // LDS-only barrier: the loads just issued target registers and need no cross-wave ordering
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+
+  // ---- prologue: chunk q0 -> registers -> LDS stage 0, chunk q0 + 1 -> registers
+  geometry();
+  load_dy(S0{});
+#pragma unroll
+  for (int c = 0; c < 4; ++c) load_col(c);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) transform_col(c);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    commit_v_row(smem + SLAB, r);
+    commit_z_row(smem, S0{}, r);
+  }
+  advance();
+  geometry();
+  load_dy(S1{});
+#pragma unroll
+  for (int c = 0; c < 4; ++c) load_col(c);
+#pragma unroll
+  for (int xi = 0; xi < 8; ++xi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
+  __syncthreads();
+
+#pragma unroll 1
+  for (int k = q0; k < q1; k += 2) {
+    iteration(S0{});
+    iteration(S1{});
+  }
+
+  // ---- epilogue: this wave's share of dW = G^T dU G.  Row pass t[rr][jx] = (dU G)[2 ph + rr][jx], then the two rows
+  //      weighted by G[2 ph + rr][i]; the sibling wave's rows and the other splits are added by wgrad_reduce_kernel.
+  //      G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+  const float g0[3] = {ph ? 0.5f : 1.f, ph ? -0.5f : 0.f, ph ? 0.5f : 0.f};  // G[2 ph][.]
+  const float g1[3] = {ph ? 0.f : 0.5f, ph ? 0.f : 0.5f, ph ? 1.f : 0.5f};   // G[2 ph + 1][.]
+  float *out = a.ws + (int64_t)(2 * split + ph) * a.co * ci_total * 9;
+  const int ci_o = ci_blk + wn * 32 + j;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co_o = co_blk + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    float tr[2][3];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const float u0 = acc[rr * 4 + 0][r], u1 = acc[rr * 4 + 1][r], u2 = acc[rr * 4 + 2][r], u3 = acc[rr * 4 + 3][r];
+      tr[rr][0] = u0 + 0.5f * (u1 + u2);
+      tr[rr][1] = 0.5f * (u1 - u2);
+      tr[rr][2] = 0.5f * (u1 + u2) + u3;
+    }
+    if (co_o < a.co && ci_o < ci_total) {
+      float *dst = out + ((int64_t)co_o * ci_total + ci_o) * 9;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int jx = 0; jx < 3; ++jx) dst[i * 3 + jx] = g0[i] * tr[0][jx] + g1[i] * tr[1][jx];
+    }
+  }
+}
+
+static int wino_wgrad_cus() {
+  static const int n_cu = []() {
+    int dev = 0, n = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    return n;
+  }();
+  return n_cu;
+}
+
+static int g_wgrad_algo = EDVR_CONV_AUTO;
+int winograd_wgrad_set_algo(int algo) {
+  const int prev = g_wgrad_algo;
+  g_wgrad_algo = algo;
+  return prev;
+}
+
+// Plan of the Winograd weight gradient: false if the layer is not eligible (the direct kernel handles it).
+bool winograd_wgrad_plan(int n, int c1, int c2, int h, int w, int co, int ks, int stride, int *splits) {
+  static const bool enabled = []() {
+    const char *e = getenv("EDVR_WGRAD_WINOGRAD");  // "0": always use the direct kernel (A/B, fallback)
+    return !(e && e[0] == '0');
+  }();
+  const int ci = c1 + c2;
+  const bool forced = g_wgrad_algo == EDVR_CONV_WINOGRAD;
+  if (g_wgrad_algo == EDVR_CONV_DIRECT || (!enabled && !forced)) return false;
+  if (ks != 3 || stride != 1 || (h & 1) || (w & 1)) return false;
+  if (!forced && (co < 48 || ci < 48)) return false;  // mostly-empty 64 x 64 blocks: the direct kernel's narrow tiles win
+  if (c2 > 0 && (c1 % 64) != 0) return false;                      // a 64-channel block must not straddle the two inputs
+  if ((int64_t)std::max(std::max(c1, c2), co) * h * w * 4 >= (int64_t)1 << 31) return false;  // 32-bit buffer offsets
+  const int cpr = cdiv(w / 2, 8), total_chunks = n * (h / 2) * cpr, pairs = (total_chunks + 1) / 2;
+  const int blocks = cdiv(ci, 64) * cdiv(co, 64);
+  int s = std::max(1, wino_wgrad_cus() / blocks);
+  if (s > pairs) s = pairs;
+  if (!forced && pairs < 4 * s && pairs < 64) return false;  // too little work per workgroup to amortise the pipeline fill
+  *splits = s;
+  return true;
+}
+
+size_t winograd_wgrad_ws_bytes(int co, int ci, int splits) { return (size_t)2 * splits * co * ci * 9 * sizeof(float); }
+
+int winograd_wgrad_launch(const float *x1, const float *x2, const float *dz, float *ws, int c1, int c2, int n, int h, int w, int co,
+                          int64_t x1_img_stride, int64_t x2_img_stride, int x2_div, int x2_mul, int x2_add, int64_t dz_img_stride,
+                          int splits, hipStream_t stream) {
+  WinoWgradArgs a;
+  a.x1 = x1; a.x2 = x2; a.dz = dz; a.ws = ws;
+  a.c1 = c1; a.c2 = c2; a.n = n; a.h = h; a.w = w; a.co = co;
+  a.x1_img_stride = x1_img_stride; a.x2_img_stride = x2_img_stride; a.dz_img_stride = dz_img_stride;
+  a.x2_div = x2_div; a.x2_mul = x2_mul; a.x2_add = x2_add;
+  a.cpr = cdiv(w / 2, 8);
+  a.th = h / 2;
+  a.total_chunks = n * a.th * a.cpr;
+  a.splits = splits;
+  a.ci_blocks = cdiv(c1 + c2, 64);
+  a.co_blocks = cdiv(co, 64);
+  hipLaunchKernelGGL(conv3x3_winograd_wgrad_kernel, dim3(splits * a.ci_blocks * a.co_blocks), dim3(512), 0, stream, a);
+  return check_launch("conv3x3_winograd_wgrad_kernel");
+}
+
+}  // namespace edvr

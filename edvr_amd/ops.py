@@ -286,8 +286,17 @@ def act_backward(dy, y, act, act_from=0, res1=None, res2=None):
     return dz
 
 
+def set_wgrad_algo(algo):
+    """Process-wide algorithm request of conv2d_wgrad (CONV_AUTO | CONV_DIRECT | CONV_WINOGRAD); returns the previous one."""
+    prev = _lib.lib().edvr_conv2d_wgrad_algo(int(algo))
+    if prev < 0:
+        _lib.check(prev, 'edvr_conv2d_wgrad_algo')
+    return prev
+
+
 def conv2d_wgrad(x1, x2, x2_map, dz, co, ks, stride):
-    """dW (co, c1+c2, ks, ks) of the fused conv, fp32 MFMA implicit GEMM over the pixel axis."""
+    """dW (co, c1+c2, ks, ks) of the fused conv: Winograd-domain GEMM over tiles (3x3 / stride 1) or fp32 MFMA implicit GEMM
+    over the pixel axis."""
     require_gpu(x1, x2, dz)
     L = _lib.lib()
     x1, dz = _as_planes(x1), _as_planes(dz)

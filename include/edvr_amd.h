@@ -169,6 +169,12 @@ size_t edvr_conv2d_wgrad_ws_bytes(int n, int ci, int h, int w, int co, int ks, i
 int edvr_conv2d_wgrad_f32(const float *x1, const float *x2, const float *dz, float *dw, int c1, int c2, int n, int h, int w,
                           int co, int ks, int stride, int64_t x1_img_stride, int64_t x2_img_stride, int x2_div, int x2_mul,
                           int x2_add, int64_t dz_img_stride, int accumulate, void *ws, size_t ws_bytes, edvr_stream_t stream);
+
+/* Algorithm request for edvr_conv2d_wgrad_f32 (process-wide; tests and benchmarks use it to run both kernels on the same
+ * layer): EDVR_CONV_AUTO (default: Winograd-domain kernel where eligible and profitable), EDVR_CONV_DIRECT, or
+ * EDVR_CONV_WINOGRAD (wherever structurally possible: 3x3, stride 1, even h and w, c1 % 64 == 0 when x2 is given).
+ * Returns the previous setting.  No reference counterpart (cuDNN picks its backward-filter algorithm internally). */
+int edvr_conv2d_wgrad_algo(int algo);
 /* out[c] = sum_{n,p} x[n,c,p]  (bias gradient); img_stride 0 = contiguous; ws: >= 64*c floats of scratch for the
  * deterministic two-stage reduction (NULL = single-stage, slower) */
 int edvr_channel_sum_f32(const float *x, float *out, int n, int c, int64_t hw, int64_t img_stride, void *ws, size_t ws_bytes,

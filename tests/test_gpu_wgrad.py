@@ -1,0 +1,51 @@
+"""-m gpu: weight gradient of the fused conv through the C ABI (edvr_conv2d_wgrad_f32): the Winograd-domain kernel and the
+direct kernel against torch's fp64 conv2d_weight on the CPU (tolerance: 2e-5 of max |dW|, fp32 accumulation over <= 1e5 pixels)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # n, c1, c2, h, w, co, x2_map
+    (4, 64, 0, 32, 32, 64, None),
+    (2, 128, 0, 16, 48, 128, None),      # 24 tiles per row: 3 chunks
+    (3, 64, 64, 20, 36, 96, None),       # concat input, 18 tiles per row (phantom tiles in the last chunk), partial co block
+    (2, 48, 0, 8, 8, 48, None),          # partial ci and co blocks
+    (1, 64, 0, 4, 6, 64, None),          # 3 chunks: odd count, masked tail chunk
+    (6, 64, 64, 16, 16, 64, (3, 1, 0)),  # x2 is a broadcast reference frame: image i of x2 is i // 3
+    (5, 192, 0, 12, 20, 216, None),      # 3 ci blocks x 4 co blocks (the offset-conv shape)
+    (32, 128, 0, 64, 64, 128, None),     # EDVR-L training trunk layer at full size
+]
+
+
+@pytest.mark.parametrize('algo', ['winograd', 'direct', 'auto'])
+@pytest.mark.parametrize('case', CASES, ids=lambda c: 'n%d_c%d+%d_%dx%d_co%d%s' % (c[0], c[1], c[2], c[3], c[4], c[5], '_map' if c[6] else ''))
+def test_wgrad_matches_fp64_reference(gpu, case, algo):
+    from edvr_amd import ops
+    n, c1, c2, h, w, co, x2_map = case
+    g = torch.Generator().manual_seed(n * 1000 + h * 10 + co)
+    x1 = torch.randn(n, c1, h, w, generator=g)
+    n2 = n if x2_map is None else n // x2_map[0]
+    x2 = torch.randn(n2, c2, h, w, generator=g) if c2 else None
+    dz = torch.randn(n, co, h, w, generator=g)
+    if c2:
+        x2_full = x2 if x2_map is None else x2[(torch.arange(n) // x2_map[0]) * x2_map[1] + x2_map[2]]
+        xcat = torch.cat([x1, x2_full], 1)
+    else:
+        xcat = x1
+    ref = torch.nn.grad.conv2d_weight(xcat.double(), (co, c1 + c2, 3, 3), dz.double(), padding=1)
+    prev = ops.set_wgrad_algo({'winograd': ops.CONV_WINOGRAD, 'direct': ops.CONV_DIRECT, 'auto': ops.CONV_AUTO}[algo])
+    try:
+        dw = ops.conv2d_wgrad(x1.to(gpu), x2.to(gpu) if c2 else None, x2_map, dz.to(gpu), co, 3, 1)
+        dw2 = ops.conv2d_wgrad(x1.to(gpu), x2.to(gpu) if c2 else None, x2_map, dz.to(gpu), co, 3, 1)
+    finally:
+        ops.set_wgrad_algo(prev)
+    assert torch.equal(dw, dw2), 'split-K reduction must be deterministic'
+    err = (dw.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-5, err
+
+
+def test_wgrad_algo_setter_rejects_unknown(gpu):
+    from edvr_amd import ops
+    with pytest.raises(Exception):
+        ops.set_wgrad_algo(17)
+    assert ops.set_wgrad_algo(ops.CONV_AUTO) == ops.CONV_AUTO
