@@ -36,7 +36,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct WinoArgs {
   edvr_conv2d_desc d;
   const float *U;  // [ci_pad][16][cop]
-  int ci, cop, tiles_x, tiles_y, items;
+  int ci, ci_real, cop, tiles_x, tiles_y, items;  // ci: rounded up to 16 (U has all-zero rows there), ci_real = c1 + c2
 };
 
 // Accumulators are plain vector values: with 128 of them per wave (two waves per SIMD share the unified 512-register file,
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_kernel(const WinoArgs
   auto load_begin = [&](int c0) {
     const int c = c0 + wave;
     const float *pl = (c < d.c1) ? (x1 + (int64_t)c * hw) : (x2 + (int64_t)(c - d.c1) * hw);
-    ld_rsrc = uniform_rsrc(pl, plane_bytes);
+    ld_rsrc = uniform_rsrc(pl, c < a.ci_real ? plane_bytes : 0);  // channels of the 16-padding: empty buffer, every load returns 0
     u_rsrc = uniform_rsrc(a.U, u_bytes);
     ld_u_soff = (c0 * 16 * a.cop + co_blk) * 4;
   };
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_kernel(const WinoArgs
   __syncthreads();
 
   for (int item = item_first; item < item_end; item += xcd_wgs) {
-    // ci is a multiple of 2*CK (checked by winograd_eligible): chunk k (parity k & 1) loads chunk k+2
+    // a.ci is a multiple of 2*CK (rounded up by the host): chunk k (parity k & 1) loads chunk k+2
 #pragma unroll 1
     for (int c0 = 2 * CK; c0 < a.ci; c0 += 2 * CK) {
       iteration(S0{}, c0, std::true_type{});
@@ -465,16 +465,17 @@ bool winograd_eligible(const edvr_conv2d_desc &d) {
       (d.out_mode != EDVR_OUT_NCHW && has_res))
     return false;
   if (d.algo == EDVR_CONV_DIRECT) return false;
-  const bool applicable = d.ks == 3 && d.stride == 1 && (d.c1 + d.c2) % 16 == 0;
+  const bool applicable = d.ks == 3 && d.stride == 1;  // any channel count: the loop runs over ci rounded up to 16
   if (d.algo == EDVR_CONV_WINOGRAD) return applicable;  // explicit request: any size the kernel can do
-  return enabled && applicable && d.co >= 48 && d.w > 16 && d.h >= 4;  // auto: only where it beats the direct kernel
+  return enabled && applicable && d.co >= 48 && d.c1 + d.c2 >= 32 && d.w > 16 && d.h >= 4;  // auto: only where it beats the direct kernel
 }
 
 int winograd_launch(const edvr_conv2d_desc &d, const float *U, int cop, hipStream_t stream) {
   WinoArgs a;
   a.d = d;
   a.U = U;
-  a.ci = d.c1 + d.c2;
+  a.ci_real = d.c1 + d.c2;
+  a.ci = (a.ci_real + 15) / 16 * 16;
   a.cop = cop;
   a.tiles_x = cdiv(d.w, 32);
   a.tiles_y = cdiv(d.h, 8);

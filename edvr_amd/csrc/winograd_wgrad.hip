@@ -125,8 +125,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
   auto load_col = [&](int c) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
+#ifdef WW_EXP_NOLOAD
+      pr[r * 4 + c] = (rowok[r] && colok[c]) ? 1.f : 0.f;  /* ablation only */
+#elif defined(WW_EXP_ONEADDR)
+      pr[r * 4 + c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (rowok[r] && colok[c]) ? 64 : OOB, 0, 0));
+#else
       pr[r * 4 + c] = __builtin_bit_cast(
           float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (rowok[r] && colok[c]) ? rel[r * 4 + c] : OOB, 0, 0));
+#endif
   };
   auto load_dy = [&](auto SET) {
     constexpr int S = decltype(SET)::value;
@@ -143,10 +149,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
   auto commit_v_row = [&](float *Vs, int r) {  // positions xi = 4r .. 4r+3 of (B^T d) B
     const float *s = tt + r * 4;
     float *dst = Vs + t * TS + (r * 4) * 64 + chl;
-    dst[0 * 64] = s[0] - s[2];
-    dst[1 * 64] = s[1] + s[2];
-    dst[2 * 64] = s[2] - s[1];
-    dst[3 * 64] = s[1] - s[3];
+#ifdef WW_EXP_NOCOMMIT
+    if (s[0] == 12345.f)  /* ablation only */
+#endif
+    {
+      dst[0 * 64] = s[0] - s[2];
+      dst[1 * 64] = s[1] + s[2];
+      dst[2 * 64] = s[2] - s[1];
+      dst[3 * 64] = s[1] - s[3];
+    }
   };
   auto commit_z_row = [&](float *Zs, auto SET, int r) {  // row r of A dY A^T, A = [[1,0],[1,1],[1,-1],[0,-1]]
     constexpr int S = decltype(SET)::value;
@@ -171,8 +182,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
     using Other = std::integral_constant<int, 1 - P>;
     const float *Zs = smem + P * 2 * SLAB, *Vs = Zs + SLAB;
     float *Zd = smem + (1 - P) * 2 * SLAB, *Vd = Zd + SLAB;
+#ifndef WW_EXP_NOGEOM
     advance();
     geometry();
+#endif
     float av[2][4], bv[2][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

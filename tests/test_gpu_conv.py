@@ -33,6 +33,8 @@ CASES = [
     (1, 16, 16, 10, 50, 64, 3, 1, 'relu', 0, 0),            # winograd: concat input
     (1, 48, 0, 8, 36, 128, 3, 1, 'lrelu', 0, 1),            # winograd: pixel-shuffle epilogue
     (1, 32, 0, 9, 33, 216, 3, 1, 'sigmoid_from', 0, 0),     # winograd: sigmoid-from-channel epilogue, odd width
+    (2, 216, 0, 12, 40, 128, 3, 1, 'none', 0, 0),           # winograd: ci not a multiple of 16 (data gradient of the offset conv)
+    (1, 100, 20, 8, 34, 64, 3, 1, 'lrelu', 1, 0),           # winograd: concat boundary inside a chunk, 120 -> 128 padded channels
 ]
 
 
