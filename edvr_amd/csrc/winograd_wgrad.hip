@@ -214,6 +214,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
         commit_v_row(Vd, g - 4);
         commit_z_row(Zd, Other{}, g - 4);
       }
+      __builtin_amdgcn_sched_barrier(0);  // pin the slice schedule (see winograd.hip)
     }
     // LDS-only barrier: the loads just issued target registers and need no cross-wave ordering
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
