@@ -44,6 +44,16 @@ WORKLOADS = {
                                   shape=(5, 3, 64, 64), batch=32,
                                   desc='EDVR-L x4 training, 5 frames, 64x64 LR crops (256x256 GT), 32 clips/GPU, '
                                        'Charbonnier(sum) + Adam(4e-4, betas 0.9/0.99), DDP'),
+    # BASELINE.json configs[2]: EDVR-L, 7 frames, 180x320, batch 8, TSA on; with --mode train it is the fwd+bwd case
+    # (the saved activations of 8 x 7 frames at 128 channels need ~150 GB: sized for the 288 GB of one MI355X)
+    'edvr_l_x4_t7_180x320': dict(net=dict(num_feat=128, num_frame=7, num_reconstruct_block=40, center_frame_idx=None),
+                                 shape=(7, 3, 180, 320), batch=8,
+                                 desc='EDVR-L x4, 7 frames, 180x320 LR -> 720x1280, batch 8/GPU, TSA on'),
+    # BASELINE.json configs[4]: EDVR-L deblur (hr_in + predeblur, no upscale), 5 frames of 1280x720, 32 clips over 8 GPUs
+    'edvr_l_deblur_t5_720x1280': dict(net=dict(num_feat=128, num_frame=5, num_reconstruct_block=40, center_frame_idx=None,
+                                               hr_in=True, with_predeblur=True),
+                                      shape=(5, 3, 720, 1280), batch=4, scale=1,
+                                      desc='EDVR-L deblur (hr_in, predeblur), 5 frames, 1280x720 -> 1280x720, batch 4/GPU'),
     # BASELINE.json configs[0] (plumbing-sized)
     'edvr_m_x4_t5_64x64': dict(net=dict(num_feat=64, num_frame=5, num_reconstruct_block=10, center_frame_idx=2),
                                shape=(5, 3, 64, 64), batch=1, desc='EDVR-M x4, 5 frames, 64x64 LR crop, batch 1'),
@@ -55,7 +65,8 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', default='edvr_l_x4_t5_180x320', choices=list(WORKLOADS))
+    ap.add_argument('--workload', default=None, choices=list(WORKLOADS),
+                    help='default: edvr_l_x4_t5_180x320 (infer) / edvr_l_train_t5_64x64 (train)')
     ap.add_argument('--batch', type=int, default=0, help='clips per GPU (default: the workload\'s)')
     ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
                     help='infer: forward clips/s (default).  train: fwd + Charbonnier + bwd + grad all-reduce + Adam')
@@ -151,8 +162,8 @@ def main():
     from edvr_amd import _lib
     assert _lib.lib().edvr_check_device() == 0, _lib.lib().edvr_last_error().decode()
 
-    if args.mode == 'train' and not args.workload.startswith('edvr_l_train'):
-        args.workload = 'edvr_l_train_t5_64x64'
+    if args.workload is None:
+        args.workload = 'edvr_l_train_t5_64x64' if args.mode == 'train' else 'edvr_l_x4_t5_180x320'
     cfg = WORKLOADS[args.workload]
     batch = args.batch or cfg['batch']
     net = build_net(cfg, device)
@@ -163,7 +174,8 @@ def main():
         from edvr_amd import dist as D
         from edvr_amd.autograd import charbonnier_loss
         net.train()
-        gt = torch.rand(batch, 3, 4 * cfg['shape'][2], 4 * cfg['shape'][3], generator=torch.Generator().manual_seed(1000 + rank)).to(device)
+        sc = cfg.get('scale', 4)
+        gt = torch.rand(batch, 3, sc * cfg['shape'][2], sc * cfg['shape'][3], generator=torch.Generator().manual_seed(1000 + rank)).to(device)
         model = D.wrap_ddp(net)  # RCCL gradient all-reduce, bucketed and overlapped with backward
         dcn = [p for n, p in net.named_parameters() if 'dcn' in n]  # edvr_model.py:21-53 (dcn_lr_mul: 1)
         rest = [p for n, p in net.named_parameters() if 'dcn' not in n]
@@ -204,10 +216,13 @@ def main():
     result = None
     if rank == 0:
         clips = batch * world * args.steps
-        if args.mode == 'train':
-            metric = 'EDVR-L x4 training clips/sec (= iters/sec x global batch)'
+        if args.workload == 'edvr_l_x4_t5_180x320' and args.mode == 'infer':
+            metric = 'EDVR-L x4 5-frame 720p clips/sec'  # BASELINE.json's metric
+        elif args.mode == 'train':
+            metric = ('EDVR-L x4 training clips/sec (= iters/sec x global batch)' if args.workload == 'edvr_l_train_t5_64x64'
+                      else f'{args.workload} fwd+bwd+Adam clips/sec')
         else:
-            metric = 'EDVR-L x4 5-frame 720p clips/sec' if args.workload.startswith('edvr_l') else 'EDVR-M x4 5-frame 720p clips/sec'
+            metric = f'{args.workload} inference clips/sec'
         result = {
             'metric': metric,
             'value': round(clips / elapsed, 4), 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
