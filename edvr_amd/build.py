@@ -16,7 +16,11 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libedvr_amd.so')
 OBJDIR = os.path.join(HERE, 'build')
-SOURCES = ['api.hip', 'conv2d.hip', 'dcn.hip', 'elementwise.hip', 'wgrad.hip', 'backward.hip', 'dcn_fused.hip', 'winograd.hip', 'winograd_wgrad.hip']
+SOURCES = ['api.hip', 'conv2d.hip', 'dcn.hip', 'elementwise.hip', 'wgrad.hip', 'backward.hip', 'dcn_fused.hip', 'winograd.hip', 'winograd_wgrad.hip', 'blas.hip']
+# rocBLAS: the two plain GEMMs of the DCNv2 backward (csrc/blas.hip).  In a PyTorch process the already-loaded librocblas.so.5
+# of torch satisfies the dependency; stand-alone C hosts get it from the ROCm install.
+LINK = ['-L' + os.path.join(os.environ.get('ROCM_PATH', '/opt/rocm'), 'lib'), '-lrocblas',
+        '-Wl,-rpath,' + os.path.join(os.environ.get('ROCM_PATH', '/opt/rocm'), 'lib')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-ffp-contract=fast']
 
 
@@ -60,7 +64,7 @@ def build(force=False, verbose=False):
     with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
-        run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs)
+        run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + LINK)
     return LIB
 
 

@@ -40,6 +40,12 @@ bool winograd_eligible(const edvr_conv2d_desc &d);
 int winograd_launch(const edvr_conv2d_desc &d, const float *U, int cop64, hipStream_t stream);
 int winograd_pack(const float *w, float *U, int co, int ci, int cop64, int cip, int transpose_flip, hipStream_t stream);
 
+// blas.hip: row-major strided-batched fp32 GEMM on rocBLAS (plain GEMMs only: the DCNv2 backward's dcol and dW)
+int blas_gemm_rowmajor(const float *A, const float *B, float *C, int M, int N, int K, bool a_trans, bool b_trans, int64_t lda,
+                       int64_t ldb, int64_t ldc, int64_t stride_a, int64_t stride_b, int64_t stride_c, int batch, hipStream_t stream);
+// wgrad.hip: out[i] (+)= sum_k ws[k * total + i]
+int reduce_partials_launch(const float *ws, float *out, int64_t total, int parts, int accumulate, hipStream_t stream);
+
 // winograd_wgrad.hip: weight gradient of the 3x3 / stride-1 conv in the Winograd domain.  plan() says whether the layer is
 // eligible and how many split-K partial pairs it writes; the partials ([2*splits][co][ci][9]) are summed by wgrad_reduce_kernel.
 bool winograd_wgrad_plan(int n, int c1, int c2, int h, int w, int co, int ks, int stride, int *splits);

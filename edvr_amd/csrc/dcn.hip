@@ -330,7 +330,7 @@ static BwdWs bwd_ws(const DcnShape &s) {
   w.wpk = off;
   off += align_up(edvr_conv2d_packed_weight_elems((int)(cig * K), cog, 1) * 4 * s.groups, 256);
   w.gemm = off;
-  off += align_up(gemm_nt_ws_elems_b(cog, (int)(cig * K), (int64_t)P, s.B) * 4, 256);
+  off += align_up(std::max(gemm_nt_ws_elems_b(cog, (int)(cig * K), (int64_t)P, s.B), (size_t)s.B * s.Co * cig * K) * 4, 256);
   w.total = off;
   return w;
 }
@@ -430,10 +430,20 @@ int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, c
   float *wpk = reinterpret_cast<float *>(static_cast<char *>(ws) + wsz.wpk);
   float *gws = reinterpret_cast<float *>(static_cast<char *>(ws) + wsz.gemm);
   const int cig = C / groups, cog = Co / groups;
-  // 1. dcol = W^T dY  (1x1 conv over the pixel grid: "input channels" = cog, "output channels" = cig*K)
+  // 1. dcol[b, g] (cig*K x P) = W[g]^T (cig*K x cog) dY[b, g] (cog x P): plain GEMM, rocBLAS (blas.hip)
+  static const bool use_blas = []() {
+    const char *e = getenv("EDVR_DCN_BLAS");  // "0": the library's own GEMM kernels (A/B)
+    return !(e && e[0] == '0');
+  }();
   const size_t wpk_g = edvr_conv2d_packed_weight_elems(cig * K, cog, 1);
   for (int g = 0; g < groups; ++g) {
     const float *wg = weight + (size_t)g * cog * cig * K;
+    if (use_blas) {
+      rc = blas_gemm_rowmajor(wg, dy + (int64_t)g * cog * P, col + (int64_t)g * cig * K * P, cig * K, (int)P, cog, /*a_trans=*/true,
+                              false, cig * K, P, P, 0, (int64_t)Co * P, (int64_t)C * K * P, B, stream);
+      if (rc) return rc;
+      continue;
+    }
     const float *wuse = wg;
     if ((cog % 32) != 0 || ((cig * K) % 32) != 0) {  // W (cog x cig*K, row-major) is already the packed layout when aligned
       rc = edvr_conv2d_pack_weight_f32(wg, wpk + g * wpk_g, cig * K, cog, 1, 1, stream_);
@@ -464,6 +474,15 @@ int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, c
   if (rc) return rc;
   // 3. dW[g] = sum_{b,p} dY[b, g] col[b, g]^T ; db = sum dY
   for (int g = 0; g < groups; ++g) {
+    if (use_blas) {  // per-image partials dY[b, g] col[b, g]^T (batched GEMM), then a deterministic sum over the batch
+      const int64_t wsz_g = (int64_t)cog * cig * K;
+      rc = blas_gemm_rowmajor(dy + (int64_t)g * cog * P, col + (int64_t)g * cig * K * P, gws, cog, cig * K, (int)P, false,
+                              /*b_trans=*/true, P, P, cig * K, (int64_t)Co * P, (int64_t)C * K * P, wsz_g, B, stream);
+      if (rc) return rc;
+      rc = reduce_partials_launch(gws, dweight + (size_t)g * wsz_g, wsz_g, B, 0, stream);
+      if (rc) return rc;
+      continue;
+    }
     rc = gemm_nt_batched(dy + (int64_t)g * cog * P, col + (int64_t)g * cig * K * P, dweight + (size_t)g * cog * cig * K, cog, cig * K, P,
                          P, P, B, (int64_t)Co * P, (int64_t)C * K * P, false, gws, stream);
     if (rc) return rc;

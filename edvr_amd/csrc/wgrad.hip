@@ -198,6 +198,12 @@ __global__ void channel_sum_final_kernel(const float *__restrict__ part, float *
   out[c] = s;
 }
 
+int reduce_partials_launch(const float *ws, float *out, int64_t total, int parts, int accumulate, hipStream_t stream) {
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 2048)), dim3(256), 0, stream, ws, out, total,
+                     parts, accumulate);
+  return check_launch("wgrad_reduce_kernel");
+}
+
 static inline int wgrad_mw(int co, int stride) {
   const int mw = co > 64 ? 4 : (co > 32 ? 2 : 1);
   return (stride == 2 && mw == 1) ? 2 : mw;  // the stride-2 halo tile of 128 input channels would not fit LDS
