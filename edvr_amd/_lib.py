@@ -37,7 +37,7 @@ PROTOTYPES = {
     'edvr_dcnv2_fwd_ws_bytes': (sz, [i32] * 12),
     'edvr_dcnv2_fwd_f32': (i32, [vp] * 6 + [i32] * 12 + [i64, i64, i32, i32, vp, sz, vp]),
     'edvr_dcnv2_bwd_ws_bytes': (sz, [i32] * 12),
-    'edvr_dcnv2_bwd_f32': (i32, [vp] * 10 + [i32] * 12 + [i64, i64, i64, i64, vp, sz, vp]),
+    'edvr_dcnv2_bwd_f32': (i32, [vp] * 10 + [i32] * 12 + [i64, i64, i64, i64, i32, vp, sz, vp]),
     'edvr_tsa_temporal_f32': (i32, [vp] * 5 + [i32] * 4 + [vp]),
     'edvr_pool_maxavg_3x3s2_f32': (i32, [vp, vp, i32, i32, i32, i32, vp]),
     'edvr_upsample2x_f32': (i32, [vp, vp, i32, i32, i32, f32, vp]),

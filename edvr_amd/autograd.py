@@ -73,7 +73,7 @@ class DcnFromPackedFn(Function):
 
     @staticmethod
     def forward(ctx, x, om, weight, bias, cfg):
-        stride, padding, dilation, groups, dg, act, hint = cfg
+        stride, padding, dilation, groups, dg, act, hint, _ = cfg
         split = 2 * om.shape[1] // 3
         out = ops.dcnv2_forward(x, om[:, :split], om[:, split:], weight, bias, stride, padding, dilation, groups, dg, act=act,
                                 halo_hint=hint)
@@ -86,13 +86,15 @@ class DcnFromPackedFn(Function):
     @once_differentiable
     def backward(ctx, dy):
         x, om, weight, out = ctx.saved_tensors
-        stride, padding, dilation, groups, dg, act, _ = ctx.cfg
+        stride, padding, dilation, groups, dg, act, _, module = ctx.cfg
+        from .functional import scatter_hint_from_absmean
+        scatter = scatter_hint_from_absmean(getattr(module, 'last_offset_absmean', None))  # statistic of THIS forward
         if act != ACT_NONE:
             dy = ops.act_backward(dy, out, act)
         split = 2 * om.shape[1] // 3
         dom = torch.empty_like(om)
         dx, _, _, dw, db = ops.dcnv2_backward(x, om[:, :split], om[:, split:], weight, dy, ctx.with_bias, stride, padding, dilation,
-                                              groups, dg, doffset=dom[:, :split], dmask=dom[:, split:])
+                                              groups, dg, doffset=dom[:, :split], dmask=dom[:, split:], scatter_hint=scatter)
         return dx, dom, dw, db, None
 
 

@@ -43,6 +43,7 @@ struct Tap {
   int o00, o01, o10, o11;    // clamped element offsets inside one channel plane
   float lh, lw;
   bool ok00, ok01, ok10, ok11;  // corner inside the image AND tap valid
+  int h0, w0;                   // unclamped integer coordinates of corner 00
 };
 
 __device__ __forceinline__ Tap resolve_tap(float h, float w, int H, int W) {
@@ -50,6 +51,8 @@ __device__ __forceinline__ Tap resolve_tap(float h, float w, int H, int W) {
   const bool valid = (h > -1.f) && (w > -1.f) && (h < (float)H) && (w < (float)W);
   const float fh = floorf(h), fw = floorf(w);
   const int h0 = (int)fh, w0 = (int)fw, h1 = h0 + 1, w1 = w0 + 1;
+  t.h0 = h0;
+  t.w0 = w0;
   t.lh = h - fh;
   t.lw = w - fw;
   const float hh = 1.f - t.lh, hw = 1.f - t.lw;
@@ -155,6 +158,125 @@ __global__ __launch_bounds__(256) void dcn_bwd_coord_kernel(const float *__restr
     float *dob = doffset + (int64_t)b * s.doff_bs + (int64_t)(g * 2 * K + 2 * k) * P + p;
     dob[0] = s_y * m;
     dob[P] = s_x * m;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward, tile version for the EDVR signature (3x3, stride 1, pad 1, dil 1, <= 16 channels per deformable group):
+// same arithmetic as dcn_bwd_coord_kernel, but dX is accumulated in LDS.  The grid-stride kernel above issues four
+// device-scope fp32 atomics per (pixel, tap, channel) - 9 GB of fabric write traffic per launch by the PMC counters, and the
+// reason it ran at ~5600 cycles per (tap, channel) iteration.  Here a workgroup owns (image, group, 8 x 32 output pixels):
+// its corner contributions go to a (8 + 2 + 2R) x (32 + 2 + 2R) x 16-channel LDS window with ds_add_f32, and the window is
+// flushed once with one global atomic per touched element (windows of neighbouring tiles overlap): ~14x fewer global
+// atomics.  Taps that leave the window (|offset| > R) fall back to the global atomic, per corner.
+template <int R>
+__global__ __launch_bounds__(256) void dcn_bwd_coord_tile_kernel(const float *__restrict__ x, const float *__restrict__ offset,
+                                                                 const float *__restrict__ mask, float *__restrict__ dcol,
+                                                                 float *__restrict__ dx, float *__restrict__ doffset,
+                                                                 float *__restrict__ dmask, const DcnShape s, int tiles_x) {
+  constexpr int TH = 8, TW = 32, LH = TH + 2 + 2 * R, LW = TW + 2 + 2 * R, LWP = LW + 1, MAXC = 16, K = 9;
+  __shared__ float win[MAXC * LH * LWP];
+  const int tid = threadIdx.x;
+  int tile, g, b;
+  xcd_block_index(tile, g, b);  // neighbouring tiles (overlapping windows, shared x lines) on one XCD
+  const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
+  const int wy0 = ty0 - 1 - R, wx0 = tx0 - 1 - R;  // image coordinates of window element (0, 0)
+  const int P = s.Ho * s.Wo, cpg = s.C / s.dg;
+  for (int i = tid; i < MAXC * LH * LWP; i += 256) win[i] = 0.f;
+  __syncthreads();
+
+  const int ho = ty0 + (tid >> 5), wo = tx0 + (tid & 31);
+  const bool live = ho < s.Ho && wo < s.Wo;
+  const int p = live ? ho * s.Wo + wo : 0;
+  const int64_t plane = (int64_t)s.H * s.W;
+  const float *xg = x + ((int64_t)b * s.C + (int64_t)g * cpg) * plane;
+  float *gg = dx + ((int64_t)b * s.C + (int64_t)g * cpg) * plane;
+  if (live) {
+    for (int k = 0; k < K; ++k) {
+      const int i = k / 3, j = k - 3 * i;
+      const float *off_b = offset + (int64_t)b * s.off_bs + (int64_t)(g * 2 * K + 2 * k) * P + p;
+      const float dy = off_b[0], dxo = off_b[P];
+      const float m = mask[(int64_t)b * s.msk_bs + (int64_t)(g * K + k) * P + p];
+      const Tap t = resolve_tap((float)(ho - 1 + i) + dy, (float)(wo - 1 + j) + dxo, s.H, s.W);
+      const float hh = 1.f - t.lh, hw = 1.f - t.lw;
+      const bool ok00 = t.ok00, ok01 = t.ok01, ok10 = t.ok10, ok11 = t.ok11;
+      const float gy00 = ok00 ? -hw : 0.f, gy01 = ok01 ? -t.lw : 0.f, gy10 = ok10 ? hw : 0.f, gy11 = ok11 ? t.lw : 0.f;
+      const float gx00 = ok00 ? -hh : 0.f, gx01 = ok01 ? hh : 0.f, gx10 = ok10 ? -t.lh : 0.f, gx11 = ok11 ? t.lh : 0.f;
+      const int ly = t.h0 - wy0, lx = t.w0 - wx0;
+      const bool inwin = ly >= 0 && ly + 1 < LH && lx >= 0 && lx + 1 < LW;
+      float *w00 = win + ly * LWP + lx;  // only dereferenced when inwin
+      const float *xp = xg;
+      float *gp = gg;
+      float *cp = dcol + ((int64_t)b * s.C * K + (int64_t)(g * cpg) * K + k) * P + p;
+      float s_m = 0.f, s_y = 0.f, s_x = 0.f;
+      // Channels in batches of 4 with all loads first: the column is rewritten in place, so the compiler cannot hoist the
+      // loads of channel c+1 above the store of channel c and every iteration paid a full dependent memory round trip.
+      for (int cc0 = 0; cc0 < cpg; cc0 += 4) {
+        float dc[4], a00[4], a01[4], a10[4], a11[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int cu = cc0 + u < cpg ? u : 0;  // (cpg is a multiple of 4 for every EDVR layer; clamp keeps the loads in range)
+          dc[u] = cp[(int64_t)cu * K * P];
+          a00[u] = xp[cu * plane + t.o00];
+          a01[u] = xp[cu * plane + t.o01];
+          a10[u] = xp[cu * plane + t.o10];
+          a11[u] = xp[cu * plane + t.o11];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (cc0 + u < cpg) {
+            const float val = t.w00 * a00[u] + t.w01 * a01[u] + t.w10 * a10[u] + t.w11 * a11[u];
+            s_m += dc[u] * val;
+            s_y += dc[u] * (gy00 * a00[u] + gy01 * a01[u] + gy10 * a10[u] + gy11 * a11[u]);
+            s_x += dc[u] * (gx00 * a00[u] + gx01 * a01[u] + gx10 * a10[u] + gx11 * a11[u]);
+            const float tt = dc[u] * m;
+#ifdef DCNB_EXP_NOLDSATOM
+            if (tt == 12345.f) {  /* ablation only */
+#else
+            if (inwin) {
+#endif
+              float *wc = w00 + (cc0 + u) * (LH * LWP);
+              if (ok00) atomicAdd(wc, t.w00 * tt);  // LDS: ds_add_f32
+              if (ok01) atomicAdd(wc + 1, t.w01 * tt);
+              if (ok10) atomicAdd(wc + LWP, t.w10 * tt);
+              if (ok11) atomicAdd(wc + LWP + 1, t.w11 * tt);
+#ifdef DCNB_EXP_NOLDSATOM
+            } else if (!inwin) {
+#else
+            } else {
+#endif
+              float *gq = gp + u * plane;
+              if (ok00) unsafeAtomicAdd(gq + t.o00, t.w00 * tt);
+              if (ok01) unsafeAtomicAdd(gq + t.o01, t.w01 * tt);
+              if (ok10) unsafeAtomicAdd(gq + t.o10, t.w10 * tt);
+              if (ok11) unsafeAtomicAdd(gq + t.o11, t.w11 * tt);
+            }
+#ifdef DCNB_EXP_NOCOLWRITE
+            if (val == 12345.f)  /* ablation only */
+#endif
+            cp[(int64_t)u * K * P] = val * m;  // forward column, consumed by the dW GEMM
+          }
+        }
+        xp += 4 * plane;
+        gp += 4 * plane;
+        cp += (int64_t)4 * K * P;
+      }
+      dmask[(int64_t)b * s.dmsk_bs + (int64_t)(g * K + k) * P + p] = s_m;
+      float *dob = doffset + (int64_t)b * s.doff_bs + (int64_t)(g * 2 * K + 2 * k) * P + p;
+      dob[0] = s_y * m;
+      dob[P] = s_x * m;
+    }
+  }
+  __syncthreads();
+  // flush the window: one global atomic per touched element inside the image
+  for (int i = tid; i < cpg * LH * LW; i += 256) {
+    const int cc = i / (LH * LW), rem = i - cc * (LH * LW), ly = rem / LW, lx = rem - ly * LW;
+    const float v = win[cc * (LH * LWP) + ly * LWP + lx];
+    const int gy = wy0 + ly, gx = wx0 + lx;
+#ifdef DCNB_EXP_NOFLUSH
+    if (v == 12345.f)  /* ablation only */
+#endif
+    if (v != 0.f && gy >= 0 && gy < s.H && gx >= 0 && gx < s.W) unsafeAtomicAdd(gg + (int64_t)cc * plane + gy * s.W + gx, v);
   }
 }
 
@@ -410,7 +532,8 @@ int edvr_dcnv2_fwd_f32(const float *x, const float *offset, const float *mask, c
 int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, const float *weight, const float *dy, float *dx,
                        float *doffset, float *dmask, float *dweight, float *dbias, int B, int C, int H, int W, int Co, int kh,
                        int kw, int stride, int pad, int dil, int groups, int dg, int64_t offset_bstride, int64_t mask_bstride,
-                       int64_t doffset_bstride, int64_t dmask_bstride, void *ws, size_t ws_bytes, edvr_stream_t stream_) {
+                       int64_t doffset_bstride, int64_t dmask_bstride, int scatter_hint, void *ws, size_t ws_bytes,
+                       edvr_stream_t stream_) {
   using namespace edvr;
   EDVR_REQUIRE(x && offset && mask && weight && dy && dx && doffset && dmask && dweight, "dcnv2_bwd: null pointer");
   DcnShape s;
@@ -467,10 +590,22 @@ int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, c
     set_error("dcnv2_bwd: hipMemsetAsync failed");
     return EDVR_ERR_LAUNCH;
   }
-  const int64_t total = (int64_t)B * dg * K * P;
-  hipLaunchKernelGGL(dcn_bwd_coord_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 1 << 20)), dim3(256), 0, stream, x,
-                     offset, mask, col, dx, doffset, dmask, s);
-  rc = check_launch("dcn_bwd_coord_kernel");
+  static const bool use_tile = []() {
+    const char *e = getenv("EDVR_DCN_BWD_TILE");  // "0": never use the LDS-window kernel (A/B)
+    return !(e && e[0] == '0');
+  }();
+  if (use_tile && scatter_hint != EDVR_DCN_SCATTER_DEVICE && kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1 &&
+      C / dg <= 16) {
+    const int tiles_x = cdiv(s.Wo, 32), tiles_y = cdiv(s.Ho, 8);
+    hipLaunchKernelGGL((dcn_bwd_coord_tile_kernel<3>), dim3(tiles_x * tiles_y, dg, B), dim3(256), 0, stream, x, offset, mask, col, dx,
+                       doffset, dmask, s, tiles_x);
+    rc = check_launch("dcn_bwd_coord_tile_kernel");
+  } else {
+    const int64_t total = (int64_t)B * dg * K * P;
+    hipLaunchKernelGGL(dcn_bwd_coord_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 1 << 20)), dim3(256), 0, stream, x,
+                       offset, mask, col, dx, doffset, dmask, s);
+    rc = check_launch("dcn_bwd_coord_kernel");
+  }
   if (rc) return rc;
   // 3. dW[g] = sum_{b,p} dY[b, g] col[b, g]^T ; db = sum dY
   for (int g = 0; g < groups; ++g) {

@@ -95,6 +95,7 @@ def pack_conv_weight(weight, transpose_flip=False):
 
 
 # ------------------------------------------------------------------------------------------------ conv
+DCN_SCATTER_AUTO, DCN_SCATTER_DEVICE, DCN_SCATTER_LDS = 0, 1, 2  # include/edvr_amd.h EDVR_DCN_SCATTER_*
 LAUNCH_HOOK = None  # callable(kernel_name, algorithmic_flops, launch_fn, algorithmic_bytes) or None
 CONV_ALGO = CONV_AUTO  # default algorithm request of conv2d(); tests flip it to cover both kernels on every shape
 
@@ -192,7 +193,8 @@ def dcnv2_forward(x, offset, mask, weight, bias, stride, pad, dil, groups, dg, a
     return y
 
 
-def dcnv2_backward(x, offset, mask, weight, dy, with_bias, stride, pad, dil, groups, dg, doffset=None, dmask=None):
+def dcnv2_backward(x, offset, mask, weight, dy, with_bias, stride, pad, dil, groups, dg, doffset=None, dmask=None,
+                   scatter_hint=0):
     """Returns (dx, doffset, dmask, dweight, dbias).  `doffset` / `dmask` may be preallocated channel slices of one
     buffer (image-strided views): the kernels write them in place."""
     require_gpu(x, offset, mask, weight, dy)
@@ -210,7 +212,7 @@ def dcnv2_backward(x, offset, mask, weight, dy, with_bias, stride, pad, dil, gro
     ws = workspace(nbytes, x.device)
     _lib.check(L.edvr_dcnv2_bwd_f32(_ptr(x), _ptr(offset), _ptr(mask), _ptr(weight), _ptr(dy), _ptr(dx), _ptr(doff), _ptr(dmsk),
                                     _ptr(dw), _ptr(db), *dims, _bstride(offset), _bstride(mask), _bstride(doff), _bstride(dmsk),
-                                    _ptr(ws), nbytes, _stream()), 'edvr_dcnv2_bwd_f32')
+                                    int(scatter_hint), _ptr(ws), nbytes, _stream()), 'edvr_dcnv2_bwd_f32')
     return dx, doff, dmsk, dw, db
 
 

@@ -60,6 +60,9 @@ int edvr_check_device(void);
 #define EDVR_ACT_LRELU 2 /* negative slope 0.1 (edvr_arch.py:70,157,248,356) */
 #define EDVR_ACT_SIGMOID 3
 
+#define EDVR_DCN_SCATTER_AUTO 0
+#define EDVR_DCN_SCATTER_DEVICE 1
+#define EDVR_DCN_SCATTER_LDS 2
 #define EDVR_CONV_AUTO 0
 #define EDVR_CONV_DIRECT 1
 #define EDVR_CONV_WINOGRAD 2
@@ -132,8 +135,16 @@ int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, c
                        float *dx, float *doffset, float *dmask, float *dweight, float *dbias, int B, int C, int H,
                        int W, int Co, int kh, int kw, int stride, int pad, int dil, int groups, int dg,
                        int64_t offset_bstride, int64_t mask_bstride, int64_t doffset_bstride, int64_t dmask_bstride,
-                       void *ws, size_t ws_bytes, edvr_stream_t stream);
-/* doffset_bstride / dmask_bstride (0 = contiguous): image strides of the two gradient outputs, so both can be
+                       int scatter_hint, void *ws, size_t ws_bytes, edvr_stream_t stream);
+/* scatter_hint (performance only, like halo_hint of the forward; results are the same up to the summation order of dx):
+ * how the four corner contributions per (pixel, tap, channel) are accumulated into dx.
+ *   EDVR_DCN_SCATTER_DEVICE (1): fp32 device atomics straight to dx, as the reference's col2im (.cu:688).  Fastest when the
+ *       offset field is smooth (neighbouring pixels hit neighbouring addresses: 6 ms on the EDVR-L training layer), collapses
+ *       when it is not (89 ms with white-noise offsets of 1 px).
+ *   EDVR_DCN_SCATTER_LDS (2): per-tile LDS window (ds_add_f32) flushed with one device atomic per touched element: 7 ms /
+ *       14 ms on the same two cases.  3x3, stride 1, pad 1, dil 1, <= 16 channels per deformable group; else DEVICE is used.
+ *   EDVR_DCN_SCATTER_AUTO (0): LDS where applicable.
+ * doffset_bstride / dmask_bstride (0 = contiguous): image strides of the two gradient outputs, so both can be
  * written straight into channel slices of one (B, 3*dg*K, Ho, Wo) buffer = the gradient of conv_offset's output. */
 
 /* ------------------------------------------------------------------ TSA / PCD glue kernels (HBM-bound) */

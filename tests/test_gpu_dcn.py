@@ -43,8 +43,9 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize('scatter', ['lds', 'device'])  # the two dx accumulation strategies of the backward (EDVR_DCN_SCATTER_*)
 @pytest.mark.parametrize('case', CASES)
-def test_dcnv2_forward_backward_vs_oracle(gpu, case):
+def test_dcnv2_forward_backward_vs_oracle(gpu, case, scatter):
     from edvr_amd import ops
     from oracle import dcn_oracle as O
     *dims, kw = case
@@ -55,7 +56,8 @@ def test_dcnv2_forward_backward_vs_oracle(gpu, case):
     ref_g = O.c_backward(x.double(), off.double(), m.double(), w.double(), dy.double(), True, *cfg)
     xg, og, mg, wg, bg, dyg = (t.to(gpu) for t in (x, off, m, w, b, dy))
     y = ops.dcnv2_forward(xg, og, mg, wg, bg, *cfg)
-    grads = ops.dcnv2_backward(xg, og, mg, wg, dyg, True, *cfg)
+    grads = ops.dcnv2_backward(xg, og, mg, wg, dyg, True, *cfg,
+                               scatter_hint={'lds': ops.DCN_SCATTER_LDS, 'device': ops.DCN_SCATTER_DEVICE}[scatter])
     torch.cuda.synchronize()
     assert _rel(y, ref_y) < FWD_RTOL
     for name, a, r in zip(('dx', 'doffset', 'dmask', 'dweight', 'dbias'), grads, ref_g):
