@@ -75,6 +75,32 @@ __device__ __forceinline__ Tap resolve_tap(float h, float w, int H, int W) {
   return t;
 }
 
+// Neighbour exchange inside a wave (DPP wave shifts, no LDS): lane i reads lane i+1 / lane i-1; lanes without a neighbour get 0.
+__device__ __forceinline__ int lane_next_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false); }
+__device__ __forceinline__ int lane_prev_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
+__device__ __forceinline__ float lane_prev_f(float v) { return __int_as_float(lane_prev_i(__float_as_int(v))); }
+
+// In a smooth offset field the right-hand corners (01, 11) of pixel p are the left-hand corners (00, 10) of pixel p+1,
+// i.e. of the next lane.  merge_right() decides, once per (pixel, tap), whether this lane hands its 01 / 11 contributions
+// to the next lane (which adds them to its own 00 / 10 before its atomic): half the atomics where the field is smooth.
+struct Merge {
+  bool give01, give11;  // this lane's 01 / 11 go to lane+1
+  bool take00, take10;  // lane-1 gives its 01 / 11 to this lane's 00 / 10
+};
+__device__ __forceinline__ Merge merge_right(const Tap &t, bool same_plane_as_next) {
+  Merge mg;
+  const int lane = __lane_id();
+  const int n_o00 = lane_next_i(t.o00), n_o10 = lane_next_i(t.o10);
+  const int n_ok = lane_next_i((t.ok00 ? 1 : 0) | (t.ok10 ? 2 : 0));
+  const bool has_next = lane < 63 && same_plane_as_next;
+  mg.give01 = has_next && t.ok01 && (n_ok & 1) && n_o00 == t.o01;
+  mg.give11 = has_next && t.ok11 && (n_ok & 2) && n_o10 == t.o11;
+  const int p_give = lane_prev_i((mg.give01 ? 1 : 0) | (mg.give11 ? 2 : 0));
+  mg.take00 = (p_give & 1) != 0;
+  mg.take10 = (p_give & 2) != 0;
+  return mg;
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward gather: col[img, c*K + k, p] = mask * bilinear(x[img, c], p + tap + offset)
 __global__ __launch_bounds__(256) void dcn_im2col_kernel(const float *__restrict__ x, const float *__restrict__ offset,
@@ -137,6 +163,9 @@ __global__ __launch_bounds__(256) void dcn_bwd_coord_kernel(const float *__restr
     float *gp = dx + ((int64_t)b * s.C + (int64_t)g * cpg) * plane;
     float *cp = dcol + ((int64_t)b * s.C * K + (int64_t)(g * cpg) * K + k) * P + p;
     float s_m = 0.f, s_y = 0.f, s_x = 0.f;
+    // lane+1 is pixel p+1 of the same (image, group, tap) unless this lane is the last pixel of the plane
+    // (all 64 lanes of a wave are live here or the wave is the grid's tail: idx + 1 < total covers it)
+    const Merge mg = merge_right(t, p + 1 < P && idx + 1 < total);
     for (int cc = 0; cc < cpg; ++cc) {
       const float dc = *cp;
       const float a00 = xp[t.o00], a01 = xp[t.o01], a10 = xp[t.o10], a11 = xp[t.o11];
@@ -145,10 +174,13 @@ __global__ __launch_bounds__(256) void dcn_bwd_coord_kernel(const float *__restr
       s_y += dc * (gy00 * a00 + gy01 * a01 + gy10 * a10 + gy11 * a11);
       s_x += dc * (gx00 * a00 + gx01 * a01 + gx10 * a10 + gx11 * a11);
       const float tt = dc * m;
-      if (ok00) unsafeAtomicAdd(gp + t.o00, t.w00 * tt);
-      if (ok01) unsafeAtomicAdd(gp + t.o01, t.w01 * tt);
-      if (ok10) unsafeAtomicAdd(gp + t.o10, t.w10 * tt);
-      if (ok11) unsafeAtomicAdd(gp + t.o11, t.w11 * tt);
+      const float v01 = t.w01 * tt, v11 = t.w11 * tt;
+      const float l01 = lane_prev_f(v01), l11 = lane_prev_f(v11);  // uniform control flow: every lane executes the shifts
+      const float v00 = t.w00 * tt + (mg.take00 ? l01 : 0.f), v10 = t.w10 * tt + (mg.take10 ? l11 : 0.f);
+      if (ok00 || mg.take00) unsafeAtomicAdd(gp + t.o00, v00);
+      if (ok01 && !mg.give01) unsafeAtomicAdd(gp + t.o01, v01);
+      if (ok10 || mg.take10) unsafeAtomicAdd(gp + t.o10, v10);
+      if (ok11 && !mg.give11) unsafeAtomicAdd(gp + t.o11, v11);
       *cp = val * m;  // forward column, consumed by the dW GEMM
       xp += plane;
       gp += plane;
@@ -209,6 +241,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_coord_tile_kernel(const float *__
       float *gp = gg;
       float *cp = dcol + ((int64_t)b * s.C * K + (int64_t)(g * cpg) * K + k) * P + p;
       float s_m = 0.f, s_y = 0.f, s_x = 0.f;
+      const Merge mg = merge_right(t, true);  // lane+1 = next pixel of the row (addresses only match inside one plane)
       // Channels in batches of 4 with all loads first: the column is rewritten in place, so the compiler cannot hoist the
       // loads of channel c+1 above the store of channel c and every iteration paid a full dependent memory round trip.
       for (int cc0 = 0; cc0 < cpg; cc0 += 4) {
@@ -230,26 +263,29 @@ __global__ __launch_bounds__(256) void dcn_bwd_coord_tile_kernel(const float *__
             s_y += dc[u] * (gy00 * a00[u] + gy01 * a01[u] + gy10 * a10[u] + gy11 * a11[u]);
             s_x += dc[u] * (gx00 * a00[u] + gx01 * a01[u] + gx10 * a10[u] + gx11 * a11[u]);
             const float tt = dc[u] * m;
+            const float v01 = t.w01 * tt, v11 = t.w11 * tt;
+            const float l01 = lane_prev_f(v01), l11 = lane_prev_f(v11);
+            const float v00 = t.w00 * tt + (mg.take00 ? l01 : 0.f), v10 = t.w10 * tt + (mg.take10 ? l11 : 0.f);
 #ifdef DCNB_EXP_NOLDSATOM
             if (tt == 12345.f) {  /* ablation only */
 #else
             if (inwin) {
 #endif
               float *wc = w00 + (cc0 + u) * (LH * LWP);
-              if (ok00) atomicAdd(wc, t.w00 * tt);  // LDS: ds_add_f32
-              if (ok01) atomicAdd(wc + 1, t.w01 * tt);
-              if (ok10) atomicAdd(wc + LWP, t.w10 * tt);
-              if (ok11) atomicAdd(wc + LWP + 1, t.w11 * tt);
+              if (ok00) atomicAdd(wc, v00);  // LDS: ds_add_f32
+              if (ok01 && !mg.give01) atomicAdd(wc + 1, v01);
+              if (ok10) atomicAdd(wc + LWP, v10);
+              if (ok11 && !mg.give11) atomicAdd(wc + LWP + 1, v11);
 #ifdef DCNB_EXP_NOLDSATOM
             } else if (!inwin) {
 #else
             } else {
 #endif
               float *gq = gp + u * plane;
-              if (ok00) unsafeAtomicAdd(gq + t.o00, t.w00 * tt);
-              if (ok01) unsafeAtomicAdd(gq + t.o01, t.w01 * tt);
-              if (ok10) unsafeAtomicAdd(gq + t.o10, t.w10 * tt);
-              if (ok11) unsafeAtomicAdd(gq + t.o11, t.w11 * tt);
+              if (ok00) unsafeAtomicAdd(gq + t.o00, v00);
+              if (ok01 && !mg.give01) unsafeAtomicAdd(gq + t.o01, v01);
+              if (ok10) unsafeAtomicAdd(gq + t.o10, v10);
+              if (ok11 && !mg.give11) unsafeAtomicAdd(gq + t.o11, v11);
             }
 #ifdef DCNB_EXP_NOCOLWRITE
             if (val == 12345.f)  /* ablation only */
