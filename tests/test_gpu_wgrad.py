@@ -49,3 +49,16 @@ def test_wgrad_algo_setter_rejects_unknown(gpu):
     with pytest.raises(Exception):
         ops.set_wgrad_algo(17)
     assert ops.set_wgrad_algo(ops.CONV_AUTO) == ops.CONV_AUTO
+
+
+@pytest.mark.parametrize('shape', [(32, 128, 64, 64), (5, 128, 16, 16), (3, 216, 12, 20), (2, 64, 9, 7), (160, 128, 64, 64), (2, 3, 40, 40)])
+def test_channel_sum_bias_gradient(gpu, shape):
+    """db = sum over (n, h, w): single-stage kernel (aligned, <= 1M elements per channel) and the two-stage one."""
+    from edvr_amd import ops
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(shape[1]))
+    ref = x.double().sum((0, 2, 3))
+    got = ops.channel_sum(x.to(gpu)).cpu().double()
+    assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()) + 1e-3 * (shape[0] * shape[2] * shape[3]) ** 0.5 * 1e-3
+    sl = x.to(gpu)[:, 1:shape[1] - 1] if shape[1] > 8 else None  # channel-sliced view: image stride != c * hw
+    if sl is not None:
+        assert torch.allclose(ops.channel_sum(sl).cpu().double(), ref[1:-1], rtol=0, atol=2e-5 * max(1.0, ref.abs().max().item()) + 1e-4)
