@@ -122,17 +122,27 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
   float pr[16];   // raw patch (channel chl, tile t) of the chunk being staged
   float tt[16];   // B^T d
   f32x2 dy[2][2]; // [chunk parity][row] 2x2 output-gradient tile of (channel chl, tile t)
+  // Column c of the patch for chunk q (the geometry() state).  Columns 1 and 2 of a row are an 8-byte aligned pair (even x,
+  // even w and h), both valid or both invalid: one 64-bit load, issued once both columns have been consumed (c == 2).
   auto load_col = [&](int c) {
+    if (c == 1) return;
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < 4; ++r) {
 #ifdef WW_EXP_NOLOAD
+      if (c == 2) pr[r * 4 + 1] = (rowok[r] && colok[1]) ? 1.f : 0.f;
       pr[r * 4 + c] = (rowok[r] && colok[c]) ? 1.f : 0.f;  /* ablation only */
-#elif defined(WW_EXP_ONEADDR)
-      pr[r * 4 + c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (rowok[r] && colok[c]) ? 64 : OOB, 0, 0));
 #else
-      pr[r * 4 + c] = __builtin_bit_cast(
-          float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (rowok[r] && colok[c]) ? rel[r * 4 + c] : OOB, 0, 0));
+      if (c == 2) {
+        const f32x2 v = __builtin_bit_cast(
+            f32x2, __builtin_amdgcn_raw_buffer_load_b64(x_rsrc, (rowok[r] && colok[1]) ? rel[r * 4 + 1] : OOB, 0, 0));
+        pr[r * 4 + 1] = v[0];
+        pr[r * 4 + 2] = v[1];
+      } else {
+        pr[r * 4 + c] = __builtin_bit_cast(
+            float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (rowok[r] && colok[c]) ? rel[r * 4 + c] : OOB, 0, 0));
+      }
 #endif
+    }
   };
   auto load_dy = [&](auto SET) {
     constexpr int S = decltype(SET)::value;
