@@ -47,6 +47,9 @@ __device__ __forceinline__ void mfma_acc(f32x16 &acc, float a, float b) {
   acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
 }
 
+// PAIR: even image width and 8-byte aligned planes - columns 1 and 2 of every patch row are then an aligned pair, valid or
+// padded together, and come from ONE 64-bit load (12 instead of 16 gathers per chunk and thread).
+template <bool PAIR>
 __global__ __launch_bounds__(512, 1) void conv3x3_winograd_kernel(const WinoArgs a) {
   constexpr int CK = 8, TY = 4, TX = 16;  // 64 tiles = 8 x 32 output pixels
   constexpr int SLAB = CK * 16 * 64;      // floats per LDS slab (U or V)
@@ -121,9 +124,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_kernel(const WinoArgs
     ld_u_soff = (c0 * 16 * a.cop + co_blk) * 4;
   };
   auto load_col = [&](int c) {
+    if (PAIR && c == 1) return;  // loaded together with column 2, once both have been consumed
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      pr[r * 4 + c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ld_rsrc, p_off[r * 4 + c], 0, 0));
+    for (int r = 0; r < 4; ++r) {
+      if (PAIR && c == 2) {
+        const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(ld_rsrc, p_off[r * 4 + 1], 0, 0));
+        pr[r * 4 + 1] = v[0];
+        pr[r * 4 + 2] = v[1];
+      } else {
+        pr[r * 4 + c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ld_rsrc, p_off[r * 4 + c], 0, 0));
+      }
+    }
   };
   auto load_u = [&](int g) {
     ur[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_voff, ld_u_soff + g * 32 * a.cop * 4, 0));
@@ -506,7 +517,10 @@ int winograd_launch(const edvr_conv2d_desc &d, const float *U, int cop, hipStrea
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
     return n;
   }();
-  hipLaunchKernelGGL(conv3x3_winograd_kernel, dim3(std::min(a.items, n_cu)), dim3(512), 0, stream, a);
+  auto aligned8 = [](const float *p, int64_t img_stride) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0 && (img_stride & 1) == 0; };
+  const bool pair = (d.w & 1) == 0 && aligned8(d.x1, d.x1_img_stride) && (!d.x2 || aligned8(d.x2, d.x2_img_stride));
+  if (pair) hipLaunchKernelGGL(conv3x3_winograd_kernel<true>, dim3(std::min(a.items, n_cu)), dim3(512), 0, stream, a);
+  else hipLaunchKernelGGL(conv3x3_winograd_kernel<false>, dim3(std::min(a.items, n_cu)), dim3(512), 0, stream, a);
   return check_launch("conv3x3_winograd_kernel");
 }
 
