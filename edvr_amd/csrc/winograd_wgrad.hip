@@ -34,8 +34,8 @@ struct WinoWgradArgs {
 };
 
 __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const WinoWgradArgs a) {
-  constexpr int TS = 16 * 64 + 8;  // floats per tile in a slab: [tile][xi][channel], +8 so the 8 tiles x 8 channels a wave
-                                   // writes per instruction land in 64 different banks
+  constexpr int TS = 16 * 64 + 4;  // floats per tile in a slab: [tile][xi][channel], +4 so the 8 tiles x 4 channels a half-wave
+                                   // writes per pass land in 32 different banks (PMC: +8 left 25 % of the LDS cycles in conflicts)
   constexpr int SLAB = 8 * TS, SMEM = 4 * SLAB;  // (Z, V) x 2 stages = 132 KB
   constexpr int RSRC_FLAGS = 0x00020000;
   constexpr int OOB = (int)0x80000000;  // >= num_records: the load returns 0 without touching memory

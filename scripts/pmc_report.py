@@ -17,6 +17,6 @@ rep['_launches_per_counter'] = max(cnt.values()) if cnt else 0
 rep['_kernel'] = key
 if 'SQ_BUSY_CYCLES' in rep and 'SQ_VALU_MFMA_BUSY_CYCLES' in rep and 'GRBM_GUI_ACTIVE' in rep:
     # SQ_VALU_MFMA_BUSY_CYCLES is summed over SIMDs in units of 4 cycles... report the ratio the guide uses
-    rep['_mfma_busy_frac'] = rep['SQ_VALU_MFMA_BUSY_CYCLES'] / (rep['GRBM_GUI_ACTIVE'] * 256 * 4) * 4
+    rep['_mfma_busy_frac'] = rep["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * rep["GRBM_GUI_ACTIVE"] / 8)
 json.dump(rep, open(out, 'w'), indent=1)
 print(json.dumps(rep, indent=1))
