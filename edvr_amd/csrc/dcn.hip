@@ -658,9 +658,8 @@ int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, c
                          P, P, B, (int64_t)Co * P, (int64_t)C * K * P, false, gws, stream);
     if (rc) return rc;
   }
-  if (dbias) {
-    hipLaunchKernelGGL(row_sum_kernel, dim3(Co), dim3(256), 0, stream, dy, dbias, B, Co, P, (int64_t)Co * P);
-    rc = check_launch("row_sum_kernel");
+  if (dbias) {  // db = sum over (image, pixel) of dY: the conv layers' bias-gradient kernel (gws is free again here)
+    rc = edvr_channel_sum_f32(dy, dbias, B, Co, P, (int64_t)Co * P, gws, (size_t)64 * Co * sizeof(float), stream_);
     if (rc) return rc;
   }
   return EDVR_OK;

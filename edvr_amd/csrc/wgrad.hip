@@ -196,14 +196,30 @@ __global__ __launch_bounds__(512) void channel_sum_single_kernel(const float *__
                                                                  int64_t img_stride) {
   const int c = blockIdx.x;
   const int64_t hw4 = hw >> 2;  // hw % 4 == 0 (checked by the host)
-  float s = 0.f;
-  for (int b = 0; b < n; ++b) {
+  // four images per trip, independent accumulators: 4+ loads in flight per thread (one at a time ran at 0.33 TB/s)
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = 0;
+  for (; b + 3 < n; b += 4) {
+    const float4 *p0 = reinterpret_cast<const float4 *>(x + (int64_t)b * img_stride + (int64_t)c * hw);
+    const float4 *p1 = reinterpret_cast<const float4 *>(x + (int64_t)(b + 1) * img_stride + (int64_t)c * hw);
+    const float4 *p2 = reinterpret_cast<const float4 *>(x + (int64_t)(b + 2) * img_stride + (int64_t)c * hw);
+    const float4 *p3 = reinterpret_cast<const float4 *>(x + (int64_t)(b + 3) * img_stride + (int64_t)c * hw);
+    for (int64_t i = threadIdx.x; i < hw4; i += 512) {
+      const float4 v0 = p0[i], v1 = p1[i], v2 = p2[i], v3 = p3[i];
+      s0 += (v0.x + v0.y) + (v0.z + v0.w);
+      s1 += (v1.x + v1.y) + (v1.z + v1.w);
+      s2 += (v2.x + v2.y) + (v2.z + v2.w);
+      s3 += (v3.x + v3.y) + (v3.z + v3.w);
+    }
+  }
+  for (; b < n; ++b) {
     const float4 *p = reinterpret_cast<const float4 *>(x + (int64_t)b * img_stride + (int64_t)c * hw);
     for (int64_t i = threadIdx.x; i < hw4; i += 512) {
       const float4 v = p[i];
-      s += (v.x + v.y) + (v.z + v.w);
+      s0 += (v.x + v.y) + (v.z + v.w);
     }
   }
+  float s = (s0 + s1) + (s2 + s3);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
   __shared__ float red[8];
