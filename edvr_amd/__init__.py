@@ -10,8 +10,8 @@ NotImplementedError exactly like the reference op, and a missing library raises 
 """
 from ._lib import ExtensionMissing  # noqa: F401
 from .arch_util import DCNv2Pack, ResidualBlockNoBN, default_init_weights, make_layer  # noqa: F401
-from .dcn import (ModulatedDeformConv, ModulatedDeformConvFunction, ModulatedDeformConvPack,  # noqa: F401
-                  modulated_deform_conv)
+from .dcn import (DeformConv, DeformConvFunction, DeformConvPack, ModulatedDeformConv,  # noqa: F401
+                  ModulatedDeformConvFunction, ModulatedDeformConvPack, deform_conv, modulated_deform_conv)
 from .edvr_arch import EDVR, PCDAlignment, PredeblurModule, TSAFusion  # noqa: F401
 
 __version__ = '0.1.0'

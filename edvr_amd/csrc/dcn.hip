@@ -38,6 +38,10 @@ struct DcnShape {
   int64_t doff_bs, dmsk_bs;  // image strides of doffset / dmask (backward outputs)
 };
 
+__global__ void fill_kernel(float *__restrict__ p, float v, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
 struct Tap {
   float w00, w01, w10, w11;  // bilinear corner weights, 0 where the corner is outside the image
   int o00, o01, o10, o11;    // clamped element offsets inside one channel plane
@@ -451,7 +455,7 @@ static int fill_shape(DcnShape &s, int B, int C, int H, int W, int Co, int kh, i
   EDVR_REQUIRE(s.Ho > 0 && s.Wo > 0, "dcnv2: convolution input is too small (output would be %dx%d)", s.Ho, s.Wo);
   const int64_t P = (int64_t)s.Ho * s.Wo, K = kh * kw;
   s.off_bs = off_bs ? off_bs : (int64_t)dg * 2 * K * P;
-  s.msk_bs = msk_bs ? msk_bs : (int64_t)dg * K * P;
+  s.msk_bs = msk_bs < 0 ? 0 : (msk_bs ? msk_bs : (int64_t)dg * K * P);  // < 0: one mask plane set broadcast over the batch (DCNv1)
   s.doff_bs = (int64_t)dg * 2 * K * P;
   s.dmsk_bs = (int64_t)dg * K * P;
   return EDVR_OK;
@@ -576,7 +580,7 @@ int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, c
   int rc = fill_shape(s, B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, offset_bstride, mask_bstride);
   if (rc) return rc;
   if (doffset_bstride) s.doff_bs = doffset_bstride;
-  if (dmask_bstride) s.dmsk_bs = dmask_bstride;
+  if (dmask_bstride) s.dmsk_bs = dmask_bstride < 0 ? 0 : dmask_bstride;  // < 0: every image writes the same (discarded) planes
   const BwdWs wsz = bwd_ws(s);
   if (!ws || ws_bytes < wsz.total) {
     set_error("dcnv2_bwd: workspace %zu < required %zu", ws_bytes, wsz.total);
@@ -663,6 +667,68 @@ int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, c
     if (rc) return rc;
   }
   return EDVR_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------ DCNv1 (DeformConv)
+// deform_conv_forward / deform_conv_backward_input / deform_conv_backward_parameters of the reference
+// (deform_conv_ext.cpp:51-104, deform_conv_cuda.cpp:152-488): the same gather as DCNv2 without the modulation mask and without
+// bias (deformable_im2col, .cu:190-250, is modulated_deformable_im2col with mask = 1).  Runs the DCNv2 kernels on ONE
+// all-ones mask plane set that is broadcast over the batch (mask image stride 0); d(mask) lands in a scratch plane set.
+// The reference's im2col_step batching is a workspace-size knob of its column buffer and has no counterpart here.
+size_t edvr_dcnv1_fwd_ws_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil, int groups, int dg) {
+  edvr::DcnShape s;
+  if (edvr::fill_shape(s, B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, 0, 0)) return 0;
+  return edvr::fwd_ws(s).total + edvr::align_up((size_t)dg * kh * kw * s.Ho * s.Wo * 4, 256);
+}
+
+int edvr_dcnv1_fwd_f32(const float *x, const float *offset, const float *weight, float *y, int B, int C, int H, int W, int Co, int kh,
+                       int kw, int stride, int pad, int dil, int groups, int dg, int64_t offset_bstride, int halo_hint, void *ws,
+                       size_t ws_bytes, edvr_stream_t stream_) {
+  using namespace edvr;
+  const size_t v2 = edvr_dcnv2_fwd_ws_bytes(B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg);
+  const size_t need = edvr_dcnv1_fwd_ws_bytes(B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg);
+  EDVR_REQUIRE(v2 && need, "dcnv1: bad shape");
+  if (!ws || ws_bytes < need) {
+    set_error("dcnv1_fwd: workspace %zu < required %zu", ws_bytes, need);
+    return EDVR_ERR_WORKSPACE;
+  }
+  float *ones = reinterpret_cast<float *>(static_cast<char *>(ws) + v2);
+  const int64_t n1 = (int64_t)(need - v2) / 4;
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(n1, 256), 4096)), dim3(256), 0, as_stream(stream_), ones, 1.f, n1);
+  int rc = check_launch("fill_kernel");
+  if (rc) return rc;
+  return edvr_dcnv2_fwd_f32(x, offset, ones, weight, nullptr, y, B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, offset_bstride, -1,
+                            EDVR_ACT_NONE, halo_hint, ws, v2, stream_);
+}
+
+size_t edvr_dcnv1_bwd_ws_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil, int groups, int dg) {
+  edvr::DcnShape s;
+  if (edvr::fill_shape(s, B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, 0, 0)) return 0;
+  return edvr::bwd_ws(s).total + 2 * edvr::align_up((size_t)dg * kh * kw * s.Ho * s.Wo * 4, 256);
+}
+
+int edvr_dcnv1_bwd_f32(const float *x, const float *offset, const float *weight, const float *dy, float *dx, float *doffset,
+                       float *dweight, int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil, int groups,
+                       int dg, int64_t offset_bstride, int64_t doffset_bstride, int scatter_hint, void *ws, size_t ws_bytes,
+                       edvr_stream_t stream_) {
+  using namespace edvr;
+  const size_t v2 = edvr_dcnv2_bwd_ws_bytes(B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg);
+  const size_t need = edvr_dcnv1_bwd_ws_bytes(B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg);
+  EDVR_REQUIRE(v2 && need, "dcnv1: bad shape");
+  if (!ws || ws_bytes < need) {
+    set_error("dcnv1_bwd: workspace %zu < required %zu", ws_bytes, need);
+    return EDVR_ERR_WORKSPACE;
+  }
+  const size_t plane = (need - v2) / 2;
+  float *ones = reinterpret_cast<float *>(static_cast<char *>(ws) + v2);
+  float *dmask_scratch = reinterpret_cast<float *>(static_cast<char *>(ws) + v2 + plane);
+  const int64_t n1 = (int64_t)plane / 4;
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(n1, 256), 4096)), dim3(256), 0, as_stream(stream_), ones, 1.f, n1);
+  int rc = check_launch("fill_kernel");
+  if (rc) return rc;
+  return edvr_dcnv2_bwd_f32(x, offset, ones, weight, dy, dx, doffset, dmask_scratch, dweight, nullptr, B, C, H, W, Co, kh, kw, stride, pad,
+                            dil, groups, dg, offset_bstride, -1, doffset_bstride, -1, scatter_hint, ws, v2, stream_);
 }
 
 }  // extern "C"

@@ -5,6 +5,7 @@ Mirrors basicsr/models/ops/dcn/deform_conv.py of xinntao/EDVR:
   modulated_deform_conv       (:185)      -> modulated_deform_conv
   ModulatedDeformConv         (:295-342)  -> ModulatedDeformConv
   ModulatedDeformConvPack     (:345-390)  -> ModulatedDeformConvPack
+  DeformConvFunction / deform_conv / DeformConv / DeformConvPack (:12-108,183,188-292: DCNv1)
 Same constructor arguments, attributes, parameter names/shapes/init, `_version = 2`,
 and the same refusal of CPU tensors (NotImplementedError, :133-134,151-152).  The native
 side is edvr_dcnv2_{fwd,bwd}_f32 of libedvr_amd.so instead of the deform_conv_ext module.
@@ -103,3 +104,112 @@ class ModulatedDeformConvPack(ModulatedDeformConv):
     def forward(self, x):
         from . import functional as F_
         return F_.dcn_from_packed(self, x, F_.offset_mask_conv(self.conv_offset, x))
+
+
+# ------------------------------------------------------------------------------------------------ DCNv1
+class DeformConvFunction(Function):
+    """deform_conv.py:12-108.  `im2col_step` only sizes the reference's column buffer; it is accepted, checked the same way
+    (must divide the batch) and otherwise unused."""
+
+    @staticmethod
+    def forward(ctx, input, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1, im2col_step=64):
+        if input is not None and input.dim() != 4:
+            raise ValueError(f'Expected 4D tensor as input, got {input.dim()}D tensor instead.')
+        stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
+        if stride[0] != stride[1] or padding[0] != padding[1] or dilation[0] != dilation[1]:
+            raise NotImplementedError('edvr_amd DeformConv: square stride / padding / dilation only')
+        if not input.is_cuda:
+            raise NotImplementedError
+        cur = min(im2col_step, input.shape[0])
+        assert (input.shape[0] % cur) == 0, 'im2col step must divide batchsize'
+        DeformConvFunction._output_size(input, weight, padding, dilation, stride)  # raises like the reference if too small
+        ctx.cfg = (stride[0], padding[0], dilation[0], groups, deformable_groups)
+        ctx.save_for_backward(input, offset, weight)
+        return ops.dcnv1_forward(input.contiguous(), offset, weight.contiguous(), *ctx.cfg)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        input, offset, weight = ctx.saved_tensors
+        if not grad_output.is_cuda:
+            raise NotImplementedError
+        dx, doff, dw = ops.dcnv1_backward(input.contiguous(), offset, weight.contiguous(), grad_output, *ctx.cfg)
+        return dx, doff, dw, None, None, None, None, None, None
+
+    @staticmethod
+    def _output_size(input, weight, padding, dilation, stride):
+        channels = weight.size(0)
+        output_size = (input.size(0), channels)
+        for d in range(input.dim() - 2):
+            in_size = input.size(d + 2)
+            pad = padding[d]
+            kernel = dilation[d] * (weight.size(d + 2) - 1) + 1
+            stride_ = stride[d]
+            output_size += ((in_size + (2 * pad) - kernel) // stride_ + 1, )
+        if not all(map(lambda s: s > 0, output_size)):
+            raise ValueError('convolution input is too small (output would be ' f'{"x".join(map(str, output_size))})')
+        return output_size
+
+
+deform_conv = DeformConvFunction.apply
+
+
+class DeformConv(nn.Module):
+    """deform_conv.py:188-250."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1,
+                 bias=False):
+        super().__init__()
+        assert not bias
+        assert in_channels % groups == 0, f'in_channels {in_channels} is not divisible by groups {groups}'
+        assert out_channels % groups == 0, f'out_channels {out_channels} is not divisible by groups {groups}'
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = _pair(kernel_size)
+        self.stride, self.padding, self.dilation = _pair(stride), _pair(padding), _pair(dilation)
+        self.groups, self.deformable_groups = groups, deformable_groups
+        self.transposed = False  # enable compatibility with nn.Conv2d
+        self.output_padding = _single(0)
+        self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // self.groups, *self.kernel_size))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        n = self.in_channels
+        for k in self.kernel_size:
+            n *= k
+        stdv = 1. / math.sqrt(n)
+        self.weight.data.uniform_(-stdv, stdv)
+
+    def forward(self, x, offset):
+        # the reference pads inputs smaller than the kernel (deform_conv.py:234-250); same shim, same crop
+        input_pad = (x.size(2) < self.kernel_size[0] or x.size(3) < self.kernel_size[1])
+        if input_pad:
+            pad_h = max(self.kernel_size[0] - x.size(2), 0)
+            pad_w = max(self.kernel_size[1] - x.size(3), 0)
+            x = torch.nn.functional.pad(x, (0, pad_w, 0, pad_h), 'constant', 0).contiguous()
+            offset = torch.nn.functional.pad(offset, (0, pad_w, 0, pad_h), 'constant', 0).contiguous()
+        out = deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups, self.deformable_groups)
+        if input_pad:
+            out = out[:, :, :out.size(2) - pad_h, :out.size(3) - pad_w].contiguous()
+        return out
+
+
+class DeformConvPack(DeformConv):
+    """deform_conv.py:253-292: conv_offset (zero-initialised, nn.Conv2d with the same geometry) predicts the offsets."""
+
+    _version = 2
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.conv_offset = nn.Conv2d(self.in_channels, self.deformable_groups * 2 * self.kernel_size[0] * self.kernel_size[1],
+                                     kernel_size=self.kernel_size, stride=_pair(self.stride), padding=_pair(self.padding),
+                                     dilation=_pair(self.dilation), bias=True)
+        self.init_offset()
+
+    def init_offset(self):
+        self.conv_offset.weight.data.zero_()
+        self.conv_offset.bias.data.zero_()
+
+    def forward(self, x):
+        from . import functional as F_
+        offset = F_.conv(self.conv_offset, x)  # the fused conv kernel: 3x3 (stride 1/2, pad 1) or 1x1 geometries
+        return deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups, self.deformable_groups)

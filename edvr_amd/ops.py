@@ -157,6 +157,40 @@ def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NON
     return out
 
 
+# ------------------------------------------------------------------------------------------------ DCNv1
+def dcnv1_forward(x, offset, weight, stride, pad, dil, groups, dg, halo_hint=0):
+    """DeformConv forward (no mask, no bias): edvr_dcnv1_fwd_f32."""
+    require_gpu(x, offset, weight)
+    L = _lib.lib()
+    offset = _as_planes(offset)
+    dims = _dcn_dims(x, weight, stride, pad, dil, groups, dg)
+    B, C, H, W, Co, kh, kw = dims[:7]
+    ho, wo = offset.shape[2], offset.shape[3]
+    y = torch.empty(B, Co, ho, wo, dtype=torch.float32, device=x.device)
+    nbytes = L.edvr_dcnv1_fwd_ws_bytes(*dims)
+    ws = workspace(nbytes, x.device)
+    _lib.check(L.edvr_dcnv1_fwd_f32(_ptr(x), _ptr(offset), _ptr(weight), _ptr(y), *dims, _bstride(offset), halo_hint, _ptr(ws), nbytes,
+                                    _stream()), 'edvr_dcnv1_fwd_f32')
+    return y
+
+
+def dcnv1_backward(x, offset, weight, dy, stride, pad, dil, groups, dg, scatter_hint=0):
+    """Returns (dx, doffset, dweight) of DeformConv: edvr_dcnv1_bwd_f32."""
+    require_gpu(x, offset, weight, dy)
+    L = _lib.lib()
+    offset = _as_planes(offset)
+    dy = dy.contiguous()
+    dims = _dcn_dims(x, weight, stride, pad, dil, groups, dg)
+    dx = torch.empty_like(x)
+    doff = torch.empty(offset.shape, dtype=torch.float32, device=x.device)
+    dw = torch.empty_like(weight)
+    nbytes = L.edvr_dcnv1_bwd_ws_bytes(*dims)
+    ws = workspace(nbytes, x.device)
+    _lib.check(L.edvr_dcnv1_bwd_f32(_ptr(x), _ptr(offset), _ptr(weight), _ptr(dy), _ptr(dx), _ptr(doff), _ptr(dw), *dims,
+                                    _bstride(offset), _bstride(doff), int(scatter_hint), _ptr(ws), nbytes, _stream()), 'edvr_dcnv1_bwd_f32')
+    return dx, doff, dw
+
+
 # ------------------------------------------------------------------------------------------------ DCNv2
 def _dcn_dims(x, weight, stride, pad, dil, groups, dg):
     B, C, H, W = x.shape

@@ -147,6 +147,22 @@ int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, c
  * doffset_bstride / dmask_bstride (0 = contiguous): image strides of the two gradient outputs, so both can be
  * written straight into channel slices of one (B, 3*dg*K, Ho, Wo) buffer = the gradient of conv_offset's output. */
 
+/* DCNv1 (DeformConv / DeformConvPack: no mask, no bias) <- deform_conv_forward, deform_conv_backward_input,
+ * deform_conv_backward_parameters, basicsr/models/ops/dcn/src/deform_conv_ext.cpp:51-104 (drivers deform_conv_cuda.cpp:152-488,
+ * kernels .cu:190-465).  Same offset layout and gather as DCNv2; gradients are overwritten; dx by fp32 atomics.
+ * The reference's im2col_step only sizes its column buffer and has no counterpart. */
+size_t edvr_dcnv1_fwd_ws_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil,
+                               int groups, int dg);
+int edvr_dcnv1_fwd_f32(const float *x, const float *offset, const float *weight, float *y, int B, int C, int H, int W,
+                       int Co, int kh, int kw, int stride, int pad, int dil, int groups, int dg, int64_t offset_bstride,
+                       int halo_hint, void *ws, size_t ws_bytes, edvr_stream_t stream);
+size_t edvr_dcnv1_bwd_ws_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil,
+                               int groups, int dg);
+int edvr_dcnv1_bwd_f32(const float *x, const float *offset, const float *weight, const float *dy, float *dx,
+                       float *doffset, float *dweight, int B, int C, int H, int W, int Co, int kh, int kw, int stride,
+                       int pad, int dil, int groups, int dg, int64_t offset_bstride, int64_t doffset_bstride,
+                       int scatter_hint, void *ws, size_t ws_bytes, edvr_stream_t stream);
+
 /* ------------------------------------------------------------------ TSA / PCD glue kernels (HBM-bound) */
 /* Temporal attention (edvr_arch.py:171-184): prob[b,t,p] = sigmoid(sum_c emb[b,t,c,p]*emb_ref[b,c,p]);
  * out[b,t,c,p] = aligned[b,t,c,p] * prob[b,t,p].  prob_out (b,t,hw) may be NULL. */

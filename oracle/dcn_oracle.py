@@ -177,3 +177,45 @@ def dcnv2_torch(x, offset, mask, weight, bias=None, stride=1, padding=0, dilatio
     col = (v * (valid * mask.reshape(B, dg, K, Ho, Wo)).unsqueeze(2)).reshape(B, groups, cig * K, Ho * Wo)
     out = torch.einsum('gok,bgkp->bgop', weight.reshape(groups, Co // groups, cig * K), col).reshape(B, Co, Ho, Wo)
     return out if bias is None else out + bias.view(1, -1, 1, 1)
+
+
+# ------------------------------------------------------------------------------------------------ DCNv1
+def ref_dcn1_forward(x, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1):
+    """The reference's OWN deformable_im2col kernel (.cu:190-250) + the restated driver (deform_conv_cuda.cpp:152-243), fp64."""
+    lib = _load('ref')
+    (x, offset, weight), _ = _prep(x.double(), offset.double(), weight.double())
+    B, C, H, W = x.shape
+    Co, _, kh, kw = weight.shape
+    Ho, Wo = _out_hw(H, W, kh, kw, stride, padding, dilation)
+    y = torch.empty(B, Co, Ho, Wo, dtype=torch.float64)
+    rc = lib.ref_dcn1_forward_f64(_p(x), _p(weight), _p(offset), _p(y), B, C, H, W, Co, kh, kw, stride, padding, dilation, groups,
+                                  deformable_groups)
+    assert rc == 0
+    return y
+
+
+def ref_dcn1_backward(x, offset, weight, dy, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1):
+    """(dx, doffset, dweight) from the reference's own col2im / col2im_coord / im2col kernels (.cu:280-465), fp64."""
+    lib = _load('ref')
+    (x, offset, weight, dy), _ = _prep(x.double(), offset.double(), weight.double(), dy.double())
+    B, C, H, W = x.shape
+    Co, _, kh, kw = weight.shape
+    dx, dw, doff = torch.zeros_like(x), torch.zeros_like(weight), torch.zeros_like(offset)
+    rc = lib.ref_dcn1_backward_f64(_p(x), _p(weight), _p(offset), _p(dy), _p(dx), _p(dw), _p(doff), B, C, H, W, Co, kh, kw, stride,
+                                   padding, dilation, groups, deformable_groups)
+    assert rc == 0
+    return dx, doff, dw
+
+
+def c_dcn1_forward(x, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1):
+    """DCNv1 on the plain-C oracle: DCNv2 with an all-ones mask and no bias (pinned against ref_dcn1_* in tests/test_oracle_vs_ref.py)."""
+    B, _, Ho, Wo = offset.shape
+    ones = torch.ones(B, offset.shape[1] // 2, Ho, Wo, dtype=offset.dtype)
+    return c_forward(x, offset, ones, weight, None, stride, padding, dilation, groups, deformable_groups)
+
+
+def c_dcn1_backward(x, offset, weight, dy, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1):
+    B, _, Ho, Wo = offset.shape
+    ones = torch.ones(B, offset.shape[1] // 2, Ho, Wo, dtype=offset.dtype)
+    dx, doff, _, dw, _ = c_backward(x, offset, ones, weight, dy, False, stride, padding, dilation, groups, deformable_groups)
+    return dx, doff, dw

@@ -4,6 +4,7 @@
 
 Golden vectors come from the REFERENCE ITSELF wherever it can execute here:
   dcn_*.pt   - inputs + outputs/gradients of the reference's own DCNv2 kernels
+  dcn1_*.pt  - the same for DCNv1 (DeformConv), from the reference's own deformable_im2col / col2im / col2im_coord kernels
                (deform_conv_cuda_kernel.cu compiled serially for the CPU: oracle/_ref), fp64
   edvr_*.pt  - seeded input + output of the reference's own Python network (basicsr/models/archs/edvr_arch.py
                imported unchanged, oracle/ref_import.py) with the DCN op supplied by oracle/_ref
@@ -56,6 +57,17 @@ def dcn_case(name):
                 dweight=dw, dbias=db)
 
 
+DCN1_CASES = ('edvr_like', 'half_taps', 'stride2_groups2', 'dilation2')  # same shapes; DCNv1 = no mask, no bias
+
+
+def dcn1_case(name):
+    d = dcn_case(name)  # same seeded inputs
+    cfg = d['cfg']
+    y = O.ref_dcn1_forward(d['x'], d['offset'], d['weight'], *cfg)
+    dx, doff, dw = O.ref_dcn1_backward(d['x'], d['offset'], d['weight'], d['dy'], *cfg)
+    return dict(cfg=cfg, x=d['x'], offset=d['offset'], weight=d['weight'], dy=d['dy'], y=y, dx=dx, doffset=doff, dweight=dw)
+
+
 def edvr_case(name):
     from util_edvr import CONFIGS, randomize_offsets
     kwargs, shape = CONFIGS[name]
@@ -76,6 +88,8 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     for name in DCN_CASES:
         torch.save(dcn_case(name), os.path.join(OUT, f'dcn_{name}.pt'))
+    for name in DCN1_CASES:
+        torch.save(dcn1_case(name), os.path.join(OUT, f'dcn1_{name}.pt'))
     for name in EDVR_CASES:
         torch.save(edvr_case(name), os.path.join(OUT, f'edvr_{name}.pt'))
     for f in sorted(os.listdir(OUT)):

@@ -10,6 +10,7 @@
 // What is restated here (ours): only the HOST drivers of
 //   basicsr/models/ops/dcn/src/deform_conv_cuda.cpp:490-569  (modulated forward)
 //   basicsr/models/ops/dcn/src/deform_conv_cuda.cpp:571-685  (modulated backward)
+//   basicsr/models/ops/dcn/src/deform_conv_cuda.cpp:152-488  (DCNv1 forward / backward_input / backward_parameters)
 // whose at::addmm_ calls become plain triple loops (they need ATen, which the
 // shim does not provide).  Per-sample loop, zeroed columns, group split and
 // the final bias add follow those lines.
@@ -133,9 +134,78 @@ int mdcn_backward(const T *input, const T *weight, const T *offset, const T *mas
   return 0;
 }
 
+// ---- DCNv1 (DeformConv): deform_conv_cuda.cpp:152-243 (forward), :245-372 (backward_input), :374-488 (backward_parameters),
+//      restated per sample (im2col_step = 1, so parallel_imgs = 1 and the column layout has batch_size 1).
+template <typename T>
+int dcn1_forward(const T *input, const T *weight, const T *offset, T *output, int batch, int channels, int height, int width,
+                 int channels_out, int kh, int kw, int stride, int pad, int dil, int group, int dg) {
+  const int Ho = (height + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1;
+  const int Wo = (width + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
+  const int K = kh * kw, P = Ho * Wo;
+  if (channels % group || channels_out % group || channels % dg) return -1;
+  std::vector<T> columns((size_t)channels * K * P, (T)0);
+  for (size_t i = 0; i < (size_t)batch * channels_out * P; ++i) output[i] = 0;
+  const int cig = channels / group, cog = channels_out / group;
+  for (int b = 0; b < batch; ++b) {
+    deformable_im2col_gpu_kernel<T>(channels * Ho * Wo * 1, input + (size_t)b * channels * height * width,
+                                    offset + (size_t)b * dg * 2 * K * P, height, width, kh, kw, pad, pad, stride, stride, dil, dil,
+                                    channels / dg, 1, channels, dg, Ho, Wo, columns.data());  // .cu:252-276 launcher
+    for (int g = 0; g < group; ++g)                                                             // .cpp:214-222
+      gemm_nn_acc(weight + (size_t)g * cog * cig * K, columns.data() + (size_t)g * cig * K * P,
+                  output + ((size_t)b * channels_out + (size_t)g * cog) * P, cog, cig * K, P);
+  }
+  return 0;
+}
+
+// grad_* must be zero-filled by the caller (deform_conv.py:71-76 allocates zeros)
+template <typename T>
+int dcn1_backward(const T *input, const T *weight, const T *offset, const T *grad_output, T *grad_input, T *grad_weight,
+                  T *grad_offset, int batch, int channels, int height, int width, int channels_out, int kh, int kw, int stride,
+                  int pad, int dil, int group, int dg) {
+  const int Ho = (height + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1;
+  const int Wo = (width + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
+  const int K = kh * kw, P = Ho * Wo;
+  if (channels % group || channels_out % group || channels % dg) return -1;
+  std::vector<T> columns((size_t)channels * K * P, (T)0);
+  const int cig = channels / group, cog = channels_out / group;
+  for (int b = 0; b < batch; ++b) {
+    const T *in_b = input + (size_t)b * channels * height * width;
+    const T *off_b = offset + (size_t)b * dg * 2 * K * P;
+    const T *go_b = grad_output + (size_t)b * channels_out * P;
+    for (int g = 0; g < group; ++g)  // .cpp:325-334 columns[g] = W[g]^T dY[b][g]
+      gemm_tn_set(weight + (size_t)g * cog * cig * K, go_b + (size_t)g * cog * P, columns.data() + (size_t)g * cig * K * P, cig * K,
+                  cog, P);
+    deformable_col2im_coord_gpu_kernel<T>(Ho * Wo * 2 * K * dg * 1, columns.data(), in_b, off_b, channels, height, width, kh, kw,
+                                          pad, pad, stride, stride, dil, dil, channels * K / dg, 1, 2 * K * dg, dg, Ho, Wo,
+                                          grad_offset + (size_t)b * dg * 2 * K * P);  // .cpp:341-344
+    deformable_col2im_gpu_kernel<T>(channels * K * Ho * Wo * 1, columns.data(), off_b, channels, height, width, kh, kw, pad, pad,
+                                    stride, stride, dil, dil, channels / dg, 1, dg, Ho, Wo,
+                                    grad_input + (size_t)b * channels * height * width);  // .cpp:346-348
+    deformable_im2col_gpu_kernel<T>(channels * Ho * Wo * 1, in_b, off_b, height, width, kh, kw, pad, pad, stride, stride, dil, dil,
+                                    channels / dg, 1, channels, dg, Ho, Wo, columns.data());  // .cpp:445-447
+    for (int g = 0; g < group; ++g)  // .cpp:460-468 (scale = 1)
+      gemm_nt_acc(go_b + (size_t)g * cog * P, columns.data() + (size_t)g * cig * K * P, grad_weight + (size_t)g * cog * cig * K, cog, P,
+                  cig * K);
+  }
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
+
+int ref_dcn1_forward_f64(const double *input, const double *weight, const double *offset, double *output, int batch, int channels,
+                         int height, int width, int channels_out, int kh, int kw, int stride, int pad, int dil, int group, int dg) {
+  return dcn1_forward<double>(input, weight, offset, output, batch, channels, height, width, channels_out, kh, kw, stride, pad, dil,
+                              group, dg);
+}
+int ref_dcn1_backward_f64(const double *input, const double *weight, const double *offset, const double *grad_output,
+                          double *grad_input, double *grad_weight, double *grad_offset, int batch, int channels, int height,
+                          int width, int channels_out, int kh, int kw, int stride, int pad, int dil, int group, int dg) {
+  return dcn1_backward<double>(input, weight, offset, grad_output, grad_input, grad_weight, grad_offset, batch, channels, height,
+                               width, channels_out, kh, kw, stride, pad, dil, group, dg);
+}
+
 
 int ref_mdcn_forward_f64(const double *input, const double *weight, const double *bias, const double *offset,
                          const double *mask, double *output, int batch, int channels, int height, int width,

@@ -11,6 +11,7 @@ from util_edvr import CONFIGS, oracle_kwargs, randomize_offsets
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 DCN_FILES = sorted(glob.glob(os.path.join(GOLD, 'dcn_*.pt')))
+DCN1_FILES = sorted(glob.glob(os.path.join(GOLD, 'dcn1_*.pt')))
 EDVR_FILES = sorted(glob.glob(os.path.join(GOLD, 'edvr_*.pt')))
 GRADS = ('dx', 'doffset', 'dmask', 'dweight', 'dbias')
 
@@ -20,7 +21,7 @@ def _load(f):
 
 
 def test_fixtures_exist():
-    assert len(DCN_FILES) >= 7 and len(EDVR_FILES) >= 3
+    assert len(DCN_FILES) >= 7 and len(EDVR_FILES) >= 3 and len(DCN1_FILES) >= 4
 
 
 @pytest.mark.parametrize('f', DCN_FILES, ids=os.path.basename)
@@ -34,6 +35,14 @@ def test_oracle_reproduces_dcn_golden(f):
     O.dcnv2_torch(*t, *d['cfg']).backward(d['dy'])
     for name, v in zip(GRADS, t):
         assert (v.grad - d[name]).abs().max().item() <= 1e-11 * max(1.0, d[name].abs().max().item()), name
+
+
+@pytest.mark.parametrize('f', DCN1_FILES, ids=os.path.basename)
+def test_oracle_reproduces_dcn1_golden(f):
+    d = _load(f)
+    assert (O.c_dcn1_forward(d['x'], d['offset'], d['weight'], *d['cfg']) - d['y']).abs().max().item() < 1e-12
+    for name, got in zip(('dx', 'doffset', 'dweight'), O.c_dcn1_backward(d['x'], d['offset'], d['weight'], d['dy'], *d['cfg'])):
+        assert (got - d[name]).abs().max().item() <= 1e-12 * max(1.0, d[name].abs().max().item()), name
 
 
 def _rebuild(d):
@@ -66,6 +75,20 @@ def test_hip_reproduces_dcn_golden(gpu, f):
     rel = lambda a, r: ((a.double().cpu() - r).abs().max() / r.abs().max().clamp_min(1e-30)).item()
     assert rel(y, d['y']) < 2e-5
     for name, got in zip(GRADS, grads):
+        assert rel(got, d[name]) < 1e-4, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('f', DCN1_FILES, ids=os.path.basename)
+def test_hip_reproduces_dcn1_golden(gpu, f):
+    from edvr_amd import ops
+    d = _load(f)
+    x, off, w, dy = (d[k].float().to(gpu) for k in ('x', 'offset', 'weight', 'dy'))
+    y = ops.dcnv1_forward(x, off, w, *d['cfg'])
+    grads = ops.dcnv1_backward(x, off, w, dy, *d['cfg'])
+    rel = lambda a, r: ((a.double().cpu() - r).abs().max() / r.abs().max().clamp_min(1e-30)).item()
+    assert rel(y, d['y']) < 2e-5
+    for name, got in zip(('dx', 'doffset', 'dweight'), grads):
         assert rel(got, d[name]) < 1e-4, name
 
 

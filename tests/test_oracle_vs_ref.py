@@ -82,3 +82,18 @@ def test_gradcheck_of_the_torch_restatement():
     off = (torch.randn(1, 36, 5, 5, generator=g, dtype=torch.float64) * 1.3 + 0.017).requires_grad_()  # away from integers
     m = torch.rand(1, 18, 5, 5, generator=g, dtype=torch.float64, requires_grad=True)
     assert torch.autograd.gradcheck(lambda *a: O.dcnv2_torch(*a, None, 1, 1, 1, 1, 2), (x, off, m, w), eps=1e-6, atol=1e-6)
+
+
+@needs_ref
+@pytest.mark.parametrize('case', CASES)
+def test_dcnv1_oracle_matches_the_references_own_v1_kernels(case):
+    """DCNv1: the C oracle run with an all-ones mask equals the reference's deformable_im2col /
+    col2im / col2im_coord kernels (.cu:190-465) driven as deform_conv_cuda.cpp:152-488 does - forward and all gradients."""
+    x, off, _, w, _, dy, cfg = _mk(case, torch.float64)
+    y_ref = O.ref_dcn1_forward(x, off, w, *cfg)
+    y_c = O.c_dcn1_forward(x, off, w, *cfg)
+    assert torch.equal(y_ref, y_c) or (y_ref - y_c).abs().max().item() <= 1e-13 * max(1.0, y_ref.abs().max().item())
+    g_ref = O.ref_dcn1_backward(x, off, w, dy, *cfg)
+    g_c = O.c_dcn1_backward(x, off, w, dy, *cfg)
+    for name, a, r in zip(('dx', 'doffset', 'dweight'), g_c, g_ref):
+        assert (a - r).abs().max().item() <= 1e-12 * max(1.0, r.abs().max().item()), name
