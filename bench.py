@@ -70,6 +70,7 @@ def parse():
     ap.add_argument('--batch', type=int, default=0, help='clips per GPU (default: the workload\'s)')
     ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
                     help='infer: forward clips/s (default).  train: fwd + Charbonnier + bwd + grad all-reduce + Adam')
+    ap.add_argument('--optimizer', default='fused', choices=['fused', 'torch'], help='train mode: edvr_amd FusedAdam or torch.optim.Adam')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     return ap.parse_args()
@@ -177,9 +178,11 @@ def main():
         sc = cfg.get('scale', 4)
         gt = torch.rand(batch, 3, sc * cfg['shape'][2], sc * cfg['shape'][3], generator=torch.Generator().manual_seed(1000 + rank)).to(device)
         model = D.wrap_ddp(net)  # RCCL gradient all-reduce, bucketed and overlapped with backward
-        dcn = [p for n, p in net.named_parameters() if 'dcn' in n]  # edvr_model.py:21-53 (dcn_lr_mul: 1)
+        from edvr_amd.optim import FusedAdam
+        dcn = [p for n, p in net.named_parameters() if 'dcn' in n]  # edvr_model.py:21-53 (two groups as with dcn_lr_mul != 1)
         rest = [p for n, p in net.named_parameters() if 'dcn' not in n]
-        opt = torch.optim.Adam([{'params': rest, 'lr': 4e-4}, {'params': dcn, 'lr': 4e-4 * 1}], lr=4e-4, betas=(0.9, 0.99))
+        groups = [{'params': rest, 'lr': 4e-4}, {'params': dcn, 'lr': 4e-4 * 1}]
+        opt = (torch.optim.Adam if args.optimizer == 'torch' else FusedAdam)(groups, lr=4e-4, betas=(0.9, 0.99))
 
         def step():
             opt.zero_grad(set_to_none=True)
@@ -235,7 +238,8 @@ def main():
         }
         if args.mode == 'train':
             result['iters_per_sec'] = round(args.steps / elapsed, 4)
-            result['optimizer'] = 'torch.optim.Adam (as the reference; fused Adam is SURVEY 8(f) next)'
+            result['optimizer'] = ('edvr_amd.optim.FusedAdam (one HIP launch for all tensors; arithmetic of torch.optim.Adam)'
+                                   if args.optimizer == 'fused' else 'torch.optim.Adam')
         if not args.no_roofline and args.mode == 'infer':
             per = instrumented_pass(net, x, max(1, min(args.steps, 3)))
             name = max(per, key=lambda k: per[k][2])

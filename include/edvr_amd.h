@@ -224,6 +224,14 @@ int edvr_tsa_combine_bwd_f32(const float *feat, const float *attn, const float *
 int edvr_charbonnier_f32(const float *pred, const float *target, float *loss, float *dpred, int64_t numel, float eps,
                          float grad_scale, edvr_stream_t stream);
 
+/* Multi-tensor Adam step <- torch.optim.Adam.step() as the reference builds it (basicsr/models/edvr_model.py:21-53, parameter
+ * groups with dcn_lr_mul; stepped in sr_model.py:112).  `chunk_table` is a DEVICE array of n_chunks records of
+ * edvr_adam_chunk_bytes() = 64 bytes: { float *p; const float *g; float *m; float *v; int32 n (<= 65536 elements of one tensor);
+ * float lr; float weight_decay; float 1/(1-beta1^t); float 1/sqrt(1-beta2^t); 12 bytes padding }.  One launch updates every
+ * tensor of every group; arithmetic of torch.optim.Adam (amsgrad = False, maximize = False). */
+size_t edvr_adam_chunk_bytes(void);
+int edvr_adam_multi_f32(const void *chunk_table, int n_chunks, float beta1, float beta2, float eps, edvr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

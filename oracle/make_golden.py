@@ -83,6 +83,29 @@ def edvr_case(name):
                 n_params=sum(p.numel() for p in net.parameters()))
 
 
+def lr_sched_case():
+    """Learning rates of the reference's own schedulers (basicsr/models/lr_scheduler.py) for two parameter groups."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location('ref_lr_scheduler', '/root/reference/basicsr/models/lr_scheduler.py')
+    ls = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ls)
+    out = {}
+    for name, make in (('cosine', lambda o: ls.CosineAnnealingRestartLR(o, periods=[50, 50, 30, 70], restart_weights=[1, 0.5, 0.5, 0.25], eta_min=1e-7)),
+                       ('multistep', lambda o: ls.MultiStepRestartLR(o, milestones=[20, 40, 90, 120], gamma=0.5, restarts=[0, 80], restart_weights=[1, 0.5]))):
+        w = [torch.nn.Parameter(torch.zeros(1)), torch.nn.Parameter(torch.zeros(1))]
+        opt = torch.optim.SGD([{'params': [w[0]], 'lr': 4e-4}, {'params': [w[1]], 'lr': 1e-4}], lr=4e-4)
+        sch = make(opt)
+        lrs = []
+        for _ in range(200):
+            lrs.append([g['lr'] for g in opt.param_groups])
+            opt.step()
+            sch.step()
+        out[name] = lrs
+    with open(os.path.join(OUT, 'lr_sched.json'), 'w') as f:
+        json.dump(out, f)
+
+
 def main():
     assert ref_import.available() and O.have_ref(), 'needs /root/reference and oracle/_ref (make -C oracle ref)'
     os.makedirs(OUT, exist_ok=True)
@@ -90,6 +113,7 @@ def main():
         torch.save(dcn_case(name), os.path.join(OUT, f'dcn_{name}.pt'))
     for name in DCN1_CASES:
         torch.save(dcn1_case(name), os.path.join(OUT, f'dcn1_{name}.pt'))
+    lr_sched_case()
     for name in EDVR_CASES:
         torch.save(edvr_case(name), os.path.join(OUT, f'edvr_{name}.pt'))
     for f in sorted(os.listdir(OUT)):
