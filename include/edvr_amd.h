@@ -224,6 +224,15 @@ int edvr_tsa_combine_bwd_f32(const float *feat, const float *attn, const float *
 int edvr_charbonnier_f32(const float *pred, const float *target, float *loss, float *dpred, int64_t numel, float eps,
                          float grad_scale, edvr_stream_t stream);
 
+/* Validation PSNR on the device <- tensor2img (basicsr/utils/img_util.py:36-98) + calculate_psnr (basicsr/metrics/psnr_ssim.py:7-51),
+ * which the reference runs per frame on the host after a D2H copy (video_base_model.py:60-98).  a, b: (n, c, h, w) fp32 in RGB
+ * channel order, c = 3 or 1.  partial[img * blocks + k] receives the k-th partial sum of squared differences of the two
+ * clamp[0,1]-x255-round uint8 images inside the crop (exact integers in double; sum them per image, divide by the element
+ * count, PSNR = 20 log10(255 / sqrt(mse))).  y_channel != 0: differences of the Y channel as to_y_channel computes it
+ * (metric_util.py:34-47; float32, not rounded), one value per pixel. */
+int edvr_psnr_sse_f32(const float *a, const float *b, double *partial, int n, int c, int h, int w, int64_t a_img_stride,
+                      int64_t b_img_stride, int crop_border, int y_channel, int blocks, edvr_stream_t stream);
+
 /* Multi-tensor Adam step <- torch.optim.Adam.step() as the reference builds it (basicsr/models/edvr_model.py:21-53, parameter
  * groups with dcn_lr_mul; stepped in sr_model.py:112).  `chunk_table` is a DEVICE array of n_chunks records of
  * edvr_adam_chunk_bytes() = 64 bytes: { float *p; const float *g; float *m; float *v; int32 n (<= 65536 elements of one tensor);

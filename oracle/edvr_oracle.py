@@ -181,6 +181,26 @@ def psnr(pred, gt):
     return psnr_uint8(tensor2img_uint8(pred), tensor2img_uint8(gt))
 
 
+def psnr_cropped(pred, gt, crop_border=0, test_y_channel=False):
+    """calculate_psnr(tensor2img(pred), tensor2img(gt), crop_border, 'HWC', test_y_channel) restated in NumPy for ONE image
+    (c, h, w), RGB channel order (psnr_ssim.py:7-51, metric_util.py:34-47, matlab_functions.py:207-240)."""
+    import math
+
+    import numpy as np
+    a = tensor2img_uint8(pred).numpy().astype(np.float64)
+    b = tensor2img_uint8(gt).numpy().astype(np.float64)
+    if crop_border:
+        a, b = a[:, crop_border:-crop_border, crop_border:-crop_border], b[:, crop_border:-crop_border, crop_border:-crop_border]
+    if test_y_channel and a.shape[0] == 3:
+        def to_y(img):  # BGR of the reference = RGB reversed
+            f = img.astype(np.float32) / 255.
+            y = np.dot(np.moveaxis(f[::-1], 0, -1), [24.966, 128.553, 65.481]) + 16.0
+            return (y / 255.).astype(np.float32) * 255.
+        a, b = to_y(a), to_y(b)
+    mse = np.mean((a - b) ** 2)
+    return float('inf') if mse == 0 else float(20. * math.log10(255. / math.sqrt(mse)))
+
+
 def charbonnier_sum(pred, target, eps=1e-12):
     """basicsr/models/losses/losses.py:23-25 with reduction='sum'."""
     return torch.sqrt((pred - target) ** 2 + eps).sum()

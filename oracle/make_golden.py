@@ -83,6 +83,47 @@ def edvr_case(name):
                 n_params=sum(p.numel() for p in net.parameters()))
 
 
+def psnr_case():
+    """PSNR of the reference's own calculate_psnr (basicsr/metrics/psnr_ssim.py) on tensor2img-converted random tensors
+    (uint8, HWC, BGR as tensor2img produces them), for crop_border / test_y_channel combinations."""
+    import sys
+    import types
+    import importlib.util
+    sys.modules.setdefault('cv2', types.ModuleType('cv2'))  # psnr_ssim.py imports cv2 for SSIM only
+    # the package __init__ files pull in torchvision / lmdb: load the three files the PSNR path needs under bare parent packages
+    for pkg in ('basicsr', 'basicsr.utils', 'basicsr.metrics'):
+        if pkg not in sys.modules:
+            m = types.ModuleType(pkg)
+            m.__path__ = []
+            sys.modules[pkg] = m
+    def load(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join('/root/reference', rel))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+        return mod
+    load('basicsr.utils.matlab_functions', 'basicsr/utils/matlab_functions.py')
+    load('basicsr.metrics.metric_util', 'basicsr/metrics/metric_util.py')
+    calculate_psnr = load('basicsr.metrics.psnr_ssim', 'basicsr/metrics/psnr_ssim.py').calculate_psnr
+    from oracle import edvr_oracle as EO
+    g = torch.Generator().manual_seed(77)
+    pred = torch.rand(3, 3, 24, 36, generator=g) * 1.2 - 0.1  # some values outside [0, 1]: tensor2img clamps
+    gt = (pred + 0.05 * torch.randn(3, 3, 24, 36, generator=g)).clamp(-0.2, 1.2)
+    gt[2] = pred[2]                                           # identical image: inf
+    gray_p, gray_g = pred[:, :1].contiguous(), gt[:, :1].contiguous()
+    def hwc_bgr(t):  # what tensor2img returns for a 3-channel RGB tensor (rgb2bgr=True), CHW -> HWC
+        u = EO.tensor2img_uint8(t).numpy()
+        return u[::-1].transpose(1, 2, 0) if u.shape[0] == 3 else u.transpose(1, 2, 0)
+    cases = []
+    for crop in (0, 2):
+        for ych in (False, True):
+            cases.append(dict(crop_border=crop, test_y_channel=ych, gray=False,
+                              psnr=[float(calculate_psnr(hwc_bgr(pred[i]), hwc_bgr(gt[i]), crop, 'HWC', ych)) for i in range(3)]))
+    cases.append(dict(crop_border=1, test_y_channel=False, gray=True,
+                      psnr=[float(calculate_psnr(hwc_bgr(gray_p[i]), hwc_bgr(gray_g[i]), 1, 'HWC', False)) for i in range(3)]))
+    torch.save(dict(pred=pred, gt=gt, cases=cases), os.path.join(OUT, 'psnr.pt'))
+
+
 def lr_sched_case():
     """Learning rates of the reference's own schedulers (basicsr/models/lr_scheduler.py) for two parameter groups."""
     import importlib.util
@@ -114,6 +155,7 @@ def main():
     for name in DCN1_CASES:
         torch.save(dcn1_case(name), os.path.join(OUT, f'dcn1_{name}.pt'))
     lr_sched_case()
+    psnr_case()
     for name in EDVR_CASES:
         torch.save(edvr_case(name), os.path.join(OUT, f'edvr_{name}.pt'))
     for f in sorted(os.listdir(OUT)):
