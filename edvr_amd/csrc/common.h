@@ -38,7 +38,8 @@ int gemm_nt_launch(const float *A, const float *B, float *C, int M, int N, int64
 // follows the direct packed layout inside the buffer edvr_conv2d_pack_weight_f32 fills.
 bool winograd_eligible(const edvr_conv2d_desc &d);
 int winograd_launch(const edvr_conv2d_desc &d, const float *U, int cop64, hipStream_t stream);
-int winograd_pack(const float *w, float *U, int co, int ci, int cop64, int cip, int transpose_flip, hipStream_t stream);
+int winograd_pack(const float *w, float *U, int co, int ci, int cop64, int cip, int transpose_flip, float *wpk_direct, int cop32,
+                  hipStream_t stream);  // wpk_direct != nullptr: also writes the direct layout [cip][9][cop32] in the same launch
 
 // blas.hip: row-major strided-batched fp32 GEMM on rocBLAS (plain GEMMs only: the DCNv2 backward's dcol and dW)
 int blas_gemm_rowmajor(const float *A, const float *B, float *C, int M, int N, int K, bool a_trans, bool b_trans, int64_t lda,

@@ -369,12 +369,12 @@ int edvr_conv2d_pack_weight_f32(const float *w, float *wpk, int co, int ci, int 
   const int cop = edvr::round_up(co, 32), cip = edvr::round_up(ci, ks == 1 ? 32 : 16), kk = ks * ks;
   const int64_t total = (int64_t)cip * kk * cop;
   const int blocks = (int)std::min<int64_t>(edvr::cdiv64(total, 256), 4096);
+  if (ks == 3)  // one launch writes both the direct layout and the Winograd-transformed weights
+    return edvr::winograd_pack(w, wpk + edvr::direct_packed_elems(co, ci, 3), co, ci, edvr::round_up(co, 64), cip, transpose_flip, wpk, cop,
+                               edvr::as_stream(stream));
   hipLaunchKernelGGL(edvr::pack_weight_kernel, dim3(blocks), dim3(256), 0, edvr::as_stream(stream), w, wpk, co, ci, kk,
                      cop, cip, transpose_flip);
-  int rc = edvr::check_launch("pack_weight_kernel");
-  if (rc || ks != 3) return rc;
-  return edvr::winograd_pack(w, wpk + edvr::direct_packed_elems(co, ci, 3), co, ci, edvr::round_up(co, 64), cip, transpose_flip,
-                             edvr::as_stream(stream));
+  return edvr::check_launch("pack_weight_kernel");
 }
 
 int edvr_conv2d_kernel_name(const edvr_conv2d_desc *d, char *buf, size_t buf_len) {

@@ -236,7 +236,29 @@ __global__ void channel_sum_final_kernel(const float *__restrict__ part, float *
   out[c] = s;
 }
 
+// 16-byte version: the sum over up to 2 x 64 split-K partials is a pure streaming read (75 MB per trunk layer)
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float4 *__restrict__ ws, float4 *__restrict__ dw, int64_t total4, int splits,
+                                                            int accumulate) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 s = accumulate ? dw[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int k = 0; k < splits; ++k) {
+      const float4 v = ws[(int64_t)k * total4 + i];
+      s.x += v.x;
+      s.y += v.y;
+      s.z += v.z;
+      s.w += v.w;
+    }
+    dw[i] = s;
+  }
+}
+
 int reduce_partials_launch(const float *ws, float *out, int64_t total, int parts, int accumulate, hipStream_t stream) {
+  if ((total & 3) == 0 && ((reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+    hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total / 4, 256), 2048)), dim3(256), 0, stream,
+                       reinterpret_cast<const float4 *>(ws), reinterpret_cast<float4 *>(out), total / 4, parts, accumulate);
+    return check_launch("wgrad_reduce4_kernel");
+  }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 2048)), dim3(256), 0, stream, ws, out, total,
                      parts, accumulate);
   return check_launch("wgrad_reduce_kernel");
@@ -307,10 +329,7 @@ int edvr_conv2d_wgrad_f32(const float *x1, const float *x2, const float *dz, flo
     int rc = winograd_wgrad_launch(x1, x2, dz, a.ws, c1, c2, n, h, w, co, x1_img_stride, x2_img_stride, x2_div, x2_mul, x2_add,
                                    dz_img_stride, wsplits, stream);
     if (rc) return rc;
-    const int64_t total = (int64_t)co * ci * 9;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 2048)), dim3(256), 0, stream, a.ws, dw,
-                       total, 2 * wsplits, accumulate);
-    return check_launch("wgrad_reduce_kernel");
+    return reduce_partials_launch(a.ws, dw, (int64_t)co * ci * 9, 2 * wsplits, accumulate, stream);
   }
   dim3 grid(cdiv(ci, 32 * (4 / mw)), cdiv(co, 32 * mw), a.splits);
 #define EDVR_WGRAD_LAUNCH(KS_, ST_)                                                                                   \
@@ -325,10 +344,7 @@ int edvr_conv2d_wgrad_f32(const float *x1, const float *x2, const float *dz, flo
 #undef EDVR_WGRAD_LAUNCH
   int rc = check_launch("conv2d_wgrad_kernel");
   if (rc) return rc;
-  const int64_t total = (int64_t)co * ci * ks * ks;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 2048)), dim3(256), 0, stream, a.ws, dw,
-                     total, a.splits, accumulate);
-  return check_launch("wgrad_reduce_kernel");
+  return reduce_partials_launch(a.ws, dw, (int64_t)co * ci * ks * ks, a.splits, accumulate, stream);
 }
 
 int edvr_conv2d_wgrad_algo(int algo) {

@@ -454,9 +454,20 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_kernel(const WinoArgs
 }
 
 // U[ci][xi][cop] = (G g G^T)[xi] of the 3x3 kernel g = w[co][ci] (or the data-gradient kernel when transpose_flip)
+// When `wpk` is given the same launch also writes the direct kernel's layout [cip][9][cop32] (training repacks every weight
+// each step: one launch per layer and orientation instead of two).
 __global__ void winograd_weight_kernel(const float *__restrict__ w, float *__restrict__ U, int co, int ci, int cop, int cip,
-                                       int transpose_flip) {
+                                       int transpose_flip, float *__restrict__ wpk, int cop32) {
   const int64_t total = (int64_t)cip * cop;
+  if (wpk) {
+    const int64_t dtotal = (int64_t)cip * 9 * cop32;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < dtotal; i += (int64_t)gridDim.x * blockDim.x) {
+      const int o = (int)(i % cop32), t = (int)((i / cop32) % 9), c = (int)(i / ((int64_t)cop32 * 9));
+      float v = 0.f;
+      if (o < co && c < ci) v = transpose_flip ? w[((int64_t)c * co + o) * 9 + (8 - t)] : w[((int64_t)o * ci + c) * 9 + t];
+      wpk[i] = v;
+    }
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int o = (int)(i % cop), c = (int)(i / cop);
     float g[9];
@@ -524,10 +535,11 @@ int winograd_launch(const edvr_conv2d_desc &d, const float *U, int cop, hipStrea
   return check_launch("conv3x3_winograd_kernel");
 }
 
-int winograd_pack(const float *w, float *U, int co, int ci, int cop, int cip, int transpose_flip, hipStream_t stream) {
-  const int64_t total = (int64_t)cip * cop;
+int winograd_pack(const float *w, float *U, int co, int ci, int cop, int cip, int transpose_flip, float *wpk_direct, int cop32,
+                  hipStream_t stream) {
+  const int64_t total = std::max((int64_t)cip * cop, wpk_direct ? (int64_t)cip * 9 * cop32 : (int64_t)0);
   hipLaunchKernelGGL(winograd_weight_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 4096)), dim3(256), 0, stream, w, U, co, ci,
-                     cop, cip, transpose_flip);
+                     cop, cip, transpose_flip, wpk_direct, cop32);
   return check_launch("winograd_weight_kernel");
 }
 
