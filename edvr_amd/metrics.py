@@ -4,6 +4,10 @@ Mirrors xinntao/EDVR (BasicSR v1.2.0): tensor2img (basicsr/utils/img_util.py:36-
 (basicsr/metrics/psnr_ssim.py:7-51), which VideoBaseModel.dist_validation (video_base_model.py:60-98) runs per frame in NumPy
 after copying the frame to the host.  Here the clamp-round-uint8 conversion and the squared differences happen in one HIP
 kernel (csrc/metrics.hip) and only one double per image leaves the GPU.  SSIM (psnr_ssim.py:54-141) is not implemented.
+
+validate_clip() is the batched form of that loop for one clip: every frame's window of `num_frame` neighbours is built with
+generate_frame_indices (basicsr/data/data_util.py:35-88, the padding modes of the REDS4 / Vid4 test sets), windows run through
+the network `batch` at a time, and each output frame is scored on the device.
 """
 import math
 
@@ -40,3 +44,40 @@ def calculate_psnr(pred, gt, crop_border=0, test_y_channel=False):
         mse = s / count
         out.append(float('inf') if mse == 0 else 20.0 * math.log10(255.0 / math.sqrt(mse)))
     return out
+
+
+def generate_frame_indices(crt_idx, max_frame_num, num_frames, padding='reflection'):
+    """basicsr/data/data_util.py:35-88: indices of the `num_frames` frames around `crt_idx` in a sequence of `max_frame_num`
+    frames, out-of-range positions padded by 'replicate' | 'reflection' | 'reflection_circle' | 'circle'."""
+    assert num_frames % 2 == 1, 'num_frames should be an odd number.'
+    assert padding in ('replicate', 'reflection', 'reflection_circle', 'circle'), f'Wrong padding mode: {padding}.'
+    max_frame_num = max_frame_num - 1  # start from 0
+    num_pad = num_frames // 2
+    indices = []
+    for i in range(crt_idx - num_pad, crt_idx + num_pad + 1):
+        if i < 0:
+            pad_idx = {'replicate': 0, 'reflection': -i, 'reflection_circle': crt_idx + num_pad - i, 'circle': num_frames + i}[padding]
+        elif i > max_frame_num:
+            pad_idx = {'replicate': max_frame_num, 'reflection': max_frame_num * 2 - i,
+                       'reflection_circle': (crt_idx - num_pad) - (i - max_frame_num), 'circle': i - num_frames}[padding]
+        else:
+            pad_idx = i
+        indices.append(pad_idx)
+    return indices
+
+
+@torch.no_grad()
+def validate_clip(net, lq, gt=None, num_frame=5, padding='reflection_circle', batch=4, crop_border=0, test_y_channel=False):
+    """Restore every frame of one clip and (if `gt` is given) score it: what VideoBaseModel.dist_validation
+    (video_base_model.py:44-98) does frame by frame with a host round trip per frame.
+    lq: (t, c, h, w) low-quality frames on the GPU, gt: (t, c, H, W).  Returns (outputs (t, c, H, W), [PSNR per frame] or None)."""
+    t = lq.shape[0]
+    outs, scores = [], []
+    for s0 in range(0, t, batch):
+        idx = [generate_frame_indices(i, t, num_frame, padding) for i in range(s0, min(s0 + batch, t))]
+        windows = lq[torch.tensor(idx, device=lq.device)]  # (b, num_frame, c, h, w)
+        out = net(windows)
+        outs.append(out)
+        if gt is not None:
+            scores += calculate_psnr(out, gt[s0:s0 + out.shape[0]], crop_border, test_y_channel)
+    return torch.cat(outs, 0), (scores if gt is not None else None)

@@ -124,6 +124,20 @@ def psnr_case():
     torch.save(dict(pred=pred, gt=gt, cases=cases), os.path.join(OUT, 'psnr.pt'))
 
 
+def frame_indices_case():
+    """generate_frame_indices of the reference (basicsr/data/data_util.py:35-88), executed from its source text (the module
+    itself imports cv2 / lmdb helpers): every centre index of sequences of 7, 10 and 100 frames, 5- and 7-frame windows."""
+    import json
+    src = open('/root/reference/basicsr/data/data_util.py').read()
+    ns = {}
+    exec(src[src.index('def generate_frame_indices('):src.index('def paired_paths_from_lmdb(')], ns)
+    ref = ns['generate_frame_indices']
+    gold = {f'{pad}/{nf}/{T}': [ref(i, T, nf, pad) for i in range(T)]
+            for pad in ('replicate', 'reflection', 'reflection_circle', 'circle') for nf in (5, 7) for T in (7, 10, 100)}
+    with open(os.path.join(OUT, 'frame_indices.json'), 'w') as f:
+        json.dump(gold, f)
+
+
 def lr_sched_case():
     """Learning rates of the reference's own schedulers (basicsr/models/lr_scheduler.py) for two parameter groups."""
     import importlib.util
@@ -156,6 +170,7 @@ def main():
         torch.save(dcn1_case(name), os.path.join(OUT, f'dcn1_{name}.pt'))
     lr_sched_case()
     psnr_case()
+    frame_indices_case()
     for name in EDVR_CASES:
         torch.save(edvr_case(name), os.path.join(OUT, f'edvr_{name}.pt'))
     for f in sorted(os.listdir(OUT)):
