@@ -19,11 +19,14 @@
 //     bilinear cell is resolved ONCE and reused for the C/dg channels of the group (the reference
 //     re-reads them per channel), lanes run along the pixel axis so every column/offset access
 //     is a coalesced 256-B line;
-//   * the column x weight products run on the fp32 MFMA conv kernel of conv2d.hip (bias fused);
-//   * backward: one fused kernel produces dOffset, dMask, dX and rewrites the dY-columns
-//     buffer in place with the forward columns needed by dW (the reference runs three kernels
-//     and a 25-iteration window scan per column entry, .cu:677-691); dW is a deterministic
-//     split-K MFMA GEMM over the pixel axis.
+//   * forward: the EDVR signature (3x3, stride 1, pad 1, groups 1) never builds columns - dcn_fused.hip samples straight into
+//     the MFMA B operand; other signatures build columns here and run the column x weight product on the fp32 MFMA conv
+//     kernel of conv2d.hip (bias fused);
+//   * backward: one fused kernel produces dOffset, dMask, dX and rewrites the dY-columns buffer in place with the forward
+//     columns needed by dW (the reference runs three kernels and a 25-iteration window scan per column entry, .cu:677-691).
+//     dX is scattered either with device atomics or through a per-tile LDS window (scatter_hint), right-hand bilinear
+//     corners merged into the neighbouring lane by a DPP shift first.  The two plain GEMMs (dcol = W^T dY, dW = sum dY col^T,
+//     deterministic sum over the batch) run on rocBLAS (blas.hip); DCNv1 entry points at the end of the file reuse all of it.
 #include <cstdlib>
 
 #include "common.h"
@@ -318,26 +321,6 @@ __global__ __launch_bounds__(256) void dcn_bwd_coord_tile_kernel(const float *__
 #endif
     if (v != 0.f && gy >= 0 && gy < s.H && gx >= 0 && gx < s.W) unsafeAtomicAdd(gg + (int64_t)cc * plane + gy * s.W + gx, v);
   }
-}
-
-// ---------------------------------------------------------------------------------------------
-// row sums: out[r] = sum_{b, p} a[b, r, p]   (db)
-__global__ __launch_bounds__(256) void row_sum_kernel(const float *__restrict__ a, float *__restrict__ out, int nb, int rows,
-                                                      int64_t P, int64_t bstride) {
-  const int r = blockIdx.x;
-  float s = 0.f;
-  for (int b = 0; b < nb; ++b) {
-    const float *row = a + (int64_t)b * bstride + (int64_t)r * P;
-    for (int64_t p = threadIdx.x; p < P; p += 256) s += row[p];
-  }
-  __shared__ float red[256];
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) out[r] = red[0];
 }
 
 // ---------------------------------------------------------------------------------------------
