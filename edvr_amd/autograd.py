@@ -41,8 +41,12 @@ class ConvFn(Function):
             dz = ops.pixel_unshuffle2(ops.act_backward(dy, y, act) if act != ACT_NONE else dy)
         else:
             dz = ops.act_backward(dy, y, act, act_from, res1, res2) if act != ACT_NONE else dy
-        db = ops.channel_sum(dz) if (has_bias and need[3]) else None
-        dw = ops.conv2d_wgrad(x, x2, x2_map, dz, co, ks, stride) if need[2] else None
+        want_db = has_bias and need[3]
+        if need[2]:  # the weight-gradient launch produces the bias gradient as well
+            dw = ops.conv2d_wgrad(x, x2, x2_map, dz, co, ks, stride, want_db=want_db)
+            dw, db = dw if want_db else (dw, None)
+        else:
+            dw, db = None, (ops.channel_sum(dz) if want_db else None)
         dx = dx2 = None
         if need[0] or (x2 is not None and need[1]):
             c1 = x.shape[1]

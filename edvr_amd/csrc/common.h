@@ -45,7 +45,8 @@ int winograd_pack(const float *w, float *U, int co, int ci, int cop64, int cip, 
 int blas_gemm_rowmajor(const float *A, const float *B, float *C, int M, int N, int K, bool a_trans, bool b_trans, int64_t lda,
                        int64_t ldb, int64_t ldc, int64_t stride_a, int64_t stride_b, int64_t stride_c, int batch, hipStream_t stream);
 // wgrad.hip: out[i] (+)= sum_k ws[k * total + i]
-int reduce_partials_launch(const float *ws, float *out, int64_t total, int parts, int accumulate, hipStream_t stream);
+int reduce_partials_launch(const float *ws, float *out, int64_t total, int parts, int accumulate, hipStream_t stream,
+                           const float *ws2 = nullptr, float *out2 = nullptr, int total2 = 0, int parts2 = 0);  // second, small array in the same launch
 
 // winograd_wgrad.hip: weight gradient of the 3x3 / stride-1 conv in the Winograd domain.  plan() says whether the layer is
 // eligible and how many split-K partial pairs it writes; the partials ([2*splits][co][ci][9]) are summed by wgrad_reduce_kernel.
@@ -54,7 +55,7 @@ size_t winograd_wgrad_ws_bytes(int co, int ci, int splits);
 int winograd_wgrad_set_algo(int algo);
 int winograd_wgrad_launch(const float *x1, const float *x2, const float *dz, float *ws, int c1, int c2, int n, int h, int w, int co,
                           int64_t x1_img_stride, int64_t x2_img_stride, int x2_div, int x2_mul, int x2_add, int64_t dz_img_stride,
-                          int splits, hipStream_t stream);
+                          int splits, int want_db, hipStream_t stream);  // want_db: also [splits][co] partial sums of dz after the dW partials
 
 // dcn_fused.hip: column-buffer-free DCNv2 forward for the EDVR signature (3x3, stride 1, pad 1, dil 1, groups 1)
 bool dcn_fused_supported(int C, int Co, int kh, int kw, int stride, int pad, int dil, int groups, int dg);

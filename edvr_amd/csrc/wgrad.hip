@@ -238,7 +238,14 @@ __global__ void channel_sum_final_kernel(const float *__restrict__ part, float *
 
 // 16-byte version: the sum over up to 2 x 64 split-K partials is a pure streaming read (75 MB per trunk layer)
 __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float4 *__restrict__ ws, float4 *__restrict__ dw, int64_t total4, int splits,
-                                                            int accumulate) {
+                                                            int accumulate, const float *__restrict__ ws2, float *__restrict__ out2,
+                                                            int total2, int parts2) {
+  // optional second array (the bias-gradient partials [parts2][total2] of the Winograd weight gradient), summed by the first threads
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total2; i += gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < parts2; ++k) s += ws2[(int64_t)k * total2 + i];
+    out2[i] = s;
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
     float4 s = accumulate ? dw[i] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 8
@@ -253,11 +260,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float4 *__rest
   }
 }
 
-int reduce_partials_launch(const float *ws, float *out, int64_t total, int parts, int accumulate, hipStream_t stream) {
+int reduce_partials_launch(const float *ws, float *out, int64_t total, int parts, int accumulate, hipStream_t stream, const float *ws2,
+                           float *out2, int total2, int parts2) {
   if ((total & 3) == 0 && ((reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
     hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total / 4, 256), 2048)), dim3(256), 0, stream,
-                       reinterpret_cast<const float4 *>(ws), reinterpret_cast<float4 *>(out), total / 4, parts, accumulate);
+                       reinterpret_cast<const float4 *>(ws), reinterpret_cast<float4 *>(out), total / 4, parts, accumulate, ws2, out2,
+                       ws2 ? total2 : 0, parts2);
     return check_launch("wgrad_reduce4_kernel");
+  }
+  if (ws2) {  // (scalar fallback: the small array gets its own launch)
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total2, 256)), dim3(256), 0, stream, ws2, out2, (int64_t)total2, parts2, 0);
+    int rc = check_launch("wgrad_reduce_kernel");
+    if (rc) return rc;
   }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 2048)), dim3(256), 0, stream, ws, out, total,
                      parts, accumulate);
@@ -294,7 +308,7 @@ size_t edvr_conv2d_wgrad_ws_bytes(int n, int ci, int h, int w, int co, int ks, i
 
 int edvr_conv2d_wgrad_f32(const float *x1, const float *x2, const float *dz, float *dw, int c1, int c2, int n, int h, int w, int co,
                           int ks, int stride, int64_t x1_img_stride, int64_t x2_img_stride, int x2_div, int x2_mul, int x2_add,
-                          int64_t dz_img_stride, int accumulate, void *ws, size_t ws_bytes, edvr_stream_t stream_) {
+                          int64_t dz_img_stride, int accumulate, float *dbias, void *ws, size_t ws_bytes, edvr_stream_t stream_) {
   using namespace edvr;
   EDVR_REQUIRE(x1 && dz && dw && ws, "wgrad: null pointer");
   EDVR_REQUIRE((x2 != nullptr) == (c2 > 0), "wgrad: x2/c2 mismatch");
@@ -327,9 +341,11 @@ int edvr_conv2d_wgrad_f32(const float *x1, const float *x2, const float *dz, flo
   int wsplits = 0;
   if (winograd_wgrad_plan(n, c1, c2, h, w, co, ks, stride, &wsplits) && ws_bytes >= winograd_wgrad_ws_bytes(co, ci, wsplits)) {
     int rc = winograd_wgrad_launch(x1, x2, dz, a.ws, c1, c2, n, h, w, co, x1_img_stride, x2_img_stride, x2_div, x2_mul, x2_add,
-                                   dz_img_stride, wsplits, stream);
+                                   dz_img_stride, wsplits, dbias != nullptr, stream);
     if (rc) return rc;
-    return reduce_partials_launch(a.ws, dw, (int64_t)co * ci * 9, 2 * wsplits, accumulate, stream);
+    const int64_t total = (int64_t)co * ci * 9;  // the bias gradient rides on the same two launches (its partials follow dW's)
+    return reduce_partials_launch(a.ws, dw, total, 2 * wsplits, accumulate, stream, dbias ? a.ws + 2 * wsplits * total : nullptr, dbias, co,
+                                  wsplits);
   }
   dim3 grid(cdiv(ci, 32 * (4 / mw)), cdiv(co, 32 * mw), a.splits);
 #define EDVR_WGRAD_LAUNCH(KS_, ST_)                                                                                   \
@@ -344,7 +360,10 @@ int edvr_conv2d_wgrad_f32(const float *x1, const float *x2, const float *dz, flo
 #undef EDVR_WGRAD_LAUNCH
   int rc = check_launch("conv2d_wgrad_kernel");
   if (rc) return rc;
-  return reduce_partials_launch(a.ws, dw, (int64_t)co * ci * ks * ks, a.splits, accumulate, stream);
+  rc = reduce_partials_launch(a.ws, dw, (int64_t)co * ci * ks * ks, a.splits, accumulate, stream);
+  if (rc || !dbias) return rc;
+  // direct kernel: the bias gradient is a separate pass over dz (the workspace is free again)
+  return edvr_channel_sum_f32(dz, dbias, n, co, (int64_t)a.ho * a.wo, dz_img_stride, ws, ws_bytes, stream_);
 }
 
 int edvr_conv2d_wgrad_algo(int algo) {

@@ -26,7 +26,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct WinoWgradArgs {
   const float *x1, *x2, *dz;
-  float *ws;  // [2 * splits][co][ci][9]
+  float *ws;  // [2 * splits][co][ci][9], then (want_db) [splits][co] bias-gradient partials
+  int want_db;
   int c1, c2, n, h, w, co;
   int64_t x1_img_stride, x2_img_stride, dz_img_stride;
   int x2_div, x2_mul, x2_add;
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
   float pr[16];   // raw patch (channel chl, tile t) of the chunk being staged
   float tt[16];   // B^T d
   f32x2 dy[2][2]; // [chunk parity][row] 2x2 output-gradient tile of (channel chl, tile t)
+  float bsum = 0.f;  // bias gradient: sum of this thread's dY tiles (the values are in registers anyway)
   // Column c of the patch for chunk q (the geometry() state).  Columns 1 and 2 of a row are an 8-byte aligned pair (even x,
   // even w and h), both valid or both invalid: one 64-bit load, issued once both columns have been consumed (c == 2).
   auto load_col = [&](int c) {
@@ -169,9 +171,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
       dst[3 * 64] = s[1] - s[3];
     }
   };
+  float bvalid = 1.f;  // 0 once the chunk being committed lies beyond this split's range (its dY must not be counted)
   auto commit_z_row = [&](float *Zs, auto SET, int r) {  // row r of A dY A^T, A = [[1,0],[1,1],[1,-1],[0,-1]]
     constexpr int S = decltype(SET)::value;
     const float p = dy[S][0][0], qq = dy[S][0][1], u = dy[S][1][0], v = dy[S][1][1];
+    if (r == 0) bsum += bvalid * ((p + qq) + (u + v));
     // rows of A dY: (p, qq), (p + u, qq + v), (p - u, qq - v), (-u, -v)
     const float e = r == 0 ? p : r == 1 ? p + u : r == 2 ? p - u : -u;
     const float f = r == 0 ? qq : r == 1 ? qq + v : r == 2 ? qq - v : -v;
@@ -257,8 +261,19 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
 
 #pragma unroll 1
   for (int k = q0; k < q1; k += 2) {
-    iteration(S0{});
+    iteration(S0{});                     // commits chunk k + 1 (always inside the range: q1 - q0 is even)
+    bvalid = k + 2 < q1 ? 1.f : 0.f;     // the second one commits chunk k + 2
     iteration(S1{});
+  }
+
+  // ---- bias gradient partial of this split: sum over the 8 tiles a channel's lanes hold (lanes chl*8 + t), written by the
+  //      workgroups of input-channel block 0 only (every ci block saw the same dY)
+  if (a.want_db && ci_blk == 0) {
+    float s = bsum;
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (t == 0 && valid_co) (a.ws + (int64_t)2 * a.splits * a.co * ci_total * 9)[(int64_t)split * a.co + co_s] = s;
   }
 
   // ---- epilogue: this wave's share of dW = G^T dU G.  Row pass t[rr][jx] = (dU G)[2 ph + rr][jx], then the two rows
@@ -328,12 +343,15 @@ bool winograd_wgrad_plan(int n, int c1, int c2, int h, int w, int co, int ks, in
   return true;
 }
 
-size_t winograd_wgrad_ws_bytes(int co, int ci, int splits) { return (size_t)2 * splits * co * ci * 9 * sizeof(float); }
+size_t winograd_wgrad_ws_bytes(int co, int ci, int splits) {
+  return ((size_t)2 * splits * co * ci * 9 + (size_t)splits * co) * sizeof(float);  // dW partial pairs + bias-gradient partials
+}
 
 int winograd_wgrad_launch(const float *x1, const float *x2, const float *dz, float *ws, int c1, int c2, int n, int h, int w, int co,
                           int64_t x1_img_stride, int64_t x2_img_stride, int x2_div, int x2_mul, int x2_add, int64_t dz_img_stride,
-                          int splits, hipStream_t stream) {
+                          int splits, int want_db, hipStream_t stream) {
   WinoWgradArgs a;
+  a.want_db = want_db;
   a.x1 = x1; a.x2 = x2; a.dz = dz; a.ws = ws;
   a.c1 = c1; a.c2 = c2; a.n = n; a.h = h; a.w = w; a.co = co;
   a.x1_img_stride = x1_img_stride; a.x2_img_stride = x2_img_stride; a.dz_img_stride = dz_img_stride;

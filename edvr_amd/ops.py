@@ -330,9 +330,10 @@ def set_wgrad_algo(algo):
     return prev
 
 
-def conv2d_wgrad(x1, x2, x2_map, dz, co, ks, stride):
+def conv2d_wgrad(x1, x2, x2_map, dz, co, ks, stride, want_db=False):
     """dW (co, c1+c2, ks, ks) of the fused conv: Winograd-domain GEMM over tiles (3x3 / stride 1) or fp32 MFMA implicit GEMM
-    over the pixel axis."""
+    over the pixel axis.  want_db: also return db = sum of dz over (n, h, w) -> (dw, db); the Winograd-domain kernel produces it
+    in the same two launches."""
     require_gpu(x1, x2, dz)
     L = _lib.lib()
     x1, dz = _as_planes(x1), _as_planes(dz)
@@ -345,10 +346,11 @@ def conv2d_wgrad(x1, x2, x2_map, dz, co, ks, stride):
     dw = torch.empty(co, c1 + c2, ks, ks, dtype=torch.float32, device=x1.device)
     nbytes = L.edvr_conv2d_wgrad_ws_bytes(n, c1 + c2, h, w, co, ks, stride)
     ws = workspace(nbytes, x1.device)
+    db = torch.empty(co, dtype=torch.float32, device=x1.device) if want_db else None
     _lib.check(L.edvr_conv2d_wgrad_f32(_ptr(x1), _ptr(x2), _ptr(dz), _ptr(dw), c1, c2, n, h, w, co, ks, stride, _img_stride(x1),
-                                       _img_stride(x2) if x2 is not None else 0, div, mul, add, _img_stride(dz), 0, _ptr(ws), nbytes,
-                                       _stream()), 'edvr_conv2d_wgrad_f32')
-    return dw
+                                       _img_stride(x2) if x2 is not None else 0, div, mul, add, _img_stride(dz), 0, _ptr(db), _ptr(ws),
+                                       nbytes, _stream()), 'edvr_conv2d_wgrad_f32')
+    return (dw, db) if want_db else dw
 
 
 def channel_sum(x):

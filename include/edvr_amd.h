@@ -195,7 +195,10 @@ int edvr_abs_sum_f32(const float *x, float *out, int n, int64_t per_img, int64_t
 size_t edvr_conv2d_wgrad_ws_bytes(int n, int ci, int h, int w, int co, int ks, int stride);
 int edvr_conv2d_wgrad_f32(const float *x1, const float *x2, const float *dz, float *dw, int c1, int c2, int n, int h, int w,
                           int co, int ks, int stride, int64_t x1_img_stride, int64_t x2_img_stride, int x2_div, int x2_mul,
-                          int x2_add, int64_t dz_img_stride, int accumulate, void *ws, size_t ws_bytes, edvr_stream_t stream);
+                          int x2_add, int64_t dz_img_stride, int accumulate, float *dbias, void *ws, size_t ws_bytes,
+                          edvr_stream_t stream);
+/* dbias (nullable): also db[co] = sum_{n,pixel} dz (the bias gradient).  The Winograd-domain kernel holds every dz value in
+ * registers already and adds it to its two launches; the direct kernel runs edvr_channel_sum_f32 afterwards. */
 
 /* Algorithm request for edvr_conv2d_wgrad_f32 (process-wide; tests and benchmarks use it to run both kernels on the same
  * layer): EDVR_CONV_AUTO (default: Winograd-domain kernel where eligible and profitable), EDVR_CONV_DIRECT, or

@@ -35,13 +35,15 @@ def test_wgrad_matches_fp64_reference(gpu, case, algo):
     ref = torch.nn.grad.conv2d_weight(xcat.double(), (co, c1 + c2, 3, 3), dz.double(), padding=1)
     prev = ops.set_wgrad_algo({'winograd': ops.CONV_WINOGRAD, 'direct': ops.CONV_DIRECT, 'auto': ops.CONV_AUTO}[algo])
     try:
-        dw = ops.conv2d_wgrad(x1.to(gpu), x2.to(gpu) if c2 else None, x2_map, dz.to(gpu), co, 3, 1)
+        dw, db = ops.conv2d_wgrad(x1.to(gpu), x2.to(gpu) if c2 else None, x2_map, dz.to(gpu), co, 3, 1, want_db=True)
         dw2 = ops.conv2d_wgrad(x1.to(gpu), x2.to(gpu) if c2 else None, x2_map, dz.to(gpu), co, 3, 1)
     finally:
         ops.set_wgrad_algo(prev)
     assert torch.equal(dw, dw2), 'split-K reduction must be deterministic'
     err = (dw.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
     assert err < 2e-5, err
+    ref_db = dz.double().sum((0, 2, 3))  # the bias gradient produced by the same launches
+    assert (db.cpu().double() - ref_db).abs().max().item() <= 2e-5 * max(1.0, ref_db.abs().max().item()) + 1e-6 * (n * h * w) ** 0.5
 
 
 def test_wgrad_algo_setter_rejects_unknown(gpu):
