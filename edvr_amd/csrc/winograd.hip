@@ -288,6 +288,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_kernel(const WinoArgs
     // Row pass (M A)[row][.] = (m0 + m1 + m2, m1 - m2 - m3) of the row to send (tiles 0-3), one accumulator tile at a
     // time: hipcc moves a tile out of the accumulator file as a whole 16-register tuple, so walking channel by channel
     // (8 tiles live at once) needs 128 VGPRs and spilled ~150 registers to scratch per item.
+#ifdef WINO_EXP_NOEPI  /* ablation only: no output transform / exchange / stores; accumulators kept alive without instructions */
+#pragma unroll
+    for (int xi = 0; xi < 8; ++xi) asm volatile("" ::"v"(acc[xi]));
+    load_begin(CK);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) load_col(c);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) load_u(g);
+#else
     // bias now, residuals right after the row pass (when the accumulators are dead): their latency hides behind the
     // transform and the exchange instead of being exposed once per batch of stores
     float bias_r[16];
@@ -446,6 +455,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_kernel(const WinoArgs
     } else {
       if (interior) emit(F{}, F{}, F{}, T{}); else emit(F{}, F{}, F{}, F{});
     }
+#endif  // WINO_EXP_NOEPI
 #pragma unroll
     for (int xi = 0; xi < 8; ++xi)
 #pragma unroll
