@@ -41,6 +41,10 @@ int winograd_launch(const edvr_conv2d_desc &d, const float *U, int cop64, hipStr
 int winograd_pack(const float *w, float *U, int co, int ci, int cop64, int cip, int transpose_flip, float *wpk_direct, int cop32,
                   hipStream_t stream);  // wpk_direct != nullptr: also writes the direct layout [cip][9][cop32] in the same launch
 
+// conv_small.hip: 3x3 / stride-1 conv with <= 4 output channels on the vector ALUs (EDVR's conv_last)
+bool conv_small_eligible(const edvr_conv2d_desc &d);
+int conv_small_launch(const edvr_conv2d_desc &d, hipStream_t stream);
+
 // blas.hip: row-major strided-batched fp32 GEMM on rocBLAS (plain GEMMs only: the DCNv2 backward's dcol and dW)
 int blas_gemm_rowmajor(const float *A, const float *B, float *C, int M, int N, int K, bool a_trans, bool b_trans, int64_t lda,
                        int64_t ldb, int64_t ldc, int64_t stride_a, int64_t stride_b, int64_t stride_c, int batch, hipStream_t stream);

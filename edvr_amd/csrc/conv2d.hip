@@ -348,6 +348,7 @@ int conv2d_launch(const edvr_conv2d_desc &d, hipStream_t stream) {
   a.wo = (d.w + 2 * pad - d.ks) / d.stride + 1;
   a.tiles_x = a.tiles_y = 0;
   a.co_start = 0;
+  if (conv_small_eligible(d)) return conv_small_launch(d, stream);
   if (winograd_eligible(d)) return winograd_launch(d, d.wpk + direct_packed_elems(d.co, a.ci, 3), round_up(d.co, 64), stream);
   if (d.ks == 3 && d.stride == 1) return launch_mt<3, 1>(a, stream);
   if (d.ks == 3 && d.stride == 2) return launch_mt<3, 2>(a, stream);
@@ -381,6 +382,10 @@ int edvr_conv2d_kernel_name(const edvr_conv2d_desc *d, char *buf, size_t buf_len
   EDVR_REQUIRE(d && buf && buf_len > 0, "kernel_name: bad arguments");
   const int pad = d->ks / 2;
   const int ho = (d->h + 2 * pad - d->ks) / d->stride + 1, wo = (d->w + 2 * pad - d->ks) / d->stride + 1;
+  if (edvr::conv_small_eligible(*d)) {
+    snprintf(buf, buf_len, "conv3x3_smallco_kernel");
+    return EDVR_OK;
+  }
   if (edvr::winograd_eligible(*d)) {
     snprintf(buf, buf_len, "conv3x3_winograd_kernel");
     return EDVR_OK;

@@ -33,16 +33,19 @@ CASES = [
     (1, 16, 16, 10, 50, 64, 3, 1, 'relu', 0, 0),            # winograd: concat input
     (1, 48, 0, 8, 36, 128, 3, 1, 'lrelu', 0, 1),            # winograd: pixel-shuffle epilogue
     (1, 32, 0, 9, 33, 216, 3, 1, 'sigmoid_from', 0, 0),     # winograd: sigmoid-from-channel epilogue, odd width
+    (2, 64, 0, 37, 131, 3, 3, 1, 'none', 0, 0),             # auto: <= 4 output channels -> VALU kernel (conv_last), ragged tiles
+    (1, 24, 40, 9, 70, 4, 3, 1, 'lrelu', 1, 0),             # auto: VALU kernel, concat input, 64 channels in 8-chunks, residual
+    (3, 20, 0, 5, 3, 1, 3, 1, 'relu', 0, 0),                # auto: VALU kernel, one output channel, channel count not a multiple of 8
     (2, 216, 0, 12, 40, 128, 3, 1, 'none', 0, 0),           # winograd: ci not a multiple of 16 (data gradient of the offset conv)
     (1, 100, 20, 8, 34, 64, 3, 1, 'lrelu', 1, 0),           # winograd: concat boundary inside a chunk, 120 -> 128 padded channels
 ]
 
 
-@pytest.mark.parametrize('algo', ['direct', 'winograd'])
+@pytest.mark.parametrize('algo', ['direct', 'winograd', 'auto'])
 @pytest.mark.parametrize('case', CASES)
 def test_conv2d_matches_fp64(gpu, case, algo):
     from edvr_amd import ops
-    algo = {'direct': ops.CONV_DIRECT, 'winograd': ops.CONV_WINOGRAD}[algo]  # winograd falls back where not applicable
+    algo = {'direct': ops.CONV_DIRECT, 'winograd': ops.CONV_WINOGRAD, 'auto': ops.CONV_AUTO}[algo]  # winograd falls back where not applicable
     n, c1, c2, h, w, co, ks, stride, actn, nres, out_mode = case
     g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
     x1 = torch.randn(n, c1, h, w, generator=g)
