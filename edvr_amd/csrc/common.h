@@ -44,6 +44,10 @@ int winograd_pack(const float *w, float *U, int co, int ci, int cop64, int cip, 
 // conv_small.hip: 3x3 / stride-1 conv with <= 4 output channels on the vector ALUs (EDVR's conv_last)
 bool conv_small_eligible(const edvr_conv2d_desc &d);
 int conv_small_launch(const edvr_conv2d_desc &d, hipStream_t stream);
+bool wgrad_small_plan(int n, int c1, int c2, int h, int w, int co, int ks, int stride, int *splits);
+size_t wgrad_small_ws_bytes(int co, int ci, int splits);
+int wgrad_small_launch(const float *x, const float *dz, float *ws, int ci, int co, int n, int h, int w, int64_t x_img_stride,
+                       int64_t dz_img_stride, int splits, hipStream_t stream);
 
 // blas.hip: row-major strided-batched fp32 GEMM on rocBLAS (plain GEMMs only: the DCNv2 backward's dcol and dW)
 int blas_gemm_rowmajor(const float *A, const float *B, float *C, int M, int N, int K, bool a_trans, bool b_trans, int64_t lda,
@@ -57,6 +61,7 @@ int reduce_partials_launch(const float *ws, float *out, int64_t total, int parts
 bool winograd_wgrad_plan(int n, int c1, int c2, int h, int w, int co, int ks, int stride, int *splits);
 size_t winograd_wgrad_ws_bytes(int co, int ci, int splits);
 int winograd_wgrad_set_algo(int algo);
+int winograd_wgrad_get_algo();
 int winograd_wgrad_launch(const float *x1, const float *x2, const float *dz, float *ws, int c1, int c2, int n, int h, int w, int co,
                           int64_t x1_img_stride, int64_t x2_img_stride, int x2_div, int x2_mul, int x2_add, int64_t dz_img_stride,
                           int splits, int want_db, hipStream_t stream);  // want_db: also [splits][co] partial sums of dz after the dW partials

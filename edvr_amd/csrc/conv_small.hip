@@ -105,4 +105,121 @@ int conv_small_launch(const edvr_conv2d_desc &d, hipStream_t stream) {
   return check_launch("conv3x3_smallco_kernel");
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the same layers (co <= 4): dW[co][ci][tap] = sum_{n, pixel} dz[co][pixel] * x[ci][pixel + tap].  The direct
+// MFMA kernel pads co to 32 (2.6 ms for conv_last at 32 x 64 x 256 x 256, 1.4 % of the training step).  Here a thread owns one input
+// channel and one row of a 4 x 32 pixel tile and keeps its co x 9 partial sums in registers while its workgroup walks a range of
+// tiles (split-K over tiles, partials reduced by reduce_partials_launch); x tile + halo in LDS with an odd channel stride, the
+// dz values are LDS broadcasts.
+struct SmallCoWgradArgs {
+  const float *x, *dz;
+  float *ws;  // [splits][co][ci][9]
+  int ci, co, n, h, w;
+  int64_t x_img_stride, dz_img_stride;
+  int tiles_x, tiles_y, tiles, splits;
+};
+
+__global__ __launch_bounds__(256) void wgrad3x3_smallco_kernel(const SmallCoWgradArgs a) {
+  constexpr int TH = 4, TW = 32, IH = TH + 2, IW = TW + 2, CHS = IH * IW + 1;  // 205: odd channel stride, lanes = channels
+  __shared__ float xs[64 * CHS];
+  __shared__ float zs[4 * TH * TW];
+  const int tid = threadIdx.x, cl = tid & 63, q = tid >> 6;  // channel of the 64-block, tile row
+  const int ci0 = blockIdx.y * 64, split = blockIdx.x;
+  const int t_begin = (int)((int64_t)a.tiles * split / a.splits), t_end = (int)((int64_t)a.tiles * (split + 1) / a.splits);
+  const int hw = a.h * a.w;
+  float acc[4][9];
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[o][t] = 0.f;
+
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int img = tile / (a.tiles_x * a.tiles_y), tr = tile - img * (a.tiles_x * a.tiles_y);
+    const int ty0 = (tr / a.tiles_x) * TH, tx0 = (tr % a.tiles_x) * TW;
+    const float *xi = a.x + (int64_t)img * a.x_img_stride;
+    const float *zi = a.dz + (int64_t)img * a.dz_img_stride;
+    __syncthreads();  // previous tile fully consumed
+    for (int i = tid; i < 64 * IH * IW; i += 256) {  // lanes along x: coalesced rows
+      const int ch = i / (IH * IW), rem = i - ch * (IH * IW), r = rem / IW, col = rem - r * IW;
+      const int c = ci0 + ch, gy = ty0 - 1 + r, gx = tx0 - 1 + col;
+      xs[ch * CHS + r * IW + col] = (c < a.ci && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w) ? xi[(int64_t)c * hw + gy * a.w + gx] : 0.f;
+    }
+    for (int i = tid; i < 4 * TH * TW; i += 256) {
+      const int o = i / (TH * TW), rem = i - o * (TH * TW), r = rem / TW, col = rem - r * TW;
+      const int gy = ty0 + r, gx = tx0 + col;
+      zs[i] = (o < a.co && gy < a.h && gx < a.w) ? zi[(int64_t)o * hw + gy * a.w + gx] : 0.f;
+    }
+    __syncthreads();
+    // this thread: channel cl, output row q of the tile; slide along x with a 3-column window of its three input rows
+    const float *xr = xs + cl * CHS + q * IW;
+    float w0[3], w1[3], w2[3];  // columns px-1, px, px+1 of rows q, q+1, q+2 (halo coordinates)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      w0[r] = xr[r * IW + 0];
+      w1[r] = xr[r * IW + 1];
+    }
+#pragma unroll 4
+    for (int px = 0; px < TW; ++px) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) w2[r] = xr[r * IW + px + 2];
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const float z = zs[(o * TH + q) * TW + px];  // wave-uniform address: LDS broadcast
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          acc[o][r * 3 + 0] += z * w0[r];
+          acc[o][r * 3 + 1] += z * w1[r];
+          acc[o][r * 3 + 2] += z * w2[r];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        w0[r] = w1[r];
+        w1[r] = w2[r];
+      }
+    }
+  }
+  // reduce the four tile rows (one wave each) through LDS, then one partial per (split, co, ci, tap)
+  __syncthreads();
+  float *red = xs;  // 4 x 64 x 36 floats
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) red[(q * 64 + cl) * 37 + o * 9 + t] = acc[o][t];
+  __syncthreads();
+  const int ci_total = a.ci;
+  for (int i = tid; i < 64 * 36; i += 256) {
+    const int ch = i / 36, k = i - ch * 36, o = k / 9, t = k - o * 9;
+    const int c = ci0 + ch;
+    if (c < ci_total && o < a.co) {
+      const float s = (red[(0 * 64 + ch) * 37 + k] + red[(1 * 64 + ch) * 37 + k]) + (red[(2 * 64 + ch) * 37 + k] + red[(3 * 64 + ch) * 37 + k]);
+      a.ws[((int64_t)split * a.co + o) * ci_total * 9 + (int64_t)c * 9 + t] = s;
+    }
+  }
+}
+
+bool wgrad_small_plan(int n, int c1, int c2, int h, int w, int co, int ks, int stride, int *splits) {
+  if (ks != 3 || stride != 1 || co > 4 || c2 != 0) return false;
+  const int tiles = n * cdiv(h, 4) * cdiv(w, 32);
+  *splits = std::max(1, std::min(tiles, 512 / cdiv(c1, 64)));
+  return true;
+}
+
+size_t wgrad_small_ws_bytes(int co, int ci, int splits) { return (size_t)splits * co * ci * 9 * sizeof(float); }
+
+int wgrad_small_launch(const float *x, const float *dz, float *ws, int ci, int co, int n, int h, int w, int64_t x_img_stride,
+                       int64_t dz_img_stride, int splits, hipStream_t stream) {
+  SmallCoWgradArgs a;
+  a.x = x; a.dz = dz; a.ws = ws;
+  a.ci = ci; a.co = co; a.n = n; a.h = h; a.w = w;
+  a.x_img_stride = x_img_stride; a.dz_img_stride = dz_img_stride;
+  a.tiles_x = cdiv(w, 32);
+  a.tiles_y = cdiv(h, 4);
+  a.tiles = n * a.tiles_x * a.tiles_y;
+  a.splits = splits;
+  hipLaunchKernelGGL(wgrad3x3_smallco_kernel, dim3(splits, cdiv(ci, 64)), dim3(256), 0, stream, a);
+  return check_launch("wgrad3x3_smallco_kernel");
+}
+
 }  // namespace edvr

@@ -295,6 +295,8 @@ static int wgrad_splits(int tiles, int units) {
 extern "C" {
 
 size_t edvr_conv2d_wgrad_ws_bytes(int n, int ci, int h, int w, int co, int ks, int stride) {
+  int ssplits = 0;
+  const size_t small = edvr::wgrad_small_plan(n, ci, 0, h, w, co, ks, stride, &ssplits) ? edvr::wgrad_small_ws_bytes(co, ci, ssplits) + 64 * co * 4 : 0;
   int wsplits = 0;  // NOTE: c1/c2 are not known here; plan with c2 = 0 (the c1 % 64 rule is re-checked at launch time and
                     // the direct kernel's need, computed below, is the larger of the two for every EDVR layer anyway)
   size_t wino = edvr::winograd_wgrad_plan(n, ci, 0, h, w, co, ks, stride, &wsplits) ? edvr::winograd_wgrad_ws_bytes(co, ci, wsplits) : 0;
@@ -303,7 +305,7 @@ size_t edvr_conv2d_wgrad_ws_bytes(int n, int ci, int h, int w, int co, int ks, i
   const int units = n * edvr::cdiv(ho, 2) * edvr::cdiv(wo, 32);
   const int mw = edvr::wgrad_mw(co, stride);
   const int tiles = edvr::cdiv(ci, 32 * (4 / mw)) * edvr::cdiv(co, 32 * mw);
-  return std::max(wino, (size_t)edvr::wgrad_splits(tiles, units) * co * ci * ks * ks * sizeof(float));
+  return std::max(std::max(wino, small), (size_t)edvr::wgrad_splits(tiles, units) * co * ci * ks * ks * sizeof(float));  // any algorithm
 }
 
 int edvr_conv2d_wgrad_f32(const float *x1, const float *x2, const float *dz, float *dw, int c1, int c2, int n, int h, int w, int co,
@@ -338,6 +340,15 @@ int edvr_conv2d_wgrad_f32(const float *x1, const float *x2, const float *dz, flo
     return EDVR_ERR_WORKSPACE;
   }
   hipStream_t stream = as_stream(stream_);
+  int ssplits = 0;
+  if (winograd_wgrad_get_algo() == EDVR_CONV_AUTO && wgrad_small_plan(n, c1, c2, h, w, co, ks, stride, &ssplits) &&
+      ws_bytes >= wgrad_small_ws_bytes(co, ci, ssplits)) {  // <= 4 output channels (conv_last): VALU kernel (conv_small.hip)
+    int rc = wgrad_small_launch(x1, dz, a.ws, ci, co, n, h, w, x1_img_stride, dz_img_stride, ssplits, stream);
+    if (rc) return rc;
+    rc = reduce_partials_launch(a.ws, dw, (int64_t)co * ci * 9, ssplits, accumulate, stream);
+    if (rc || !dbias) return rc;
+    return edvr_channel_sum_f32(dz, dbias, n, co, (int64_t)a.ho * a.wo, dz_img_stride, ws, ws_bytes, stream_);
+  }
   int wsplits = 0;
   if (winograd_wgrad_plan(n, c1, c2, h, w, co, ks, stride, &wsplits) && ws_bytes >= winograd_wgrad_ws_bytes(co, ci, wsplits)) {
     int rc = winograd_wgrad_launch(x1, x2, dz, a.ws, c1, c2, n, h, w, co, x1_img_stride, x2_img_stride, x2_div, x2_mul, x2_add,

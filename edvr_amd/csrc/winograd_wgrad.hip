@@ -315,6 +315,7 @@ static int wino_wgrad_cus() {
 }
 
 static int g_wgrad_algo = EDVR_CONV_AUTO;
+int winograd_wgrad_get_algo() { return g_wgrad_algo; }
 int winograd_wgrad_set_algo(int algo) {
   const int prev = g_wgrad_algo;
   g_wgrad_algo = algo;

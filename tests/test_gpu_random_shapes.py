@@ -75,7 +75,7 @@ def test_winograd_wgrad_equals_direct_on_random_shapes(gpu, case):
     x2 = torch.randn(n, c2, h, w, generator=g).to(gpu) if c2 else None
     dz = torch.randn(n, co, h, w, generator=g).to(gpu)
     out = {}
-    for name, algo in (('direct', ops.CONV_DIRECT), ('winograd', ops.CONV_WINOGRAD)):
+    for name, algo in (('direct', ops.CONV_DIRECT), ('winograd', ops.CONV_WINOGRAD), ('auto', ops.CONV_AUTO)):
         prev = ops.set_wgrad_algo(algo)
         try:
             out[name] = ops.conv2d_wgrad(x1, x2, None, dz, co, 3, 1, want_db=True)
@@ -84,3 +84,6 @@ def test_winograd_wgrad_equals_direct_on_random_shapes(gpu, case):
     (dw_d, db_d), (dw_w, db_w) = out['direct'], out['winograd']
     assert ((dw_w - dw_d).abs().max() / dw_d.abs().max().clamp_min(1e-30)).item() < 3e-5
     assert ((db_w - db_d).abs().max() / db_d.abs().max().clamp_min(1.0)).item() < 3e-5
+    dw_a, db_a = out['auto']  # AUTO may pick the VALU kernel (co <= 4), the Winograd-domain kernel or the direct one
+    assert ((dw_a - dw_d).abs().max() / dw_d.abs().max().clamp_min(1e-30)).item() < 3e-5
+    assert ((db_a - db_d).abs().max() / db_d.abs().max().clamp_min(1.0)).item() < 3e-5

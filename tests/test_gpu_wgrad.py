@@ -14,6 +14,9 @@ CASES = [  # n, c1, c2, h, w, co, x2_map
     (6, 64, 64, 16, 16, 64, (3, 1, 0)),  # x2 is a broadcast reference frame: image i of x2 is i // 3
     (5, 192, 0, 12, 20, 216, None),      # 3 ci blocks x 4 co blocks (the offset-conv shape)
     (32, 128, 0, 64, 64, 128, None),     # EDVR-L training trunk layer at full size
+    (2, 64, 0, 20, 44, 3, None),         # auto: <= 4 output channels -> VALU kernel (conv_last), ragged 4 x 32 tiles
+    (3, 100, 0, 7, 9, 4, None),          # auto: VALU kernel, two 64-channel blocks (second partial), tiny image
+    (8, 64, 0, 256, 256, 3, None),       # conv_last at the training resolution
 ]
 
 
