@@ -196,10 +196,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
     using Other = std::integral_constant<int, 1 - P>;
     const float *Zs = smem + P * 2 * SLAB, *Vs = Zs + SLAB;
     float *Zd = smem + (1 - P) * 2 * SLAB, *Vd = Zd + SLAB;
-#ifndef WW_EXP_NOGEOM
-    advance();
-    geometry();
-#endif
     float av[2][4], bv[2][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -230,6 +226,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
       }
       __builtin_amdgcn_sched_barrier(0);  // pin the slice schedule (see winograd.hip)
     }
+    // geometry of the NEXT iteration's loads, here rather than at the top of the iteration: the scalar chain (pointer
+    // arithmetic, resource words, validity masks) then runs under the MFMAs of the last group instead of in front of an idle
+    // matrix pipe right after the barrier (ablation: 8 % of the kernel)
+#ifndef WW_EXP_NOGEOM
+    advance();
+    geometry();
+#endif
     // LDS-only barrier: the loads just issued target registers and need no cross-wave ordering
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
@@ -253,6 +256,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
   load_dy(S1{});
 #pragma unroll
   for (int c = 0; c < 4; ++c) load_col(c);
+  advance();
+  geometry();  // chunk q0 + 2: loaded by the first iteration (each iteration prepares the next one's geometry at its end)
 #pragma unroll
   for (int xi = 0; xi < 8; ++xi)
 #pragma unroll
