@@ -4,7 +4,7 @@
 // core: the smallest MFMA tile is 32 output channels wide, so the direct kernel spends 29/32 of its MFMAs on padding (1.19 ms,
 // 10 TF/s of useful work).  1728 multiply-adds per pixel are nothing for the VALUs: each thread owns two horizontally adjacent
 // pixels x all (<= 4) output channels, the input halo tile of 8 channels sits in LDS (every LDS value feeds 3 taps x 2 pixels
-// x co FMAs), the weights are wave-uniform and come through the scalar cache.  HBM-bound: reads 4 Ci B, writes 4 Co B per pixel.
+// x co FMAs), the weights of the chunk sit in LDS too (broadcast reads).  HBM-bound: reads 4 Ci B, writes 4 Co B per pixel.
 #include "common.h"
 
 namespace edvr {
@@ -20,6 +20,9 @@ struct SmallCoArgs {
 __global__ __launch_bounds__(256) void conv3x3_smallco_kernel(const SmallCoArgs a) {
   constexpr int TH = 8, TW = 64, CKS = 8, IH = TH + 2, IW = TW + 2, RS = 68;  // RS even: the 64-bit LDS reads stay aligned
   __shared__ __attribute__((aligned(16))) float xs[CKS * IH * RS];
+  // the chunk's weights, one 16-byte record per (channel, tap): read back as LDS broadcasts.  (Through the scalar cache every
+  // s_load shares lgkmcnt with the LDS reads and is waited with lgkmcnt(0): PMC showed the waves 78 % of the time in s_waitcnt.)
+  __shared__ f32x4 wl[CKS * 9];
   const edvr_conv2d_desc &d = a.d;
   const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
   int tile, unused, img;
@@ -35,21 +38,33 @@ __global__ __launch_bounds__(256) void conv3x3_smallco_kernel(const SmallCoArgs 
   f32x2 acc[4];
 #pragma unroll
   for (int o = 0; o < 4; ++o) acc[o] = f32x2{0.f, 0.f};
+  // the halo positions this thread stages (the same for every channel): 660 positions / 256 threads = up to 3, resolved once
+  // per tile - with the index arithmetic inside the channel loop the staging cost twice the FMAs
+  constexpr int NPOS = (IH * IW + 255) / 256;
+  int g_off[NPOS], l_off[NPOS];  // element offset inside a channel plane (-1: zero padding / no position), offset inside an LDS plane
+#pragma unroll
+  for (int k = 0; k < NPOS; ++k) {
+    const int p = tid + k * 256, r = p / IW, col = p - r * IW;
+    const int gy = ty0 - 1 + r, gx = tx0 - 1 + col;
+    l_off[k] = p < IH * IW ? r * RS + col : -1;
+    g_off[k] = (p < IH * IW && gy >= 0 && gy < d.h && gx >= 0 && gx < d.w) ? gy * d.w + gx : -1;
+  }
 
   for (int c0 = 0; c0 < a.ci; c0 += CKS) {
     // stage the halo tile of 8 channels (zero outside the image and past the last channel): lanes along x
-    for (int i = tid; i < CKS * IH * IW; i += 256) {
-      const int ch = i / (IH * IW), rem = i - ch * (IH * IW), r = rem / IW, col = rem - r * IW;
-      const int c = c0 + ch, gy = ty0 - 1 + r, gx = tx0 - 1 + col;
-      float v = 0.f;
-      if (c < a.ci && gy >= 0 && gy < d.h && gx >= 0 && gx < d.w)
-        v = (c < d.c1 ? x1 + (int64_t)c * hw : x2 + (int64_t)(c - d.c1) * hw)[gy * d.w + gx];
-      xs[(ch * IH + r) * RS + col] = v;
+#pragma unroll
+    for (int ch = 0; ch < CKS; ++ch) {
+      const int c = c0 + ch;
+      const float *plane = c < d.c1 ? x1 + (int64_t)c * hw : x2 + (int64_t)(c - d.c1) * hw;  // wave-uniform
+#pragma unroll
+      for (int k = 0; k < NPOS; ++k)
+        if (l_off[k] >= 0) xs[ch * IH * RS + l_off[k]] = (c < a.ci && g_off[k] >= 0) ? plane[g_off[k]] : 0.f;
     }
+    if (tid < CKS * 9)  // packed direct layout [ci_pad16][9][cop]: channels past ci are zero rows there
+      wl[tid] = *reinterpret_cast<const f32x4 *>(d.wpk + ((int64_t)(c0 + tid / 9) * 9 + tid % 9) * a.cop);
     __syncthreads();
 #pragma unroll
     for (int ch = 0; ch < CKS; ++ch) {
-      const float *wrow = d.wpk + (int64_t)(c0 + ch) * 9 * a.cop;  // packed direct layout [ci_pad16][9][cop]: wave-uniform
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         const float *row = xs + (ch * IH + ty + r) * RS + 2 * tx;
@@ -57,7 +72,7 @@ __global__ __launch_bounds__(256) void conv3x3_smallco_kernel(const SmallCoArgs 
         const float v[4] = {v01[0], v01[1], v23[0], v23[1]};
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-          const f32x4 w = *reinterpret_cast<const f32x4 *>(wrow + (r * 3 + kx) * a.cop);
+          const f32x4 w = wl[ch * 9 + r * 3 + kx];
           const f32x2 xv = f32x2{v[kx], v[kx + 1]};
 #pragma unroll
           for (int o = 0; o < 4; ++o) acc[o] += w[o] * xv;  // v_pk_fma_f32: both pixels at once
@@ -140,10 +155,19 @@ __global__ __launch_bounds__(256) void wgrad3x3_smallco_kernel(const SmallCoWgra
     const float *xi = a.x + (int64_t)img * a.x_img_stride;
     const float *zi = a.dz + (int64_t)img * a.dz_img_stride;
     __syncthreads();  // previous tile fully consumed
-    for (int i = tid; i < 64 * IH * IW; i += 256) {  // lanes along x: coalesced rows
-      const int ch = i / (IH * IW), rem = i - ch * (IH * IW), r = rem / IW, col = rem - r * IW;
-      const int c = ci0 + ch, gy = ty0 - 1 + r, gx = tx0 - 1 + col;
-      xs[ch * CHS + r * IW + col] = (c < a.ci && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w) ? xi[(int64_t)c * hw + gy * a.w + gx] : 0.f;
+    {  // lanes along x: coalesced rows.  (channel, position) advance incrementally: i += 256 is +1 channel and +52 positions
+      int ch = tid / (IH * IW), rem = tid - ch * (IH * IW);
+      for (int i = tid; i < 64 * IH * IW; i += 256) {
+        const int r = rem / IW, col = rem - r * IW;
+        const int c = ci0 + ch, gy = ty0 - 1 + r, gx = tx0 - 1 + col;
+        xs[ch * CHS + rem] = (c < a.ci && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w) ? xi[(int64_t)c * hw + gy * a.w + gx] : 0.f;
+        rem += 256 - IH * IW;
+        ch += 1;
+        if (rem >= IH * IW) {
+          rem -= IH * IW;
+          ch += 1;
+        }
+      }
     }
     for (int i = tid; i < 4 * TH * TW; i += 256) {
       const int o = i / (TH * TW), rem = i - o * (TH * TW), r = rem / TW, col = rem - r * TW;
