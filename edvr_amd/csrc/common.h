@@ -49,6 +49,10 @@ size_t wgrad_small_ws_bytes(int co, int ci, int splits);
 int wgrad_small_launch(const float *x, const float *dz, float *ws, int ci, int co, int n, int h, int w, int64_t x_img_stride,
                        int64_t dz_img_stride, int splits, hipStream_t stream);
 
+// conv1x1.hip: 1x1 conv as a streaming GEMM (B operand straight from global memory)
+bool conv1x1_eligible(const edvr_conv2d_desc &d);
+int conv1x1_launch(const edvr_conv2d_desc &d, hipStream_t stream);
+
 // blas.hip: row-major strided-batched fp32 GEMM on rocBLAS (plain GEMMs only: the DCNv2 backward's dcol and dW)
 int blas_gemm_rowmajor(const float *A, const float *B, float *C, int M, int N, int K, bool a_trans, bool b_trans, int64_t lda,
                        int64_t ldb, int64_t ldc, int64_t stride_a, int64_t stride_b, int64_t stride_c, int batch, hipStream_t stream);

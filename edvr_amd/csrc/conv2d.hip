@@ -352,6 +352,7 @@ int conv2d_launch(const edvr_conv2d_desc &d, hipStream_t stream) {
   if (winograd_eligible(d)) return winograd_launch(d, d.wpk + direct_packed_elems(d.co, a.ci, 3), round_up(d.co, 64), stream);
   if (d.ks == 3 && d.stride == 1) return launch_mt<3, 1>(a, stream);
   if (d.ks == 3 && d.stride == 2) return launch_mt<3, 2>(a, stream);
+  if (conv1x1_eligible(d)) return conv1x1_launch(d, stream);
   return launch_mt<1, 1>(a, stream);
 }
 
@@ -388,6 +389,10 @@ int edvr_conv2d_kernel_name(const edvr_conv2d_desc *d, char *buf, size_t buf_len
   }
   if (edvr::winograd_eligible(*d)) {
     snprintf(buf, buf_len, "conv3x3_winograd_kernel");
+    return EDVR_OK;
+  }
+  if (edvr::conv1x1_eligible(*d)) {
+    snprintf(buf, buf_len, "conv1x1_stream_kernel");
     return EDVR_OK;
   }
   const int mt = d->co >= 128 ? 4 : edvr::cdiv(d->co, 32);  // the launch carrying most of the work

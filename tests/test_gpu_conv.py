@@ -36,6 +36,9 @@ CASES = [
     (2, 64, 0, 37, 131, 3, 3, 1, 'none', 0, 0),             # auto: <= 4 output channels -> VALU kernel (conv_last), ragged tiles
     (1, 24, 40, 9, 70, 4, 3, 1, 'lrelu', 1, 0),             # auto: VALU kernel, concat input, 64 channels in 8-chunks, residual
     (3, 20, 0, 5, 3, 1, 3, 1, 'relu', 0, 0),                # auto: VALU kernel, one output channel, channel count not a multiple of 8
+    (2, 64, 64, 9, 13, 128, 1, 1, 'relu', 0, 0),            # 1x1 streaming kernel: concat input, 117 pixels (ragged 32-pixel groups)
+    (1, 640, 0, 20, 36, 128, 1, 1, 'lrelu', 2, 0),          # 1x1 streaming kernel: TSA feat_fusion shape (5 x 128 channels), two residuals
+    (3, 160, 0, 7, 5, 40, 1, 1, 'sigmoid_from', 0, 0),      # 1x1 streaming kernel: 2.5 weight slabs, 2-tile tail launch only
     (2, 216, 0, 12, 40, 128, 3, 1, 'none', 0, 0),           # winograd: ci not a multiple of 16 (data gradient of the offset conv)
     (1, 100, 20, 8, 34, 64, 3, 1, 'lrelu', 1, 0),           # winograd: concat boundary inside a chunk, 120 -> 128 padded channels
 ]
