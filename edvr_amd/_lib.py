@@ -21,7 +21,7 @@ class ConvDesc(ctypes.Structure):
         ('x2_div', i32), ('x2_mul', i32), ('x2_add', i32), ('n', i32), ('h', i32), ('w', i32), ('wpk', vp),
         ('bias', vp), ('co', i32), ('ks', i32), ('stride', i32), ('act', i32), ('act_from', i32), ('res1', vp),
         ('res2', vp), ('res1_img_stride', i64), ('res2_img_stride', i64), ('y', vp), ('y_img_stride', i64),
-        ('out_mode', i32), ('algo', i32),
+        ('out_mode', i32), ('algo', i32), ('gate', vp), ('gate_img_stride', i64), ('gate_slope', f32),
     ]
 
 

@@ -56,6 +56,11 @@ class ResidualBlockNoBN(nn.Module):
     def forward(self, x):
         if self.res_scale != 1:
             raise NotImplementedError('edvr_amd fuses the residual add; res_scale != 1 is not used by EDVR')
+        c = self.conv1.out_channels
+        if (torch.is_grad_enabled() and (x.requires_grad or self.conv1.weight.requires_grad) and x.dim() == 4 and x.shape[3] > 16
+                and x.shape[2] >= 4 and c >= 48 and self.conv1.in_channels == c and F_.ops.CONV_ALGO != F_.ops.CONV_DIRECT):
+            from . import autograd as ag  # the sizes the Winograd kernel takes: the fused ReLU-backward gate lives in its epilogue
+            return ag.resblock(self, x)
         return F_.conv(self.conv2, F_.conv(self.conv1, x, act=F_.ACT_RELU), res1=x)
 
 

@@ -9,7 +9,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import ops
-from .ops import ACT_NONE, OUT_PIXEL_SHUFFLE2
+from .ops import ACT_NONE, ACT_RELU, OUT_PIXEL_SHUFFLE2
 
 
 class ConvFn(Function):
@@ -65,6 +65,45 @@ class ConvFn(Function):
                 else:
                     dx2 = d2
         return dx, dx2, dw, db, (dres if has_r1 else None), (dres if has_r2 else None), None
+
+
+class ResBlockFn(Function):
+    """y = x + conv2(relu(conv1(x))) (ResidualBlockNoBN, arch_util.py:66-95) as ONE autograd node.  Forward = the same two fused
+    launches; backward fuses what separate nodes cannot: the ReLU backward is the `gate` of the data-gradient conv of conv2
+    (no act_backward launch) and the identity branch's gradient is the residual of the data-gradient conv of conv1 (no
+    gradient-accumulation add by the autograd engine)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        c = w1.shape[0]
+        h = ops.conv2d(x, ops.pack_conv_weight(w1), b1.detach() if b1 is not None else None, c, 3, act=ACT_RELU)
+        y = ops.conv2d(h, ops.pack_conv_weight(w2), b2.detach() if b2 is not None else None, c, 3, res1=x)
+        ctx.save_for_backward(x, h, w1, w2)
+        ctx.has_bias = (b1 is not None, b2 is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, h, w1, w2 = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        c = w1.shape[0]
+        dy = dy.contiguous()
+        dw2 = db2 = dw1 = db1 = dx = None
+        if need[3] or (need[4] and ctx.has_bias[1]):
+            dw2, db2 = ops.conv2d_wgrad(h, None, None, dy, c, 3, 1, want_db=True)
+        # d(pre-activation of conv1) = (W2^T * dy) gated by relu'(z1) = [h > 0]
+        dz1 = ops.conv2d(dy, ops.pack_conv_weight(w2, transpose_flip=True), None, c, 3, gate=h, gate_slope=0.0)
+        if need[1] or (need[2] and ctx.has_bias[0]):
+            dw1, db1 = ops.conv2d_wgrad(x, None, None, dz1, c, 3, 1, want_db=True)
+        if need[0]:
+            dx = ops.conv2d(dz1, ops.pack_conv_weight(w1, transpose_flip=True), None, c, 3, res1=dy)  # + identity branch
+        return (dx, dw1 if need[1] else None, db1 if (need[2] and ctx.has_bias[0]) else None, dw2 if need[3] else None,
+                db2 if (need[4] and ctx.has_bias[1]) else None)
+
+
+def resblock(m, x):
+    return ResBlockFn.apply(x, m.conv1.weight, m.conv1.bias, m.conv2.weight, m.conv2.bias)
 
 
 def conv(m, x, x2, x2_map, act, act_from, res1, res2, out_mode, ks, stride):

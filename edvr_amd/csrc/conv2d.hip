@@ -348,7 +348,11 @@ int conv2d_launch(const edvr_conv2d_desc &d, hipStream_t stream) {
   a.wo = (d.w + 2 * pad - d.ks) / d.stride + 1;
   a.tiles_x = a.tiles_y = 0;
   a.co_start = 0;
-  if (conv_small_eligible(d)) return conv_small_launch(d, stream);
+  if (d.gate && !winograd_eligible(d)) {
+    set_error("conv2d: gate is only supported by the Winograd 3x3 kernel (no residuals / sigmoid / pixel-shuffle, algo != DIRECT)");
+    return EDVR_ERR_UNSUPPORTED;
+  }
+  if (!d.gate && conv_small_eligible(d)) return conv_small_launch(d, stream);
   if (winograd_eligible(d)) return winograd_launch(d, d.wpk + direct_packed_elems(d.co, a.ci, 3), round_up(d.co, 64), stream);
   if (d.ks == 3 && d.stride == 1) return launch_mt<3, 1>(a, stream);
   if (d.ks == 3 && d.stride == 2) return launch_mt<3, 2>(a, stream);

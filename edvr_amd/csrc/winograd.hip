@@ -272,8 +272,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_kernel(const WinoArgs
     //      ph = 0 keeps t0 + t1 and needs t2 from its sibling, ph = 1 keeps -(t2 + t3) and needs t1.
     const int plane = d.h * d.w;  // stride 1, pad 1: output size == input size
     float *y = d.y + (int64_t)e_img * d.y_img_stride;
-    const float *r1 = d.res1 ? d.res1 + (int64_t)e_img * d.res1_img_stride : nullptr;
-    const float *r2 = d.res2 ? d.res2 + (int64_t)e_img * d.res2_img_stride : nullptr;
+    // `gate` (data gradient through a ReLU / LeakyReLU: y *= gate > 0 ? 1 : gate_slope) rides on the residual machinery:
+    // same tile, same prefetch, a select instead of an add (winograd_eligible rejects gate together with residuals)
+    const bool gated = d.gate != nullptr;
+    const float *r1 = gated ? d.gate + (int64_t)e_img * d.gate_img_stride : (d.res1 ? d.res1 + (int64_t)e_img * d.res1_img_stride : nullptr);
+    const float *r2 = (!gated && d.res2) ? d.res2 + (int64_t)e_img * d.res2_img_stride : nullptr;
     const int tile = wn * 32 + j, tyy = tile >> 4, txx = tile & 15;
     const int oy = e_ty0 + 2 * tyy + ph, ox = e_tx0 + 2 * txx;
     const int co_lane = e_co_blk + wm * 32 + 4 * half;
@@ -387,8 +390,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_kernel(const WinoArgs
 #pragma unroll
     for (int g = 0; g < 4; ++g) load_u(g);
     auto emit = [&](auto HAS_RES, auto SHUFFLE, auto SIGMOID, auto INTERIOR) {
-      constexpr bool RES = decltype(HAS_RES)::value, SHF = decltype(SHUFFLE)::value, SIG = decltype(SIGMOID)::value,
-                     INT = decltype(INTERIOR)::value;
+      constexpr int RES = decltype(HAS_RES)::value;  // 0: none, 1: add residual(s), 2: gate
+      constexpr bool SHF = decltype(SHUFFLE)::value, SIG = decltype(SIGMOID)::value, INT = decltype(INTERIOR)::value;
       if (RES && INT) load_res(8);
 #pragma unroll
       for (int rb = 0; rb < 16; rb += 4) {  // batches of 4 channels: bias / residual loads issued ahead of their use
@@ -422,7 +425,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_kernel(const WinoArgs
             float v = mine[r][xx] + bias_r[r];
             if (SIG) v = (co >= d.act_from) ? __builtin_amdgcn_rcpf(1.f + __expf(-v)) : v;
             else v = fmaxf(v, sl * v);
-            if (RES) v += rr[ri][xx];
+            if (RES == 1) v += rr[ri][xx];
+            if (RES == 2) v = rr[ri][xx] > 0.f ? v : d.gate_slope * v;
             o[xx] = v;
           }
           if (SHF) {
@@ -450,6 +454,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_kernel(const WinoArgs
       emit(F{}, F{}, T{}, F{});
     } else if (d.out_mode == EDVR_OUT_PIXEL_SHUFFLE2) {
       if (interior) emit(F{}, T{}, F{}, T{}); else emit(F{}, T{}, F{}, F{});
+    } else if (gated) {
+      using G2 = std::integral_constant<int, 2>;
+      if (interior) emit(G2{}, F{}, F{}, T{}); else emit(G2{}, F{}, F{}, F{});
     } else if (r1) {
       if (interior) emit(T{}, F{}, F{}, T{}); else emit(T{}, F{}, F{}, F{});
     } else {
@@ -513,6 +520,7 @@ bool winograd_eligible(const edvr_conv2d_desc &d) {
   }();
   // the epilogue is specialised for: plain | residual(s) | pixel-shuffle | sigmoid - other combinations use the direct kernel
   const bool has_res = d.res1 || d.res2;
+  if (d.gate && (has_res || d.act == EDVR_ACT_SIGMOID || d.out_mode != EDVR_OUT_NCHW)) return false;
   if ((d.res2 && !d.res1) || (d.act == EDVR_ACT_SIGMOID && (has_res || d.out_mode != EDVR_OUT_NCHW)) ||
       (d.out_mode != EDVR_OUT_NCHW && has_res))
     return false;

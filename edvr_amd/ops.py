@@ -101,11 +101,13 @@ CONV_ALGO = CONV_AUTO  # default algorithm request of conv2d(); tests flip it to
 
 
 def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NONE, act_from=0, res1=None, res2=None,
-           out_mode=OUT_NCHW, out=None, algo=None):
+           out_mode=OUT_NCHW, out=None, algo=None, gate=None, gate_slope=0.0):
     """y = act(conv(cat(x1, x2)) + bias) + res1 + res2 on the fp32 MFMA kernel.
     algo: CONV_AUTO (default; module-level CONV_ALGO overrides it, used by tests), CONV_DIRECT or CONV_WINOGRAD.
 
     x2_map = (div, mul, add): image i of x2 is (i // div) * mul + add (broadcast of a reference frame).
+    gate (n, co, ho, wo): y *= gate > 0 ? 1 : gate_slope - the backward of a ReLU / LeakyReLU fused into the data-gradient conv
+    (3x3 stride 1 on the Winograd kernel only; raises where that kernel does not apply).
     """
     require_gpu(x1, x2, wpk, bias, res1, res2)
     L = _lib.lib()
@@ -142,6 +144,10 @@ def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NON
                 res1 = r
             else:
                 res2 = r
+    if gate is not None:
+        gate = _as_planes(gate)
+        assert tuple(gate.shape) == (n, co, ho, wo), f'gate shape {tuple(gate.shape)}'
+        d.gate, d.gate_img_stride, d.gate_slope = _ptr(gate), _img_stride(gate), float(gate_slope)
     d.y, d.y_img_stride, d.out_mode = _ptr(out), _img_stride(out), out_mode
     d.algo = CONV_ALGO if algo is None else algo
     if LAUNCH_HOOK is not None:  # measurement only (bench.py): brackets the launch with events on this stream

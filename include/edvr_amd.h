@@ -97,6 +97,12 @@ typedef struct edvr_conv2d_desc {
   int64_t y_img_stride;   /* elements between images of y */
   int out_mode;           /* EDVR_OUT_* */
   int algo;               /* EDVR_CONV_AUTO | EDVR_CONV_DIRECT | EDVR_CONV_WINOGRAD (falls back to direct where not applicable) */
+  const float *gate;      /* optional (n, co, ho, wo): y *= gate > 0 ? 1 : gate_slope, applied after bias / act.  This is the
+                           * backward of a ReLU (slope 0) / LeakyReLU (0.1) fused into the data-gradient conv that produces its
+                           * input gradient (gate = the activation's forward output).  3x3 / stride 1 on the Winograd kernel only,
+                           * not together with residuals, sigmoid or PixelShuffle: EDVR_ERR_UNSUPPORTED otherwise. */
+  int64_t gate_img_stride;
+  float gate_slope;
 } edvr_conv2d_desc;
 
 size_t edvr_conv2d_packed_weight_elems(int co, int ci, int ks);

@@ -78,6 +78,64 @@ def test_conv_gradients(gpu, case, conv_algo):
     assert _rel(m.bias.grad, m64.bias.grad) < GRAD_RTOL
 
 
+@pytest.mark.parametrize('shape', [(2, 64, 20, 36), (1, 128, 9, 23), (1, 48, 16, 18)])
+@pytest.mark.parametrize('slope', [0.0, 0.1])
+def test_conv_gate_epilogue(gpu, shape, slope):
+    """conv2d(gate=g, gate_slope=s) == conv2d(...) * (g > 0 ? 1 : s): the activation backward fused into a data-gradient conv."""
+    from edvr_amd import ops
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, c, h, w, generator=g).to(gpu)
+    wgt = (torch.randn(c, c, 3, 3, generator=g) * 0.05).to(gpu)
+    gate = torch.randn(n, c, h, w, generator=g).relu().to(gpu)  # ~half exact zeros, like a saved ReLU output
+    wpk = ops.pack_conv_weight(wgt)
+    plain = ops.conv2d(x, wpk, None, c, 3)
+    gated = ops.conv2d(x, wpk, None, c, 3, gate=gate, gate_slope=slope)
+    ref = torch.where(gate > 0, plain, slope * plain)
+    assert torch.equal(gated, ref)
+
+
+def test_conv_gate_needs_the_winograd_kernel(gpu):
+    from edvr_amd import ops
+    x = torch.randn(1, 64, 8, 8, device=gpu)
+    wpk = ops.pack_conv_weight(torch.randn(64, 64, 3, 3, device=gpu))
+    with pytest.raises(RuntimeError):
+        ops.conv2d(x, wpk, None, 64, 3, gate=x, algo=ops.CONV_DIRECT)
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 20, 36), (1, 128, 10, 24)])
+@pytest.mark.parametrize('frozen', [False, True])
+def test_residual_block_fused_backward(gpu, shape, frozen):
+    """ResidualBlockNoBN as one autograd node (ReLU backward + identity gradient fused into the dgrad launches) vs fp64 autograd."""
+    from edvr_amd.arch_util import ResidualBlockNoBN
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(17)
+    blk = ResidualBlockNoBN(c)
+    for p_ in blk.parameters():
+        p_.data = torch.randn(p_.shape, generator=g) * 0.05
+    x = torch.randn(n, c, h, w, generator=g)
+    dy = torch.randn(n, c, h, w, generator=g)
+    w1, b1, w2, b2 = [p_.detach().double().requires_grad_() for p_ in (blk.conv1.weight, blk.conv1.bias, blk.conv2.weight, blk.conv2.bias)]
+    x64 = x.double().requires_grad_()
+    y64 = x64 + F.conv2d(F.relu(F.conv2d(x64, w1, b1, padding=1)), w2, b2, padding=1)
+    y64.backward(dy.double())
+    blk = blk.to(gpu)
+    if frozen:  # TSA-only phase: trunk weights frozen, gradient still flows to the input
+        for p_ in blk.parameters():
+            p_.requires_grad_(False)
+    xd = x.to(gpu).requires_grad_()
+    y = blk(xd)
+    assert type(y.grad_fn).__name__.startswith('ResBlockFn')
+    assert _rel(y.detach(), y64.detach()) < 2e-5
+    y.backward(dy.to(gpu))
+    assert _rel(xd.grad, x64.grad) < GRAD_RTOL
+    if frozen:
+        assert all(p_.grad is None for p_ in blk.parameters())
+    else:
+        for ours, ref in [(blk.conv1.weight, w1), (blk.conv1.bias, b1), (blk.conv2.weight, w2), (blk.conv2.bias, b2)]:
+            assert _rel(ours.grad, ref.grad) < GRAD_RTOL
+
+
 def test_conv_gradient_with_reference_frame_map(gpu):
     """x2 = the same tensor read through the clip-centre image map: its gradient is summed over the clip's frames."""
     from edvr_amd import functional as F_
