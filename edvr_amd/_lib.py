@@ -38,6 +38,7 @@ PROTOTYPES = {
     'edvr_dcnv2_fwd_f32': (i32, [vp] * 6 + [i32] * 12 + [i64, i64, i32, i32, vp, sz, vp]),
     'edvr_dcnv2_bwd_ws_bytes': (sz, [i32] * 12),
     'edvr_psnr_sse_f32': (i32, [vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, vp]),
+    'edvr_frames_u8_to_f32': (i32, [vp, vp, i32, i32, i32, i32, vp, i32, vp]),
     'edvr_adam_chunk_bytes': (sz, []),
     'edvr_adam_multi_f32': (i32, [vp, i32, ctypes.c_float, ctypes.c_float, ctypes.c_float, vp]),
     'edvr_dcnv1_fwd_ws_bytes': (sz, [i32] * 12),

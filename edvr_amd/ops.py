@@ -458,3 +458,30 @@ def abs_sum_per_image(x):
     out = torch.empty(n, dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().edvr_abs_sum_f32(_ptr(x), _ptr(out), n, c * h * w, _img_stride(x), _stream()), 'edvr_abs_sum_f32')
     return out
+
+
+# ------------------------------------------------------------------------------------------------ input pipeline
+AUG_HFLIP, AUG_VFLIP, AUG_ROT90 = 1, 2, 4
+
+
+def frames_u8_to_f32(frames_u8, flags=None, swap_rb=False):
+    """uint8 device tensor (n_clips, frames, h, w, 3) -> float32 (n_clips, frames, 3, h', w') = bytes / 255, with the per-clip
+    augmentation `flags` (bytes / sequence of n_clips OR-ed AUG_* values, host side) applied: hflip, vflip, then transpose, as
+    transforms.augment does; the channel order is reversed when swap_rb (edvr_frames_u8_to_f32, csrc/data.hip)."""
+    if not frames_u8.is_cuda:
+        raise NotImplementedError('edvr_amd ops run on the GPU only (HIP/gfx950); got a CPU tensor')
+    if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 5 or frames_u8.shape[-1] != 3:
+        raise ValueError(f'expected a uint8 (n_clips, frames, h, w, 3) tensor, got {frames_u8.dtype} {tuple(frames_u8.shape)}')
+    frames_u8 = frames_u8.contiguous()
+    n, f, h, w, _ = frames_u8.shape
+    fl = None
+    if flags is not None:
+        fl = bytes(flags)
+        if len(fl) != n:
+            raise ValueError(f'{len(fl)} augmentation flags for {n} clips')
+    rot = fl is not None and any(b & AUG_ROT90 for b in fl)
+    out = torch.empty((n, f, 3, w, h) if rot else (n, f, 3, h, w), dtype=torch.float32, device=frames_u8.device)
+    if n:
+        _lib.check(_lib.lib().edvr_frames_u8_to_f32(_ptr(frames_u8), _ptr(out), n, f, h, w, fl, int(bool(swap_rb)), _stream()),
+                   'edvr_frames_u8_to_f32')
+    return out

@@ -242,6 +242,20 @@ int edvr_charbonnier_f32(const float *pred, const float *target, float *loss, fl
 int edvr_psnr_sse_f32(const float *a, const float *b, double *partial, int n, int c, int h, int w, int64_t a_img_stride,
                       int64_t b_img_stride, int crop_border, int y_channel, int blocks, edvr_stream_t stream);
 
+/* Input pipeline, device side <- imfrombytes(float32=True) (basicsr/utils/img_util.py:101-123: uint8 -> float32 / 255.), augment
+ * (basicsr/data/transforms.py:84-151: hflip, then vflip, then transpose, the same state for every image of a clip), img2tensor
+ * (img_util.py:9-33: BGR->RGB, HWC->CHW), default collate + CUDAPrefetcher's H2D copy (prefetch_dataloader.py:84-126).
+ * src: DEVICE uint8 (n_clips, frames_per_clip, h, w, 3) - decoded and cropped on the host, 1 byte per sample over PCIe;
+ * dst: DEVICE float32 (n_clips, frames_per_clip, 3, h', w'), (h', w') = (w, h) under EDVR_AUG_ROT90;
+ * clip_flags: HOST array of n_clips bytes (OR of EDVR_AUG_*), or NULL for none (validation: read_img_seq, data_util.py:11-33);
+ * it travels in the kernel-argument block, no device allocation or copy.  ROT90 with h != w -> EDVR_ERR_ARG.
+ * swap_rb != 0: channel order of src is reversed on the way (src BGR as cv2 decodes -> RGB). */
+#define EDVR_AUG_HFLIP 1
+#define EDVR_AUG_VFLIP 2
+#define EDVR_AUG_ROT90 4
+int edvr_frames_u8_to_f32(const uint8_t *src, float *dst, int n_clips, int frames_per_clip, int h, int w,
+                          const uint8_t *clip_flags, int swap_rb, edvr_stream_t stream);
+
 /* Multi-tensor Adam step <- torch.optim.Adam.step() as the reference builds it (basicsr/models/edvr_model.py:21-53, parameter
  * groups with dcn_lr_mul; stepped in sr_model.py:112).  `chunk_table` is a DEVICE array of n_chunks records of
  * edvr_adam_chunk_bytes() = 64 bytes: { float *p; const float *g; float *m; float *v; int32 n (<= 65536 elements of one tensor);

@@ -161,6 +161,131 @@ def lr_sched_case():
         json.dump(out, f)
 
 
+def data_case():
+    """Input pipeline: outputs of the reference's own REDSDataset.__getitem__ (basicsr/data/reds_dataset.py), transforms.py,
+    img_util.py (imfrombytes / img2tensor) and EnlargedSampler (data_sampler.py), executed from /root/reference.  cv2 is not
+    installed here: a numpy stand-in provides the three calls on this path (flip in place, cvtColor BGR2RGB, imdecode of the
+    raw container below); the storage backend is an in-memory client serving oracle.data_oracle.synthetic_frame."""
+    import importlib.util
+    import logging
+    import random
+    import struct
+    import sys
+    import types
+    import numpy as np
+    from oracle import data_oracle as DO
+
+    cv2 = types.ModuleType('cv2')
+    cv2.IMREAD_COLOR, cv2.IMREAD_GRAYSCALE, cv2.IMREAD_UNCHANGED, cv2.COLOR_BGR2RGB = 1, 0, -1, 4
+
+    def flip(src, code, dst=None):
+        out = src[:, ::-1].copy() if code == 1 else src[::-1].copy()
+        if dst is not None:
+            dst[...] = out
+            return dst
+        return out
+
+    def imdecode(buf, flag):  # b'RAW0' + <h, w> + BGR bytes
+        raw = buf.tobytes()
+        assert raw[:4] == b'RAW0' and flag == cv2.IMREAD_COLOR
+        h, w = struct.unpack('<ii', raw[4:12])
+        return np.frombuffer(raw[12:], np.uint8).reshape(h, w, 3).copy()
+
+    cv2.flip, cv2.imdecode = flip, imdecode
+    cv2.cvtColor = lambda img, code: np.ascontiguousarray(img[:, :, ::-1])
+    saved = {k: sys.modules.get(k) for k in ('cv2', 'torchvision', 'torchvision.utils', 'basicsr', 'basicsr.utils', 'basicsr.data',
+                                             'basicsr.utils.flow_util', 'basicsr.data.transforms')}
+    sys.modules['cv2'] = cv2
+    tv, tvu = types.ModuleType('torchvision'), types.ModuleType('torchvision.utils')
+    tvu.make_grid = None
+    sys.modules['torchvision'], sys.modules['torchvision.utils'] = tv, tvu
+
+    def load(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join('/root/reference', rel))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+        return mod
+
+    for pkg in ('basicsr', 'basicsr.utils', 'basicsr.data'):
+        m = types.ModuleType(pkg)
+        m.__path__ = []
+        sys.modules[pkg] = m
+    img_util = load('basicsr.utils.img_util', 'basicsr/utils/img_util.py')
+    LQ_HW, SCALE = (20, 28), 4
+
+    class FileClient:  # stands for basicsr/utils/file_client.py (disk backend): path -> bytes
+        def __init__(self, backend, **kw):
+            assert backend == 'disk'
+
+        def get(self, path, client_key):
+            clip, frame = str(path).split('/')[-2:]
+            h, w = LQ_HW if client_key == 'lq' else (LQ_HW[0] * SCALE, LQ_HW[1] * SCALE)
+            return b'RAW0' + struct.pack('<ii', h, w) + DO.synthetic_frame(client_key, clip, frame[:-4], h, w).tobytes()
+
+    u = sys.modules['basicsr.utils']
+    u.FileClient, u.get_root_logger = FileClient, lambda: logging.getLogger('ref')
+    u.imfrombytes, u.img2tensor = img_util.imfrombytes, img_util.img2tensor
+    fl = types.ModuleType('basicsr.utils.flow_util')
+    fl.dequantize_flow = None
+    sys.modules['basicsr.utils.flow_util'] = fl
+    load('basicsr.data.transforms', 'basicsr/data/transforms.py')
+    reds = load('basicsr.data.reds_dataset', 'basicsr/data/reds_dataset.py')
+    sampler = load('ref_data_sampler', 'basicsr/data/data_sampler.py')
+
+    meta = [f'{c:03d} 100 (80,112,3)\n' for c in (0, 1, 2, 11, 15, 20, 240, 250, 269)]
+    meta_path = '/tmp/edvr_meta_info_golden.txt'
+    with open(meta_path, 'w') as f:
+        f.writelines(meta)
+    out = dict(meta=meta, lq_hw=LQ_HW, scale=SCALE, samples=[], keys={}, sampler=[])
+    variants = [dict(num_frame=5, interval_list=[1], random_reverse=False, use_flip=True, use_rot=True, val_partition='REDS4'),
+                dict(num_frame=7, interval_list=[1, 2, 3], random_reverse=True, use_flip=True, use_rot=True, val_partition='official'),
+                dict(num_frame=5, interval_list=[2], random_reverse=True, use_flip=False, use_rot=True, val_partition='REDS4'),
+                dict(num_frame=3, interval_list=[1, 5], random_reverse=False, use_flip=True, use_rot=False, val_partition='official'),
+                dict(num_frame=5, interval_list=[1], random_reverse=False, use_flip=False, use_rot=False, val_partition='REDS4')]
+    for vi, v in enumerate(variants):
+        opt = dict(v, dataroot_gt='/data/gt', dataroot_lq='/data/lq', dataroot_flow=None, meta_info_file=meta_path,
+                   io_backend=dict(type='disk'), gt_size=32, scale=SCALE)
+        ds = reds.REDSDataset(opt)
+        out['keys'][v['val_partition']] = (len(ds), ds.keys[:3], ds.keys[-3:])
+        for seed, index in ((1, 0), (2, 1), (3, 98), (4, 99), (5, 150), (6, 297), (7, len(ds) - 1), (8, 251)):
+            random.seed(seed * 1000 + vi)
+            item = ds[index]
+            nxt = random.random()  # position of the random stream after the sample
+            lq8, gt8 = (item['lq'] * 255).round().to(torch.uint8), (item['gt'] * 255).round().to(torch.uint8)
+            assert torch.equal(lq8.float() / 255., item['lq']) and torch.equal(gt8.float() / 255., item['gt'])
+            out['samples'].append(dict(variant=vi, opt=v, seed=seed * 1000 + vi, index=index, key=item['key'], lq_u8=lq8, gt_u8=gt8,
+                                       next_random=nxt))
+
+    class Sized:
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+
+    for n, rep, ratio in ((37, 2, 1), (37, 3, 4), (100, 8, 200), (5, 2, 1)):
+        for epoch in (0, 3):
+            for rank in range(rep):
+                smp = sampler.EnlargedSampler(Sized(n), rep, rank, ratio)
+                smp.set_epoch(epoch)
+                idx = list(smp)
+                out['sampler'].append(dict(n=n, replicas=rep, rank=rank, ratio=ratio, epoch=epoch, first=idx[:16], last=idx[-4:],
+                                           count=len(idx), checksum=int(sum((i + 1) * (k + 1) for k, i in enumerate(idx)) % (1 << 61))))
+    # imfrombytes: all 256 byte values (the float32 division the device kernel has to reproduce bit for bit)
+    ramp = np.arange(256, dtype=np.uint8).reshape(1, 256, 1).repeat(3, 2)
+    out['div255'] = torch.from_numpy(img_util.imfrombytes(b'RAW0' + struct.pack('<ii', 1, 256) + ramp.tobytes(), float32=True)[0, :, 0].copy())
+    # read_img_seq's conversion (data_util.py:26-31) on two whole frames, executed from the reference's img2tensor
+    fr = [DO.synthetic_frame('lq', '000', f'{i:08d}', 18, 30) for i in range(2)]
+    out['read_img_seq'] = torch.stack(img_util.img2tensor([f.astype(np.float32) / 255. for f in fr], bgr2rgb=True, float32=True), 0)
+    torch.save(out, os.path.join(OUT, 'data_pipeline.pt'))
+    for k, m in saved.items():
+        if m is None:
+            sys.modules.pop(k, None)
+        else:
+            sys.modules[k] = m
+
+
 def main():
     assert ref_import.available() and O.have_ref(), 'needs /root/reference and oracle/_ref (make -C oracle ref)'
     os.makedirs(OUT, exist_ok=True)
@@ -171,6 +296,7 @@ def main():
     lr_sched_case()
     psnr_case()
     frame_indices_case()
+    data_case()
     for name in EDVR_CASES:
         torch.save(edvr_case(name), os.path.join(OUT, f'edvr_{name}.pt'))
     for f in sorted(os.listdir(OUT)):

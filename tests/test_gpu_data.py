@@ -1,0 +1,126 @@
+"""-m gpu: the device side of the input pipeline (edvr_frames_u8_to_f32 through edvr_amd.ops / edvr_amd.data), bit-exact against
+the oracle and against the reference's own outputs (tests/golden/data_pipeline.pt)."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import data_oracle as DO
+from util_data import SyntheticClient, base_opt, fetch_bgr, png_bytes, write_png_dataset
+
+pytestmark = pytest.mark.gpu
+GOLD = torch.load(os.path.join(os.path.dirname(__file__), 'golden', 'data_pipeline.pt'))
+
+
+def _ref(frames_u8, flags, swap_rb):
+    """numpy: (n, f, h, w, 3) uint8 -> (n, f, 3, h', w') float32 the reference's way (float first, then permute)."""
+    out = []
+    for c, clip in enumerate(frames_u8):
+        row = []
+        for img in clip:
+            x = DO.imfrombytes_float(img)
+            x = DO.apply_aug_flags(x, flags[c] if flags is not None else 0)
+            row.append(DO.img2tensor(x) if swap_rb else torch.from_numpy(x.transpose(2, 0, 1).copy()))
+        out.append(torch.stack(row, 0))
+    return torch.stack(out, 0)
+
+
+@pytest.mark.parametrize('shape', [(8, 5, 8, 8), (8, 1, 32, 32), (9, 2, 45, 45), (8, 5, 64, 64), (8, 1, 256, 256), (300, 1, 7, 7)])
+@pytest.mark.parametrize('swap_rb', [False, True])
+def test_frames_kernel_all_augmentations(gpu, shape, swap_rb):
+    from edvr_amd import ops
+    n, f, h, w = shape
+    rs = np.random.RandomState(n * 1000 + h)
+    x = rs.randint(0, 256, (n, f, h, w, 3)).astype(np.uint8)
+    for flags in ([i % 8 for i in range(n)], [4] * n, None):  # mixed states incl. transposed ones (square: shapes agree)
+        y = ops.frames_u8_to_f32(torch.from_numpy(x).to(gpu), flags, swap_rb=swap_rb)
+        assert torch.equal(y.cpu(), _ref(x, flags, swap_rb))
+
+
+@pytest.mark.parametrize('hw', [(18, 30), (33, 97), (180, 320), (1, 5)])
+def test_frames_kernel_rectangular(gpu, hw):
+    from edvr_amd import ops
+    h, w = hw
+    x = np.random.RandomState(h).randint(0, 256, (3, 2, h, w, 3)).astype(np.uint8)
+    for flags in (None, [0, 1, 2], [3, 3, 1]):
+        y = ops.frames_u8_to_f32(torch.from_numpy(x).to(gpu), flags)
+        assert y.shape == (3, 2, 3, h, w) and torch.equal(y.cpu(), _ref(x, flags, False))
+    with pytest.raises(RuntimeError, match='square'):
+        ops.frames_u8_to_f32(torch.from_numpy(x).to(gpu), [0, 4, 0])
+    y = ops.frames_u8_to_f32(torch.from_numpy(x[:, :, :, :h]).to(gpu).contiguous(), [4, 5, 6]) if h <= w else None
+    if y is not None:
+        assert torch.equal(y.cpu(), _ref(np.ascontiguousarray(x[:, :, :, :h]), [4, 5, 6], False))
+
+
+def test_division_is_numpy_division(gpu):
+    """All 256 byte values: the kernel's float32 quotient equals the reference's `img.astype(np.float32) / 255.` bit for bit."""
+    from edvr_amd import ops
+    ramp = torch.arange(256, dtype=torch.uint8).reshape(1, 1, 1, 256, 1).repeat(1, 1, 1, 1, 3)
+    y = ops.frames_u8_to_f32(ramp.to(gpu))
+    assert torch.equal(y[0, 0, 0, 0].cpu(), GOLD['div255'])
+
+
+def test_reference_samples_through_the_device(gpu, tmp_path):
+    """The 40 samples the reference's REDSDataset produced: planner + byte crop + device conversion give the same tensors."""
+    from edvr_amd import data as D
+    meta = tmp_path / 'meta.txt'
+    meta.write_text(''.join(GOLD['meta']))
+    client = SyntheticClient(GOLD['lq_hw'], GOLD['scale'])
+    planners = {}
+    for s in GOLD['samples']:
+        pl = planners.setdefault(s['variant'], D.REDSClipPlanner(base_opt(meta=str(meta), **s['opt']), client))
+        plan = pl.plan(s['index'], random.Random(s['seed']))
+        lq, gt = pl.load(plan)
+        lq_d = D.frames_to_device(lq[None], [plan.flags], gpu)[0]
+        gt_d = D.frames_to_device(gt[None, None], [plan.flags], gpu)[0, 0]
+        assert torch.equal(lq_d.cpu(), s['lq_u8'].float() / 255.) and torch.equal(gt_d.cpu(), s['gt_u8'].float() / 255.)
+
+
+@pytest.mark.parametrize('world', [(0, 1), (1, 2)])
+def test_device_loader_epochs(gpu, tmp_path, world):
+    """REDSDeviceLoader (sampler + planner + threaded decode + pinned staging + side stream + kernel) against the oracle run
+    over the same index order and random stream, two epochs."""
+    from edvr_amd import data as D
+    rank, ws = world
+    lq_hw, scale, bs = (12, 20), 4, 4
+    meta = write_png_dataset(str(tmp_path), ['001', '002'], lq_hw, scale, frames=100)
+    opt = base_opt(root=str(tmp_path), meta=meta, gt_size=32, num_frame=5, interval_list=[1, 2], random_reverse=True)
+    loader = D.REDSDeviceLoader(opt, bs, device=gpu, rank=rank, world_size=ws, seed=10, num_threads=4, depth=2)
+    fetch = fetch_bgr(lq_hw, scale)
+    keys = DO.reds_keys(open(meta).readlines(), 'REDS4')
+    assert len(loader) == (200 // ws) // bs
+    for epoch in (0, 1):
+        order = DO.enlarged_sampler_indices(200, ws, rank, 1, epoch)
+        rng = D.epoch_rng(10 + rank, epoch)
+        nb = 0
+        while True:
+            batch = loader.next()
+            if batch is None:
+                break
+            ref = [DO.reds_getitem(keys, opt, i, rng, fetch) for i in order[nb * bs:(nb + 1) * bs]]
+            assert batch['key'] == [r['key'] for r in ref]
+            assert batch['lq'].shape == (bs, 5, 3, 8, 8) and batch['gt'].shape == (bs, 3, 32, 32)
+            assert torch.equal(batch['lq'].cpu(), torch.stack([r['lq'] for r in ref]))
+            assert torch.equal(batch['gt'].cpu(), torch.stack([r['gt'] for r in ref]))
+            nb += 1
+            if nb == 5 and epoch == 0:
+                break  # leave the first epoch early (train.py stops at total_iter): reset() has to drain the producer
+        if epoch == 0:
+            loader.reset()
+        else:
+            assert nb == len(loader)
+    loader.close()
+
+
+def test_read_img_seq(gpu, tmp_path):
+    from edvr_amd import data as D
+    paths = []
+    for i in range(2):
+        p = tmp_path / f'{i:08d}.png'
+        p.write_bytes(png_bytes(DO.synthetic_frame('lq', '000', f'{i:08d}', 18, 30)))
+        paths.append(str(p))
+    assert torch.equal(D.read_img_seq(paths, gpu).cpu(), GOLD['read_img_seq'])
+    y = D.read_img_seq(paths, gpu, require_mod_crop=True, scale=4)
+    assert torch.equal(y.cpu(), GOLD['read_img_seq'][:, :, :16, :28])
