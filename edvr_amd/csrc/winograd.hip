@@ -49,7 +49,7 @@ __device__ __forceinline__ void mfma_acc(f32x16 &acc, float a, float b) {
 
 // PAIR: even image width and 8-byte aligned planes - columns 1 and 2 of every patch row are then an aligned pair, valid or
 // padded together, and come from ONE 64-bit load (12 instead of 16 gathers per chunk and thread).
-template <bool PAIR>
+template <bool PAIR, bool GATE = false>
 __global__ __launch_bounds__(512, 1) void conv3x3_winograd_kernel(const WinoArgs a) {
   constexpr int CK = 8, TY = 4, TX = 16;  // 64 tiles = 8 x 32 output pixels
   constexpr int SLAB = CK * 16 * 64;      // floats per LDS slab (U or V)
@@ -273,8 +273,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_kernel(const WinoArgs
     const int plane = d.h * d.w;  // stride 1, pad 1: output size == input size
     float *y = d.y + (int64_t)e_img * d.y_img_stride;
     // `gate` (data gradient through a ReLU / LeakyReLU: y *= gate > 0 ? 1 : gate_slope) rides on the residual machinery:
-    // same tile, same prefetch, a select instead of an add (winograd_eligible rejects gate together with residuals)
-    const bool gated = d.gate != nullptr;
+    // same tile, same prefetch, a select instead of an add (winograd_eligible rejects gate together with residuals).  GATE is its
+    // own instantiation of the kernel, so the ungated one keeps exactly the code it had without the feature.  The gated one
+    // deliberately keeps the whole run-time dispatch below (d.gate is tested, not assumed): with only its own two epilogue
+    // variants left the compiler hoists their common part above the branch and spills 60-80 bytes per lane.
+    const bool gated = GATE && d.gate != nullptr;
     const float *r1 = gated ? d.gate + (int64_t)e_img * d.gate_img_stride : (d.res1 ? d.res1 + (int64_t)e_img * d.res1_img_stride : nullptr);
     const float *r2 = (!gated && d.res2) ? d.res2 + (int64_t)e_img * d.res2_img_stride : nullptr;
     const int tile = wn * 32 + j, tyy = tile >> 4, txx = tile & 15;
@@ -548,8 +551,12 @@ int winograd_launch(const edvr_conv2d_desc &d, const float *U, int cop, hipStrea
   }();
   auto aligned8 = [](const float *p, int64_t img_stride) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0 && (img_stride & 1) == 0; };
   const bool pair = (d.w & 1) == 0 && aligned8(d.x1, d.x1_img_stride) && (!d.x2 || aligned8(d.x2, d.x2_img_stride));
-  if (pair) hipLaunchKernelGGL(conv3x3_winograd_kernel<true>, dim3(std::min(a.items, n_cu)), dim3(512), 0, stream, a);
-  else hipLaunchKernelGGL(conv3x3_winograd_kernel<false>, dim3(std::min(a.items, n_cu)), dim3(512), 0, stream, a);
+  const dim3 grid(std::min(a.items, n_cu));
+  if (d.gate) {
+    if (pair) hipLaunchKernelGGL((conv3x3_winograd_kernel<true, true>), grid, dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL((conv3x3_winograd_kernel<false, true>), grid, dim3(512), 0, stream, a);
+  } else if (pair) hipLaunchKernelGGL((conv3x3_winograd_kernel<true, false>), grid, dim3(512), 0, stream, a);
+  else hipLaunchKernelGGL((conv3x3_winograd_kernel<false, false>), grid, dim3(512), 0, stream, a);
   return check_launch("conv3x3_winograd_kernel");
 }
 
