@@ -15,6 +15,7 @@ The storage formats are the reference's: PNG folders `<root>/<clip>/<frame:08d>.
 """
 import io
 import math
+import os
 import queue
 import random
 import threading
@@ -247,6 +248,87 @@ def read_img_seq(paths, device='cuda', require_mod_crop=False, scale=1, num_thre
     with ThreadPoolExecutor(max(1, min(num_threads, len(paths)))) as pool:
         imgs = list(pool.map(one, [str(p) for p in paths]))
     return frames_to_device(np.stack(imgs)[None], None, device)[0]
+
+
+class VideoTestClips:
+    """VideoTestDataset (basicsr/data/video_test_dataset.py:11-147) with the frames kept on the device.
+
+    Same `opt` keys (dataroot_gt, dataroot_lq, io_backend, cache_data, name, num_frame, padding, optional meta_info_file), same
+    `data_info` lists and the same items from __getitem__ ({'lq' (t, c, h, w), 'gt' (c, h, w), 'folder', 'idx', 'border',
+    'lq_path'}), except that the tensors live on the GPU: a clip is decoded once on the host (threads), converted by
+    edvr_frames_u8_to_f32 and cached there (100 REDS4 frames: 83 MB LQ + 1.1 GB GT in fp32, nothing next to 288 GB), so that
+    metrics.validate_clip can batch the windows of a whole clip.  clip(folder) returns the (lq, gt) pair of one folder."""
+
+    def __init__(self, opt, device='cuda'):
+        import glob
+        import os.path as osp
+        from .metrics import generate_frame_indices
+        self._indices = generate_frame_indices
+        self.opt, self.device = opt, device
+        self.cache_data = opt['cache_data']
+        self.gt_root, self.lq_root = opt['dataroot_gt'], opt['dataroot_lq']
+        assert dict(opt['io_backend'])['type'] != 'lmdb', 'No need to use lmdb during validation/test.'
+        self.data_info = {'lq_path': [], 'gt_path': [], 'folder': [], 'idx': [], 'border': []}
+        self.imgs_lq, self.imgs_gt, self._cache = {}, {}, {}
+        if 'meta_info_file' in opt:
+            with open(opt['meta_info_file'], 'r') as fin:
+                subfolders = [line.split(' ')[0] for line in fin]
+            subfolders_lq = [osp.join(self.lq_root, key) for key in subfolders]
+            subfolders_gt = [osp.join(self.gt_root, key) for key in subfolders]
+        else:
+            subfolders_lq = sorted(glob.glob(osp.join(self.lq_root, '*')))
+            subfolders_gt = sorted(glob.glob(osp.join(self.gt_root, '*')))
+        if opt['name'].lower() not in ['vid4', 'reds4', 'redsofficial']:
+            raise ValueError(f'Non-supported video test dataset: {type(opt["name"])}')
+
+        def files(folder):  # scandir(full_path=True): plain files, no dot files, sorted by the caller
+            return sorted(osp.join(folder, e.name) for e in os.scandir(folder) if not e.name.startswith('.') and e.is_file())
+
+        for sub_lq, sub_gt in zip(subfolders_lq, subfolders_gt):
+            name = osp.basename(sub_lq)
+            paths_lq, paths_gt = files(sub_lq), files(sub_gt)
+            max_idx = len(paths_lq)
+            assert max_idx == len(paths_gt), f'Different number of images in lq ({max_idx}) and gt folders ({len(paths_gt)})'
+            self.data_info['lq_path'].extend(paths_lq)
+            self.data_info['gt_path'].extend(paths_gt)
+            self.data_info['folder'].extend([name] * max_idx)
+            self.data_info['idx'].extend(f'{i}/{max_idx}' for i in range(max_idx))
+            border = [0] * max_idx
+            for i in range(opt['num_frame'] // 2):
+                border[i] = 1
+                border[max_idx - i - 1] = 1
+            self.data_info['border'].extend(border)
+            self.imgs_lq[name], self.imgs_gt[name] = paths_lq, paths_gt
+
+    def __len__(self):
+        return len(self.data_info['gt_path'])
+
+    @property
+    def folders(self):
+        return list(self.imgs_lq)
+
+    def clip(self, folder):
+        """(lq (t, 3, h, w), gt (t, 3, H, W)) of one folder on the device."""
+        if folder in self._cache:
+            return self._cache[folder]
+        pair = (read_img_seq(self.imgs_lq[folder], self.device), read_img_seq(self.imgs_gt[folder], self.device))
+        if self.cache_data:
+            self._cache[folder] = pair
+        return pair
+
+    def __getitem__(self, index):
+        folder = self.data_info['folder'][index]
+        idx, max_idx = (int(v) for v in self.data_info['idx'][index].split('/'))
+        select_idx = self._indices(idx, max_idx, self.opt['num_frame'], padding=self.opt['padding'])
+        if self.cache_data:
+            lq, gt = self.clip(folder)
+            imgs_lq = lq.index_select(0, torch.tensor(select_idx, device=lq.device))
+            img_gt = gt[idx]
+        else:
+            imgs_lq = read_img_seq([self.imgs_lq[folder][i] for i in select_idx], self.device)
+            img_gt = read_img_seq([self.imgs_gt[folder][idx]], self.device)[0]
+        return {'lq': imgs_lq, 'gt': img_gt, 'folder': folder, 'idx': self.data_info['idx'][index],
+                'border': self.data_info['border'][index], 'lq_path': self.data_info['lq_path'][index]}
 
 
 def epoch_rng(seed, epoch):

@@ -286,6 +286,90 @@ def data_case():
             sys.modules[k] = m
 
 
+def video_test_case():
+    """VideoTestDataset (basicsr/data/video_test_dataset.py) of the reference, executed from its source on a small PNG tree
+    (2 folders x 7 frames of synthetic_frame, a dot file that scandir has to skip), for cache_data on / off and two padding
+    modes.  Its helpers are the reference's own source texts (read_img_seq, generate_frame_indices from data_util.py, scandir
+    from utils/misc.py, img2tensor / mod_crop); cv2.imread - cv2 is absent - is PIL's PNG decoder returning BGR."""
+    import importlib.util
+    import logging
+    import shutil
+    import sys
+    import types
+    import numpy as np
+    from PIL import Image
+    from oracle import data_oracle as DO
+
+    root = '/tmp/edvr_vt_golden'
+    shutil.rmtree(root, ignore_errors=True)
+    spec = dict(folders=['000', '011'], frames=7, lq_hw=(10, 14), scale=4)
+    for kind in ('lq', 'gt'):
+        h, w = spec['lq_hw'] if kind == 'lq' else (spec['lq_hw'][0] * 4, spec['lq_hw'][1] * 4)
+        for folder in spec['folders']:
+            os.makedirs(os.path.join(root, kind, folder))
+            for f in range(spec['frames']):
+                Image.fromarray(np.ascontiguousarray(DO.synthetic_frame(kind, folder, f'{f:08d}', h, w)[:, :, ::-1])).save(
+                    os.path.join(root, kind, folder, f'{f:08d}.png'))
+            open(os.path.join(root, kind, folder, '.hidden'), 'w').close()
+    saved = {k: sys.modules.get(k) for k in ('cv2', 'torchvision', 'torchvision.utils', 'basicsr', 'basicsr.utils', 'basicsr.data',
+                                             'basicsr.data.data_util', 'basicsr.data.transforms')}
+    cv2 = types.ModuleType('cv2')
+    cv2.COLOR_BGR2RGB = 4
+    cv2.imread = lambda path: np.ascontiguousarray(np.asarray(Image.open(path).convert('RGB'))[:, :, ::-1])
+    cv2.cvtColor = lambda img, code: np.ascontiguousarray(img[:, :, ::-1])
+    sys.modules['cv2'] = cv2
+    tv, tvu = types.ModuleType('torchvision'), types.ModuleType('torchvision.utils')
+    tvu.make_grid = None
+    sys.modules['torchvision'], sys.modules['torchvision.utils'] = tv, tvu
+    for pkg in ('basicsr', 'basicsr.utils', 'basicsr.data'):
+        m = types.ModuleType(pkg)
+        m.__path__ = []
+        sys.modules[pkg] = m
+
+    def load(name, rel):
+        sp = importlib.util.spec_from_file_location(name, os.path.join('/root/reference', rel))
+        mod = importlib.util.module_from_spec(sp)
+        sys.modules[name] = mod
+        sp.loader.exec_module(mod)
+        return mod
+
+    img_util = load('basicsr.utils.img_util', 'basicsr/utils/img_util.py')
+    misc_src = open('/root/reference/basicsr/utils/misc.py').read()
+    ns = {'os': os, 'osp': os.path}
+    exec(misc_src[misc_src.index('def scandir('):misc_src.index('def check_resume(')], ns)
+    u = sys.modules['basicsr.utils']
+    u.get_root_logger, u.scandir, u.img2tensor = (lambda: logging.getLogger('ref')), ns['scandir'], img_util.img2tensor
+    tr = load('basicsr.data.transforms', 'basicsr/data/transforms.py')
+    du_src = open('/root/reference/basicsr/data/data_util.py').read()
+    du = types.ModuleType('basicsr.data.data_util')
+    du.__dict__.update(cv2=cv2, np=np, torch=torch, osp=os.path, mod_crop=tr.mod_crop, img2tensor=img_util.img2tensor, scandir=ns['scandir'])
+    exec(du_src[du_src.index('def read_img_seq('):du_src.index('def paired_paths_from_lmdb(')], du.__dict__)
+    du.duf_downsample = None
+    sys.modules['basicsr.data.data_util'] = du
+    vt = load('basicsr.data.video_test_dataset', 'basicsr/data/video_test_dataset.py')
+    out = dict(spec=spec, runs=[])
+    for cache, padding, nf in ((True, 'reflection_circle', 5), (False, 'replicate', 3)):
+        opt = dict(name='REDS4', dataroot_gt=os.path.join(root, 'gt'), dataroot_lq=os.path.join(root, 'lq'), io_backend=dict(type='disk'),
+                   cache_data=cache, num_frame=nf, padding=padding)
+        ds = vt.VideoTestDataset(opt)
+        rel = lambda pth: os.path.relpath(pth, root)
+        info = {k: ([rel(v) for v in vals] if k.endswith('path') else list(vals)) for k, vals in ds.data_info.items()}
+        items = []
+        for index in (0, 1, 6, 7, 13):
+            it = ds[index]
+            lq8, gt8 = (it['lq'] * 255).round().to(torch.uint8), (it['gt'] * 255).round().to(torch.uint8)
+            assert torch.equal(lq8.float() / 255., it['lq']) and torch.equal(gt8.float() / 255., it['gt'])
+            items.append(dict(index=index, lq_u8=lq8, gt_u8=gt8, folder=it['folder'], idx=it['idx'], border=it['border'], lq_path=rel(it['lq_path'])))
+        out['runs'].append(dict(cache_data=cache, padding=padding, num_frame=nf, length=len(ds), data_info=info, items=items))
+    torch.save(out, os.path.join(OUT, 'video_test.pt'))
+    shutil.rmtree(root, ignore_errors=True)
+    for k, m in saved.items():
+        if m is None:
+            sys.modules.pop(k, None)
+        else:
+            sys.modules[k] = m
+
+
 def main():
     assert ref_import.available() and O.have_ref(), 'needs /root/reference and oracle/_ref (make -C oracle ref)'
     os.makedirs(OUT, exist_ok=True)
@@ -297,6 +381,7 @@ def main():
     psnr_case()
     frame_indices_case()
     data_case()
+    video_test_case()
     for name in EDVR_CASES:
         torch.save(edvr_case(name), os.path.join(OUT, f'edvr_{name}.pt'))
     for f in sorted(os.listdir(OUT)):

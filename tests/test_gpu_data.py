@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import data_oracle as DO
-from util_data import SyntheticClient, base_opt, fetch_bgr, png_bytes, write_png_dataset
+from util_data import SyntheticClient, base_opt, fetch_bgr, png_bytes, video_test_opt, write_png_dataset, write_video_test_tree
 
 pytestmark = pytest.mark.gpu
 GOLD = torch.load(os.path.join(os.path.dirname(__file__), 'golden', 'data_pipeline.pt'))
@@ -124,3 +124,43 @@ def test_read_img_seq(gpu, tmp_path):
     assert torch.equal(D.read_img_seq(paths, gpu).cpu(), GOLD['read_img_seq'])
     y = D.read_img_seq(paths, gpu, require_mod_crop=True, scale=4)
     assert torch.equal(y.cpu(), GOLD['read_img_seq'][:, :, :16, :28])
+
+
+def test_video_test_clips_items_equal_reference(gpu, tmp_path):
+    """Items of VideoTestClips (frames decoded on the host, converted + cached on the device) == the reference's VideoTestDataset."""
+    from edvr_amd import data as D
+    gold = torch.load(os.path.join(os.path.dirname(__file__), 'golden', 'video_test.pt'))
+    write_video_test_tree(str(tmp_path), gold['spec'])
+    for run in gold['runs']:
+        ds = D.VideoTestClips(video_test_opt(str(tmp_path), run), device=gpu)
+        for ref in run['items']:
+            it = ds[ref['index']]
+            assert it['lq'].is_cuda and torch.equal(it['lq'].cpu(), ref['lq_u8'].float() / 255.)
+            assert torch.equal(it['gt'].cpu(), ref['gt_u8'].float() / 255.)
+            assert (it['folder'], it['idx'], it['border'], os.path.relpath(it['lq_path'], str(tmp_path))) == \
+                   (ref['folder'], ref['idx'], ref['border'], ref['lq_path'])
+        lq, gt = ds.clip('011')
+        assert lq.shape == (7, 3, 10, 14) and gt.shape == (7, 3, 40, 56)
+        assert (ds.clip('011')[0] is lq) == run['cache_data']
+
+
+def test_validate_clip_from_png_folders(gpu, tmp_path):
+    """Folder of PNGs -> VideoTestClips -> validate_clip (batched windows, device PSNR): the same frames and scores as the
+    reference's per-frame loop over dataset items."""
+    from edvr_amd import data as D, metrics
+    from util_edvr import build
+    gold = torch.load(os.path.join(os.path.dirname(__file__), 'golden', 'video_test.pt'))
+    spec = dict(gold['spec'], lq_hw=(16, 20))
+    write_video_test_tree(str(tmp_path), spec)
+    run = gold['runs'][0]
+    ds = D.VideoTestClips(video_test_opt(str(tmp_path), run), device=gpu)
+    net, _, _ = build('M_T5')
+    net = net.to(gpu).eval()
+    lq, gt = ds.clip('000')
+    outs, scores = metrics.validate_clip(net, lq, gt, num_frame=5, padding=run['padding'], batch=3)
+    for i in (0, 3, 6):
+        it = ds[i]
+        with torch.no_grad():
+            o = net(it['lq'][None])
+        assert (o[0] - outs[i]).abs().max().item() < 1e-5
+        assert abs(metrics.calculate_psnr(o, it['gt'][None])[0] - scores[i]) < 1e-2

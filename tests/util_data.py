@@ -57,3 +57,21 @@ def base_opt(root=None, meta=None, **kw):
                random_reverse=False, use_flip=True, use_rot=True, val_partition='REDS4')
     opt.update(kw)
     return opt
+
+
+def write_video_test_tree(root, spec):
+    """The PNG tree oracle/make_golden.py::video_test_case fed to the reference's VideoTestDataset."""
+    for kind in ('lq', 'gt'):
+        h, w = spec['lq_hw'] if kind == 'lq' else (spec['lq_hw'][0] * spec['scale'], spec['lq_hw'][1] * spec['scale'])
+        for folder in spec['folders']:
+            d = os.path.join(root, kind, folder)
+            os.makedirs(d, exist_ok=True)
+            for f in range(spec['frames']):
+                with open(os.path.join(d, f'{f:08d}.png'), 'wb') as fh:
+                    fh.write(png_bytes(DO.synthetic_frame(kind, folder, f'{f:08d}', h, w)))
+            open(os.path.join(d, '.hidden'), 'w').close()
+
+
+def video_test_opt(root, run):
+    return dict(name='REDS4', dataroot_gt=os.path.join(root, 'gt'), dataroot_lq=os.path.join(root, 'lq'), io_backend=dict(type='disk'),
+                cache_data=run['cache_data'], num_frame=run['num_frame'], padding=run['padding'])
