@@ -264,7 +264,7 @@ def main():
                                      for k, v in sorted(per.items(), key=lambda kv: -kv[1][2])},
                 'conv_time_share_of_step': round(total_conv_s / max(1, min(args.steps, 3)) / (elapsed / args.steps), 3),
             }
-        if not args.no_cpu_baseline and args.mode == 'infer':
+        if not args.no_cpu_baseline and args.mode == 'infer' and world == 1:  # the CPU leg runs at N = 1 only (rank 0's host cores)
             result['cpu_baseline'] = cpu_baseline(cfg)
         print(json.dumps(result), flush=True)
     if dist:
