@@ -13,6 +13,7 @@ CUDAPrefetcher.next() does, already waited for on the current stream.
 The storage formats are the reference's: PNG folders `<root>/<clip>/<frame:08d>.png` (disk backend) and its LMDB layout (keys
 `<clip>/<frame:08d>`, PNG-encoded values; file_client.py:76-144) when the `lmdb` module is importable.
 """
+import contextlib
 import io
 import math
 import os
@@ -223,18 +224,9 @@ def frames_to_device(frames_u8, flags=None, device='cuda', stream=None, swap_rb=
     assert t.dtype == torch.uint8 and t.dim() == 5 and t.shape[-1] == 3, f'expected uint8 (n, f, h, w, 3), got {t.dtype} {tuple(t.shape)}'
     if not torch.cuda.is_available():
         raise RuntimeError('edvr_amd.data: no GPU - the conversion runs on the device only (there is no CPU fallback)')
-    ctx = torch.cuda.stream(stream) if stream is not None else _NullCtx()
-    with ctx:
+    with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
         dev = t.to(device, non_blocking=True)
         return ops.frames_u8_to_f32(dev, flags, swap_rb=swap_rb)
-
-
-class _NullCtx:
-    def __enter__(self):
-        return None
-
-    def __exit__(self, *a):
-        return False
 
 
 def read_img_seq(paths, device='cuda', require_mod_crop=False, scale=1, num_threads=8):
