@@ -86,6 +86,7 @@ __device__ __forceinline__ Tap resolve_tap(float h, float w, int H, int W) {
 __device__ __forceinline__ int lane_next_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false); }
 __device__ __forceinline__ int lane_prev_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
 __device__ __forceinline__ float lane_prev_f(float v) { return __int_as_float(lane_prev_i(__float_as_int(v))); }
+__device__ __forceinline__ float lane_next_f(float v) { return __int_as_float(lane_next_i(__float_as_int(v))); }
 
 // In a smooth offset field the right-hand corners (01, 11) of pixel p are the left-hand corners (00, 10) of pixel p+1,
 // i.e. of the next lane.  merge_right() decides, once per (pixel, tap), whether this lane hands its 01 / 11 contributions
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_coord_kernel(const float *__restr
 
     const int64_t plane = (int64_t)s.H * s.W;
     const float *xp = x + ((int64_t)b * s.C + (int64_t)g * cpg) * plane;
-    float *gp = dx + ((int64_t)b * s.C + (int64_t)g * cpg) * plane;
+    float *gp = dx ? dx + ((int64_t)b * s.C + (int64_t)g * cpg) * plane : nullptr;
     float *cp = dcol + ((int64_t)b * s.C * K + (int64_t)(g * cpg) * K + k) * P + p;
     float s_m = 0.f, s_y = 0.f, s_x = 0.f;
     // lane+1 is pixel p+1 of the same (image, group, tap) unless this lane is the last pixel of the plane
@@ -184,10 +185,12 @@ __global__ __launch_bounds__(256) void dcn_bwd_coord_kernel(const float *__restr
       const float v01 = t.w01 * tt, v11 = t.w11 * tt;
       const float l01 = lane_prev_f(v01), l11 = lane_prev_f(v11);  // uniform control flow: every lane executes the shifts
       const float v00 = t.w00 * tt + (mg.take00 ? l01 : 0.f), v10 = t.w10 * tt + (mg.take10 ? l11 : 0.f);
-      if (ok00 || mg.take00) unsafeAtomicAdd(gp + t.o00, v00);
-      if (ok01 && !mg.give01) unsafeAtomicAdd(gp + t.o01, v01);
-      if (ok10 || mg.take10) unsafeAtomicAdd(gp + t.o10, v10);
-      if (ok11 && !mg.give11) unsafeAtomicAdd(gp + t.o11, v11);
+      if (dx) {  // (null: dX comes from dcn_bwd_dx_strip_kernel)
+        if (ok00 || mg.take00) unsafeAtomicAdd(gp + t.o00, v00);
+        if (ok01 && !mg.give01) unsafeAtomicAdd(gp + t.o01, v01);
+        if (ok10 || mg.take10) unsafeAtomicAdd(gp + t.o10, v10);
+        if (ok11 && !mg.give11) unsafeAtomicAdd(gp + t.o11, v11);
+      }
       *cp = val * m;  // forward column, consumed by the dW GEMM
       xp += plane;
       gp += plane;
@@ -197,6 +200,144 @@ __global__ __launch_bounds__(256) void dcn_bwd_coord_kernel(const float *__restr
     float *dob = doffset + (int64_t)b * s.doff_bs + (int64_t)(g * 2 * K + 2 * k) * P + p;
     dob[0] = s_y * m;
     dob[P] = s_x * m;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dX of the backward WITHOUT scatter atomics, for the EDVR signature (3x3, stride 1, pad 1, dil 1) at training-patch widths
+// (W <= 64).  The scatter above costs 2-4 atomics per (pixel, tap, channel) - 1.7 G per launch on the 64x64 training layer, the
+// L2 atomic rate - although every dX element is the sum of only ~36 contributions from its 5x5 neighbourhood.  Here ONE wave
+// owns whole channel planes (lane = column x) and walks the rows top to bottom:
+//   * a tap whose offset is sub-pixel (floor(offset) in {-1, 0}) lands on a 2x2 block inside the 3x3 cells around its regular
+//     position; its bilinear weights factor into 3 row x 3 column weights (2 non-zero each, selected once per (pixel, tap)), so
+//     the 9 taps of a pixel accumulate into a 5x5 register patch with STATIC indices: out[i + a][j + b] += dc * ry[a] * cx[b];
+//   * the patch is folded onto the owner lanes with DPP wave shifts (cell x + s comes from lane x - s): 4 shifts per row;
+//   * the five patch rows go into a register ring acc[5]; after row y the ring slot of row y - 2 is complete and leaves with one
+//     uncontended atomic per element (84 M per launch instead of 1.7 G; atomic because the rare path below may hit any cell);
+//   * taps with larger offsets take the reference's route: four device atomics per channel, per lane, branch-divergent.
+// No LDS, no inter-wave communication: all contributions to a channel plane are produced by the wave that owns it.
+__global__ __launch_bounds__(256, 4) void dcn_bwd_dx_strip_kernel(const float *__restrict__ offset, const float *__restrict__ mask,
+                                                               const float *__restrict__ dcol, float *__restrict__ dx,
+                                                               const DcnShape s) {
+  // CQ channels share one evaluation of the tap weights.  CQ = 1: 99 VGPRs, no scratch, 5 waves per SIMD; with 2 (4) channels in
+  // flight hipcc interleaves their 25-register patches and spills 208 (628) bytes per lane at the same occupancy.
+  constexpr int K = 9, CQ = 1;
+  constexpr int RSRC_FLAGS = 0x00020000, OOB = (int)0x80000000;
+  const int g = blockIdx.x, b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int H = s.H, W = s.W, P = H * W, cpg = s.C / s.dg;
+  const bool live = lane < W;
+  // Loads go through buffer resources (wave-uniform base in SGPRs + 32-bit per-lane offset + scalar plane offset): no 64-bit
+  // address arithmetic per lane, and out-of-range reads return 0 - dead lanes (x >= W) and channels past the group's last
+  // need no branches.
+  auto rsrc_of = [&](const float *ptr, int bytes) {
+    const uint64_t pv = reinterpret_cast<uint64_t>(ptr);
+    const uint64_t pu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pv >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pv);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(pu), (short)0, bytes, RSRC_FLAGS);
+  };
+  auto ld = [&](__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+  };
+  const float *off_g = offset + (int64_t)b * s.off_bs + (int64_t)(g * 2 * K) * P;
+  const float *msk_g = mask + (int64_t)b * s.msk_bs + (int64_t)(g * K) * P;
+  const __amdgpu_buffer_rsrc_t r_off = rsrc_of(off_g, 2 * K * P * 4), r_msk = rsrc_of(msk_g, K * P * 4);
+  const int plane_b = P * 4;
+  for (int cq = wave; cq * CQ < cpg; cq += 4) {
+    const int c0 = g * cpg + cq * CQ;  // first channel of this pass
+    const int nch = min(CQ, cpg - cq * CQ);
+    const float *dc_base = dcol + ((int64_t)b * s.C + c0) * K * P;
+    const __amdgpu_buffer_rsrc_t r_dc = rsrc_of(dc_base, nch * K * P * 4);
+    float *dx_base = dx + ((int64_t)b * s.C + c0) * P;
+    float acc[CQ][5];  // acc[c][r]: row y + r - 2 of channel c0 + c, column `lane`
+#pragma unroll
+    for (int c = 0; c < CQ; ++c)
+#pragma unroll
+      for (int r = 0; r < 5; ++r) acc[c][r] = 0.f;
+    for (int y = 0; y < H; ++y) {
+      const int p = y * W + lane;
+      const int voff = live ? p * 4 : OOB;
+      // ---- per (pixel, tap): mask-scaled row weights and column weights on the 3x3 cells around the regular tap position
+      float rym[K][3], cx[K][3];
+      unsigned far = 0;  // taps outside the sub-pixel window: slow path
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int i = k / 3, j = k - 3 * i;
+        const float dyo = ld(r_off, voff, (2 * k) * plane_b), dxo = ld(r_off, voff, (2 * k + 1) * plane_b);
+        const float m = ld(r_msk, voff, k * plane_b);  // 0 for dead lanes: all their weights vanish
+        const float ph = (float)(y - 1 + i) + dyo, pw = (float)(lane - 1 + j) + dxo;
+        const bool valid = (ph > -1.f) && (pw > -1.f) && (ph < (float)H) && (pw < (float)W);
+        const float fh = floorf(ph), fw = floorf(pw);
+        const int h0 = (int)fh, w0 = (int)fw;
+        const float lh = ph - fh, lw = pw - fw;
+        const int fy = h0 - (y - 1 + i), fx = w0 - (lane - 1 + j);  // -1 or 0 for a sub-pixel offset
+        const bool near = (fy == -1 || fy == 0) && (fx == -1 || fx == 0);
+        const float wt = (valid && near && h0 >= 0) ? m * (1.f - lh) : 0.f, wb = (valid && near && h0 + 1 <= H - 1) ? m * lh : 0.f;
+        const float wl = w0 >= 0 ? 1.f - lw : 0.f, wr = w0 + 1 <= W - 1 ? lw : 0.f;
+        rym[k][0] = fy == -1 ? wt : 0.f;
+        rym[k][1] = fy == -1 ? wb : wt;
+        rym[k][2] = fy == -1 ? 0.f : wb;
+        cx[k][0] = fx == -1 ? wl : 0.f;
+        cx[k][1] = fx == -1 ? wr : wl;
+        cx[k][2] = fx == -1 ? 0.f : wr;
+        if (valid && !near && m != 0.f) far |= 1u << k;
+      }
+#pragma unroll
+      for (int c = 0; c < CQ; ++c) {
+        float dc[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) dc[k] = ld(r_dc, voff, (c * K + k) * plane_b);  // 0 past the group's last channel
+        float out[5][5];
+#pragma unroll
+        for (int r = 0; r < 5; ++r)
+#pragma unroll
+          for (int q = 0; q < 5; ++q) out[r][q] = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const int i = k / 3, j = k - 3 * i;
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            const float ra = dc[k] * rym[k][a];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) out[i + a][j + q] += ra * cx[k][q];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 5; ++r)  // out[r][q]: contribution of pixel x to cell x + q - 2 -> owner lanes
+          acc[c][r] += out[r][2] + lane_prev_f(out[r][3] + lane_prev_f(out[r][4])) + lane_next_f(out[r][1] + lane_next_f(out[r][0]));
+        if (far && c < nch) {  // rare: the reference's scatter for the taps that left the window
+          float *gp = dx_base + (int64_t)c * P;
+          for (unsigned rest = far; rest; rest &= rest - 1) {
+            const int k = __builtin_ctz(rest), i = k / 3, j = k - 3 * i;
+            const float dyo = off_g[(int64_t)(2 * k) * P + p], dxo = off_g[(int64_t)(2 * k + 1) * P + p];
+            const Tap t = resolve_tap((float)(y - 1 + i) + dyo, (float)(lane - 1 + j) + dxo, H, W);
+            const float tt = dc_base[((int64_t)c * K + k) * P + p] * msk_g[(int64_t)k * P + p];
+            if (t.ok00) unsafeAtomicAdd(gp + t.o00, t.w00 * tt);
+            if (t.ok01) unsafeAtomicAdd(gp + t.o01, t.w01 * tt);
+            if (t.ok10) unsafeAtomicAdd(gp + t.o10, t.w10 * tt);
+            if (t.ok11) unsafeAtomicAdd(gp + t.o11, t.w11 * tt);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // ---- row y - 2 is complete; rotate the ring
+#pragma unroll
+      for (int c = 0; c < CQ; ++c) {
+        if (live && y >= 2 && cq * CQ + c < cpg) unsafeAtomicAdd(dx_base + (int64_t)c * P + (y - 2) * W + lane, acc[c][0]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[c][r] = acc[c][r + 1];
+        acc[c][4] = 0.f;
+      }
+    }
+    // ---- rows H - 2 and H - 1 (ring slots 0 and 1 after the last rotation); slots >= 2 lie below the image and hold zeros
+#pragma unroll
+    for (int c = 0; c < CQ; ++c)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int row = H - 2 + r;
+        if (live && row >= 0 && cq * CQ + c < cpg) unsafeAtomicAdd(dx_base + (int64_t)c * P + row * W + lane, acc[c][r]);
+      }
   }
 }
 
@@ -617,8 +758,15 @@ int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, c
     const char *e = getenv("EDVR_DCN_BWD_TILE");  // "0": never use the LDS-window kernel (A/B)
     return !(e && e[0] == '0');
   }();
-  if (use_tile && scatter_hint != EDVR_DCN_SCATTER_DEVICE && kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1 &&
-      C / dg <= 16) {
+  const bool edvr_sig = kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1;
+  if (scatter_hint == EDVR_DCN_SCATTER_STRIP && edvr_sig && W <= 64) {
+    // dX by the register-ring kernel (reads dcol before the next kernel rewrites it), then dOffset / dMask / columns without dX
+    hipLaunchKernelGGL(dcn_bwd_dx_strip_kernel, dim3(dg, B), dim3(256), 0, stream, offset, mask, col, dx, s);
+    const int64_t total = (int64_t)B * dg * K * P;
+    hipLaunchKernelGGL(dcn_bwd_coord_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 1 << 20)), dim3(256), 0, stream, x,
+                       offset, mask, col, static_cast<float *>(nullptr), doffset, dmask, s);
+    rc = check_launch("dcn_bwd_dx_strip_kernel + dcn_bwd_coord_kernel");
+  } else if (use_tile && scatter_hint != EDVR_DCN_SCATTER_DEVICE && scatter_hint != EDVR_DCN_SCATTER_STRIP && edvr_sig && C / dg <= 16) {
     const int tiles_x = cdiv(s.Wo, 32), tiles_y = cdiv(s.Ho, 8);
     hipLaunchKernelGGL((dcn_bwd_coord_tile_kernel<3>), dim3(tiles_x * tiles_y, dg, B), dim3(256), 0, stream, x, offset, mask, col, dx,
                        doffset, dmask, s, tiles_x);

@@ -60,10 +60,15 @@ def halo_hint_from_absmean(absmean):
 
 def scatter_hint_from_absmean(absmean):
     """How the DCNv2 backward accumulates dx (include/edvr_amd.h EDVR_DCN_SCATTER_*), from the mean |offset| of the layer's
-    latest forward: sub-pixel offsets (fresh or lightly trained conv_offset) leave neighbouring pixels on neighbouring
-    addresses, where plain device atomics coalesce and are ~15 % faster; anything larger goes through the LDS window,
-    whose cost does not depend on the offset field (6x faster on a white-noise field)."""
-    return ops.DCN_SCATTER_DEVICE if (absmean is not None and absmean < 0.75) else ops.DCN_SCATTER_LDS
+    latest forward.  Sub-pixel offsets (fresh or lightly trained conv_offset): the register-ring kernel, which needs no scatter
+    for taps with |offset| < 1 (training-patch widths; the library falls back to device atomics for wider images, where
+    neighbouring pixels still hit neighbouring addresses and the atomics coalesce).  Anything larger goes through the LDS
+    window, whose cost does not depend on the offset field (6x faster than device atomics on a white-noise field)."""
+    if absmean is None:
+        return ops.DCN_SCATTER_LDS
+    if absmean < 0.4:  # white-noise offsets of sigma 0.5 (|mean| 0.4): 9 % of the taps already leave the sub-pixel window
+        return ops.DCN_SCATTER_STRIP
+    return ops.DCN_SCATTER_DEVICE if absmean < 0.75 else ops.DCN_SCATTER_LDS
 
 
 def dcn_from_packed(m, x, om, act=ACT_NONE):

@@ -95,7 +95,7 @@ def pack_conv_weight(weight, transpose_flip=False):
 
 
 # ------------------------------------------------------------------------------------------------ conv
-DCN_SCATTER_AUTO, DCN_SCATTER_DEVICE, DCN_SCATTER_LDS = 0, 1, 2  # include/edvr_amd.h EDVR_DCN_SCATTER_*
+DCN_SCATTER_AUTO, DCN_SCATTER_DEVICE, DCN_SCATTER_LDS, DCN_SCATTER_STRIP = 0, 1, 2, 3  # include/edvr_amd.h EDVR_DCN_SCATTER_*
 LAUNCH_HOOK = None  # callable(kernel_name, algorithmic_flops, launch_fn, algorithmic_bytes) or None
 CONV_ALGO = CONV_AUTO  # default algorithm request of conv2d(); tests flip it to cover both kernels on every shape
 

@@ -63,6 +63,7 @@ int edvr_check_device(void);
 #define EDVR_DCN_SCATTER_AUTO 0
 #define EDVR_DCN_SCATTER_DEVICE 1
 #define EDVR_DCN_SCATTER_LDS 2
+#define EDVR_DCN_SCATTER_STRIP 3
 #define EDVR_CONV_AUTO 0
 #define EDVR_CONV_DIRECT 1
 #define EDVR_CONV_WINOGRAD 2
@@ -149,6 +150,10 @@ int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, c
  *       when it is not (89 ms with white-noise offsets of 1 px).
  *   EDVR_DCN_SCATTER_LDS (2): per-tile LDS window (ds_add_f32) flushed with one device atomic per touched element: 7 ms /
  *       14 ms on the same two cases.  3x3, stride 1, pad 1, dil 1, <= 16 channels per deformable group; else DEVICE is used.
+ *   EDVR_DCN_SCATTER_STRIP (3): no scatter at all for sub-pixel offsets - one wave owns whole channel planes, folds the 9 taps of a
+ *       pixel into a 5x5 register patch, the patch onto its owner lanes with DPP wave shifts and the rows into a register ring;
+ *       one uncontended atomic per dx element.  Taps with |offset| >= 1 fall back to device atomics one by one, so this is the
+ *       choice for fresh / lightly trained offset convs.  3x3, stride 1, pad 1, dil 1 and W <= 64 (training patches); else DEVICE.
  *   EDVR_DCN_SCATTER_AUTO (0): LDS where applicable.
  * doffset_bstride / dmask_bstride (0 = contiguous): image strides of the two gradient outputs, so both can be
  * written straight into channel slices of one (B, 3*dg*K, Ho, Wo) buffer = the gradient of conv_offset's output. */

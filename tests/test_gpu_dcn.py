@@ -40,10 +40,14 @@ CASES = [
     (2, 16, 9, 11, 24, 3, 2, 1, 1, 2, 4, 1.5, {}),                  # generic: stride 2, groups 2, dg 4
     (1, 8, 10, 10, 12, 3, 1, 2, 2, 1, 2, 3.0, {}),                  # dilation 2
     (1, 12, 7, 9, 10, 1, 1, 0, 1, 1, 3, 1.0, {}),                   # 1x1 kernel, unaligned channel counts
+    (1, 128, 64, 64, 128, 3, 1, 1, 1, 1, 8, 0.3, {}),               # the training layer: sub-pixel offsets, full-width waves
+    (1, 48, 10, 13, 24, 3, 1, 1, 1, 1, 8, 0.4, {}),                 # 6 channels per deformable group (ragged channel quad)
+    (1, 64, 8, 64, 32, 3, 1, 1, 1, 1, 2, 0.5, {}),                  # 32 channels per group: two quads per wave
+    (1, 16, 1, 5, 16, 3, 1, 1, 1, 1, 4, 0.6, {}),                   # one row
 ]
 
 
-@pytest.mark.parametrize('scatter', ['lds', 'device'])  # the two dx accumulation strategies of the backward (EDVR_DCN_SCATTER_*)
+@pytest.mark.parametrize('scatter', ['lds', 'device', 'strip'])  # the dx accumulation strategies of the backward (EDVR_DCN_SCATTER_*)
 @pytest.mark.parametrize('case', CASES)
 def test_dcnv2_forward_backward_vs_oracle(gpu, case, scatter):
     from edvr_amd import ops
@@ -57,10 +61,18 @@ def test_dcnv2_forward_backward_vs_oracle(gpu, case, scatter):
     xg, og, mg, wg, bg, dyg = (t.to(gpu) for t in (x, off, m, w, b, dy))
     y = ops.dcnv2_forward(xg, og, mg, wg, bg, *cfg)
     grads = ops.dcnv2_backward(xg, og, mg, wg, dyg, True, *cfg,
-                               scatter_hint={'lds': ops.DCN_SCATTER_LDS, 'device': ops.DCN_SCATTER_DEVICE}[scatter])
+                               scatter_hint={'lds': ops.DCN_SCATTER_LDS, 'device': ops.DCN_SCATTER_DEVICE, 'strip': ops.DCN_SCATTER_STRIP}[scatter])
     torch.cuda.synchronize()
     assert _rel(y, ref_y) < FWD_RTOL
-    for name, a, r in zip(('dx', 'doffset', 'dmask', 'dweight', 'dbias'), grads, ref_g):
+    # d(offset) is discontinuous where a sampling position sits on an integer: if fp32 rounding of `base + offset` crosses it,
+    # floor() picks the other cell (the reference in fp32 does the same).  Such taps - where the ORACLE run in fp32 leaves its own
+    # fp64 result - are excluded from the comparison (1 tap of 295 k in the 64x64 case).
+    ref32 = O.c_backward(x, off, m, w, dy, True, *cfg)
+    for name, a, r, r32 in zip(('dx', 'doffset', 'dmask', 'dweight', 'dbias'), grads, ref_g, ref32):
+        if name == 'doffset':
+            flip = (r32.double() - r).abs() > 1e-3 * r.abs().max()
+            assert flip.sum().item() <= 2, 'fp32 floor flips should be rare'
+            a, r = a.double().cpu().masked_fill(flip, 0.), r.masked_fill(flip, 0.)
         assert _rel(a, r) < BWD_RTOL, name
 
 
