@@ -143,6 +143,7 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(const float *__restrict
 // backward: per (img, g, k, p) reduce over the group's channels.
 //   dcol (in)  : W^T dY, layout (img, c*K + k, p);  rewritten in place with the forward column
 //   dmask, doffset written; dx accumulated with fp32 atomics (dx pre-zeroed by the driver)
+template <bool WITH_DX>
 __global__ __launch_bounds__(256) void dcn_bwd_coord_kernel(const float *__restrict__ x, const float *__restrict__ offset,
                                                             const float *__restrict__ mask, float *__restrict__ dcol,
                                                             float *__restrict__ dx, float *__restrict__ doffset,
@@ -168,24 +169,53 @@ __global__ __launch_bounds__(256) void dcn_bwd_coord_kernel(const float *__restr
 
     const int64_t plane = (int64_t)s.H * s.W;
     const float *xp = x + ((int64_t)b * s.C + (int64_t)g * cpg) * plane;
-    float *gp = dx ? dx + ((int64_t)b * s.C + (int64_t)g * cpg) * plane : nullptr;
+    float *gp = WITH_DX ? dx + ((int64_t)b * s.C + (int64_t)g * cpg) * plane : nullptr;
     float *cp = dcol + ((int64_t)b * s.C * K + (int64_t)(g * cpg) * K + k) * P + p;
     float s_m = 0.f, s_y = 0.f, s_x = 0.f;
     // lane+1 is pixel p+1 of the same (image, group, tap) unless this lane is the last pixel of the plane
     // (all 64 lanes of a wave are live here or the wave is the grid's tail: idx + 1 < total covers it)
-    const Merge mg = merge_right(t, p + 1 < P && idx + 1 < total);
-    for (int cc = 0; cc < cpg; ++cc) {
+    Merge mg = {};
+    if (WITH_DX) mg = merge_right(t, p + 1 < P && idx + 1 < total);
+    if (!WITH_DX) {
+      // no scatter: channels in batches of 4 with all loads first (the column is rewritten in place, so the compiler cannot
+      // hoist the loads of channel c + 1 above the store of channel c: one dependent memory round trip per channel otherwise)
+      for (int cc0 = 0; cc0 < cpg; cc0 += 4) {
+        float dc[4], a00[4], a01[4], a10[4], a11[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int cu = cc0 + u < cpg ? u : 0;
+          dc[u] = cp[(int64_t)cu * K * P];
+          a00[u] = xp[cu * plane + t.o00];
+          a01[u] = xp[cu * plane + t.o01];
+          a10[u] = xp[cu * plane + t.o10];
+          a11[u] = xp[cu * plane + t.o11];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (cc0 + u < cpg) {
+            const float val = t.w00 * a00[u] + t.w01 * a01[u] + t.w10 * a10[u] + t.w11 * a11[u];
+            s_m += dc[u] * val;
+            s_y += dc[u] * (gy00 * a00[u] + gy01 * a01[u] + gy10 * a10[u] + gy11 * a11[u]);
+            s_x += dc[u] * (gx00 * a00[u] + gx01 * a01[u] + gx10 * a10[u] + gx11 * a11[u]);
+            cp[(int64_t)u * K * P] = val * m;
+          }
+        }
+        xp += 4 * plane;
+        cp += (int64_t)4 * K * P;
+      }
+    }
+    for (int cc = 0; WITH_DX && cc < cpg; ++cc) {
       const float dc = *cp;
       const float a00 = xp[t.o00], a01 = xp[t.o01], a10 = xp[t.o10], a11 = xp[t.o11];
       const float val = t.w00 * a00 + t.w01 * a01 + t.w10 * a10 + t.w11 * a11;
       s_m += dc * val;
       s_y += dc * (gy00 * a00 + gy01 * a01 + gy10 * a10 + gy11 * a11);
       s_x += dc * (gx00 * a00 + gx01 * a01 + gx10 * a10 + gx11 * a11);
-      const float tt = dc * m;
-      const float v01 = t.w01 * tt, v11 = t.w11 * tt;
-      const float l01 = lane_prev_f(v01), l11 = lane_prev_f(v11);  // uniform control flow: every lane executes the shifts
-      const float v00 = t.w00 * tt + (mg.take00 ? l01 : 0.f), v10 = t.w10 * tt + (mg.take10 ? l11 : 0.f);
-      if (dx) {  // (null: dX comes from dcn_bwd_dx_strip_kernel)
+      if (WITH_DX) {  // (false: dX comes from dcn_bwd_dx_strip_kernel)
+        const float tt = dc * m;
+        const float v01 = t.w01 * tt, v11 = t.w11 * tt;
+        const float l01 = lane_prev_f(v01), l11 = lane_prev_f(v11);  // uniform control flow: every lane executes the shifts
+        const float v00 = t.w00 * tt + (mg.take00 ? l01 : 0.f), v10 = t.w10 * tt + (mg.take10 ? l11 : 0.f);
         if (ok00 || mg.take00) unsafeAtomicAdd(gp + t.o00, v00);
         if (ok01 && !mg.give01) unsafeAtomicAdd(gp + t.o01, v01);
         if (ok10 || mg.take10) unsafeAtomicAdd(gp + t.o10, v10);
@@ -219,9 +249,12 @@ __global__ __launch_bounds__(256) void dcn_bwd_coord_kernel(const float *__restr
 __global__ __launch_bounds__(256, 4) void dcn_bwd_dx_strip_kernel(const float *__restrict__ offset, const float *__restrict__ mask,
                                                                const float *__restrict__ dcol, float *__restrict__ dx,
                                                                const DcnShape s) {
-  // CQ channels share one evaluation of the tap weights.  CQ = 1: 99 VGPRs, no scratch, 5 waves per SIMD; with 2 (4) channels in
-  // flight hipcc interleaves their 25-register patches and spills 208 (628) bytes per lane at the same occupancy.
-  constexpr int K = 9, CQ = 1;
+  // CQ channels share one evaluation of the tap weights (which is 2/3 of the instructions of a one-channel pass).  Their row
+  // rings live in LDS (slot = row % 5, one private column per lane: plain read-add-write, no conflicts, no atomics) so that
+  // the channel loop can stay a real loop: unrolled with the rings in registers, hipcc interleaves the 25-register patches of
+  // all channels and spills 208 (CQ = 2) to 628 (CQ = 4) bytes per lane.  99 VGPRs, 5 waves per SIMD.
+  constexpr int K = 9, CQ = 4;
+  __shared__ float ring[4][CQ][5][64];
   constexpr int RSRC_FLAGS = 0x00020000, OOB = (int)0x80000000;
   const int g = blockIdx.x, b = blockIdx.y;
   const int lane = threadIdx.x & 63;
@@ -250,11 +283,11 @@ __global__ __launch_bounds__(256, 4) void dcn_bwd_dx_strip_kernel(const float *_
     const float *dc_base = dcol + ((int64_t)b * s.C + c0) * K * P;
     const __amdgpu_buffer_rsrc_t r_dc = rsrc_of(dc_base, nch * K * P * 4);
     float *dx_base = dx + ((int64_t)b * s.C + c0) * P;
-    float acc[CQ][5];  // acc[c][r]: row y + r - 2 of channel c0 + c, column `lane`
+    float(*acc)[5][64] = ring[wave];  // acc[c][row % 5][lane]: rows y - 2 .. y + 2 of channel c0 + c while row y is processed
 #pragma unroll
     for (int c = 0; c < CQ; ++c)
 #pragma unroll
-      for (int r = 0; r < 5; ++r) acc[c][r] = 0.f;
+      for (int r = 0; r < 5; ++r) acc[c][r][lane] = 0.f;
     for (int y = 0; y < H; ++y) {
       const int p = y * W + lane;
       const int voff = live ? p * 4 : OOB;
@@ -283,8 +316,11 @@ __global__ __launch_bounds__(256, 4) void dcn_bwd_dx_strip_kernel(const float *_
         cx[k][2] = fx == -1 ? 0.f : wr;
         if (valid && !near && m != 0.f) far |= 1u << k;
       }
+      int slot[5];  // ring slot of row y + r - 2
 #pragma unroll
-      for (int c = 0; c < CQ; ++c) {
+      for (int r = 0; r < 5; ++r) slot[r] = (y + r + 3) % 5;
+#pragma unroll 1
+      for (int c = 0; c < nch; ++c) {
         float dc[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) dc[k] = ld(r_dc, voff, (c * K + k) * plane_b);  // 0 past the group's last channel
@@ -305,8 +341,8 @@ __global__ __launch_bounds__(256, 4) void dcn_bwd_dx_strip_kernel(const float *_
         }
 #pragma unroll
         for (int r = 0; r < 5; ++r)  // out[r][q]: contribution of pixel x to cell x + q - 2 -> owner lanes
-          acc[c][r] += out[r][2] + lane_prev_f(out[r][3] + lane_prev_f(out[r][4])) + lane_next_f(out[r][1] + lane_next_f(out[r][0]));
-        if (far && c < nch) {  // rare: the reference's scatter for the taps that left the window
+          acc[c][slot[r]][lane] += out[r][2] + lane_prev_f(out[r][3] + lane_prev_f(out[r][4])) + lane_next_f(out[r][1] + lane_next_f(out[r][0]));
+        if (far) {  // rare: the reference's scatter for the taps that left the window
           float *gp = dx_base + (int64_t)c * P;
           for (unsigned rest = far; rest; rest &= rest - 1) {
             const int k = __builtin_ctz(rest), i = k / 3, j = k - 3 * i;
@@ -321,22 +357,20 @@ __global__ __launch_bounds__(256, 4) void dcn_bwd_dx_strip_kernel(const float *_
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      // ---- row y - 2 is complete; rotate the ring
-#pragma unroll
-      for (int c = 0; c < CQ; ++c) {
-        if (live && y >= 2 && cq * CQ + c < cpg) unsafeAtomicAdd(dx_base + (int64_t)c * P + (y - 2) * W + lane, acc[c][0]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[c][r] = acc[c][r + 1];
-        acc[c][4] = 0.f;
+      // ---- row y - 2 is complete: it leaves, and its slot becomes row y + 3
+#pragma unroll 1
+      for (int c = 0; c < nch; ++c) {
+        const float v = acc[c][slot[0]][lane];
+        acc[c][slot[0]][lane] = 0.f;
+        if (live && y >= 2) unsafeAtomicAdd(dx_base + (int64_t)c * P + (y - 2) * W + lane, v);
       }
     }
-    // ---- rows H - 2 and H - 1 (ring slots 0 and 1 after the last rotation); slots >= 2 lie below the image and hold zeros
-#pragma unroll
-    for (int c = 0; c < CQ; ++c)
+    // ---- rows H - 2 and H - 1; the slots of rows >= H hold zeros (corners below the image have zero weight)
+    for (int c = 0; c < nch; ++c)
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int row = H - 2 + r;
-        if (live && row >= 0 && cq * CQ + c < cpg) unsafeAtomicAdd(dx_base + (int64_t)c * P + row * W + lane, acc[c][r]);
+        if (live && row >= 0) unsafeAtomicAdd(dx_base + (int64_t)c * P + row * W + lane, acc[c][(row + 5) % 5][lane]);
       }
   }
 }
@@ -763,8 +797,8 @@ int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, c
     // dX by the register-ring kernel (reads dcol before the next kernel rewrites it), then dOffset / dMask / columns without dX
     hipLaunchKernelGGL(dcn_bwd_dx_strip_kernel, dim3(dg, B), dim3(256), 0, stream, offset, mask, col, dx, s);
     const int64_t total = (int64_t)B * dg * K * P;
-    hipLaunchKernelGGL(dcn_bwd_coord_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 1 << 20)), dim3(256), 0, stream, x,
-                       offset, mask, col, static_cast<float *>(nullptr), doffset, dmask, s);
+    hipLaunchKernelGGL(dcn_bwd_coord_kernel<false>, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 1 << 20)), dim3(256), 0, stream,
+                       x, offset, mask, col, static_cast<float *>(nullptr), doffset, dmask, s);
     rc = check_launch("dcn_bwd_dx_strip_kernel + dcn_bwd_coord_kernel");
   } else if (use_tile && scatter_hint != EDVR_DCN_SCATTER_DEVICE && scatter_hint != EDVR_DCN_SCATTER_STRIP && edvr_sig && C / dg <= 16) {
     const int tiles_x = cdiv(s.Wo, 32), tiles_y = cdiv(s.Ho, 8);
@@ -773,7 +807,7 @@ int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, c
     rc = check_launch("dcn_bwd_coord_tile_kernel");
   } else {
     const int64_t total = (int64_t)B * dg * K * P;
-    hipLaunchKernelGGL(dcn_bwd_coord_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 1 << 20)), dim3(256), 0, stream, x,
+    hipLaunchKernelGGL(dcn_bwd_coord_kernel<true>, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 1 << 20)), dim3(256), 0, stream, x,
                        offset, mask, col, dx, doffset, dmask, s);
     rc = check_launch("dcn_bwd_coord_kernel");
   }
