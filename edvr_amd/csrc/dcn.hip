@@ -234,10 +234,9 @@ __global__ __launch_bounds__(256) void dcn_bwd_coord_kernel(const float *__restr
 }
 
 // ---------------------------------------------------------------------------------------------
-// dX of the backward WITHOUT scatter atomics, for the EDVR signature (3x3, stride 1, pad 1, dil 1) at training-patch widths
-// (W <= 64).  The scatter above costs 2-4 atomics per (pixel, tap, channel) - 1.7 G per launch on the 64x64 training layer, the
+// dX of the backward WITHOUT scatter atomics, for the EDVR signature (3x3, stride 1, pad 1, dil 1).  The scatter above costs 2-4 atomics per (pixel, tap, channel) - 1.7 G per launch on the 64x64 training layer, the
 // L2 atomic rate - although every dX element is the sum of only ~36 contributions from its 5x5 neighbourhood.  Here ONE wave
-// owns whole channel planes (lane = column x) and walks the rows top to bottom:
+// owns a 64-column strip of whole channel planes (lane = column; one strip at training-patch widths) and walks the rows top to bottom:
 //   * a tap whose offset is sub-pixel (floor(offset) in {-1, 0}) lands on a 2x2 block inside the 3x3 cells around its regular
 //     position; its bilinear weights factor into 3 row x 3 column weights (2 non-zero each, selected once per (pixel, tap)), so
 //     the 9 taps of a pixel accumulate into a 5x5 register patch with STATIC indices: out[i + a][j + b] += dc * ry[a] * cx[b];
@@ -245,7 +244,8 @@ __global__ __launch_bounds__(256) void dcn_bwd_coord_kernel(const float *__restr
 //   * the five patch rows go into a register ring acc[5]; after row y the ring slot of row y - 2 is complete and leaves with one
 //     uncontended atomic per element (84 M per launch instead of 1.7 G; atomic because the rare path below may hit any cell);
 //   * taps with larger offsets take the reference's route: four device atomics per channel, per lane, branch-divergent.
-// No LDS, no inter-wave communication: all contributions to a channel plane are produced by the wave that owns it.
+//   * wider images: the <= 2 patch columns that cross a strip edge go to their cells directly (4 lanes of 64).
+// No inter-wave communication: all contributions to a strip of a channel plane are produced by the wave that owns it.
 __global__ __launch_bounds__(256, 4) void dcn_bwd_dx_strip_kernel(const float *__restrict__ offset, const float *__restrict__ mask,
                                                                const float *__restrict__ dcol, float *__restrict__ dx,
                                                                const DcnShape s) {
@@ -256,11 +256,12 @@ __global__ __launch_bounds__(256, 4) void dcn_bwd_dx_strip_kernel(const float *_
   constexpr int K = 9, CQ = 4;
   __shared__ float ring[4][CQ][5][64];
   constexpr int RSRC_FLAGS = 0x00020000, OOB = (int)0x80000000;
-  const int g = blockIdx.x, b = blockIdx.y;
+  const int g = blockIdx.x % s.dg, strip = blockIdx.x / s.dg, strips = gridDim.x / s.dg, b = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int H = s.H, W = s.W, P = H * W, cpg = s.C / s.dg;
-  const bool live = lane < W;
+  const int x = strip * 64 + lane;  // image column of this lane; images wider than 64 columns are cut into strips
+  const bool live = x < W;
   // Loads go through buffer resources (wave-uniform base in SGPRs + 32-bit per-lane offset + scalar plane offset): no 64-bit
   // address arithmetic per lane, and out-of-range reads return 0 - dead lanes (x >= W) and channels past the group's last
   // need no branches.
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(256, 4) void dcn_bwd_dx_strip_kernel(const float *_
 #pragma unroll
       for (int r = 0; r < 5; ++r) acc[c][r][lane] = 0.f;
     for (int y = 0; y < H; ++y) {
-      const int p = y * W + lane;
+      const int p = y * W + x;
       const int voff = live ? p * 4 : OOB;
       // ---- per (pixel, tap): mask-scaled row weights and column weights on the 3x3 cells around the regular tap position
       float rym[K][3], cx[K][3];
@@ -299,12 +300,12 @@ __global__ __launch_bounds__(256, 4) void dcn_bwd_dx_strip_kernel(const float *_
         const int i = k / 3, j = k - 3 * i;
         const float dyo = ld(r_off, voff, (2 * k) * plane_b), dxo = ld(r_off, voff, (2 * k + 1) * plane_b);
         const float m = ld(r_msk, voff, k * plane_b);  // 0 for dead lanes: all their weights vanish
-        const float ph = (float)(y - 1 + i) + dyo, pw = (float)(lane - 1 + j) + dxo;
+        const float ph = (float)(y - 1 + i) + dyo, pw = (float)(x - 1 + j) + dxo;
         const bool valid = (ph > -1.f) && (pw > -1.f) && (ph < (float)H) && (pw < (float)W);
         const float fh = floorf(ph), fw = floorf(pw);
         const int h0 = (int)fh, w0 = (int)fw;
         const float lh = ph - fh, lw = pw - fw;
-        const int fy = h0 - (y - 1 + i), fx = w0 - (lane - 1 + j);  // -1 or 0 for a sub-pixel offset
+        const int fy = h0 - (y - 1 + i), fx = w0 - (x - 1 + j);  // -1 or 0 for a sub-pixel offset
         const bool near = (fy == -1 || fy == 0) && (fx == -1 || fx == 0);
         const float wt = (valid && near && h0 >= 0) ? m * (1.f - lh) : 0.f, wb = (valid && near && h0 + 1 <= H - 1) ? m * lh : 0.f;
         const float wl = w0 >= 0 ? 1.f - lw : 0.f, wr = w0 + 1 <= W - 1 ? lw : 0.f;
@@ -342,12 +343,29 @@ __global__ __launch_bounds__(256, 4) void dcn_bwd_dx_strip_kernel(const float *_
 #pragma unroll
         for (int r = 0; r < 5; ++r)  // out[r][q]: contribution of pixel x to cell x + q - 2 -> owner lanes
           acc[c][slot[r]][lane] += out[r][2] + lane_prev_f(out[r][3] + lane_prev_f(out[r][4])) + lane_next_f(out[r][1] + lane_next_f(out[r][0]));
+        if (strips > 1 && live && (lane < 2 || lane > 61)) {
+          // strip edges: patch columns that belong to a neighbouring strip fall off the wave in the shifts above; they go to
+          // their cells directly (lanes 0, 1, 62, 63 only: <= 3 cells x 5 rows each)
+          float *gp = dx_base + (int64_t)c * P;
+#pragma unroll
+          for (int q = 0; q < 5; ++q) {
+            if (q == 2) continue;
+            const int tl = lane + q - 2, tx = x + q - 2;
+            if ((tl < 0 || tl > 63) && tx >= 0 && tx < W) {
+#pragma unroll
+              for (int r = 0; r < 5; ++r) {
+                const int ty = y + r - 2;
+                if (ty >= 0 && ty < H && out[r][q] != 0.f) unsafeAtomicAdd(gp + ty * W + tx, out[r][q]);
+              }
+            }
+          }
+        }
         if (far) {  // rare: the reference's scatter for the taps that left the window
           float *gp = dx_base + (int64_t)c * P;
           for (unsigned rest = far; rest; rest &= rest - 1) {
             const int k = __builtin_ctz(rest), i = k / 3, j = k - 3 * i;
             const float dyo = off_g[(int64_t)(2 * k) * P + p], dxo = off_g[(int64_t)(2 * k + 1) * P + p];
-            const Tap t = resolve_tap((float)(y - 1 + i) + dyo, (float)(lane - 1 + j) + dxo, H, W);
+            const Tap t = resolve_tap((float)(y - 1 + i) + dyo, (float)(x - 1 + j) + dxo, H, W);
             const float tt = dc_base[((int64_t)c * K + k) * P + p] * msk_g[(int64_t)k * P + p];
             if (t.ok00) unsafeAtomicAdd(gp + t.o00, t.w00 * tt);
             if (t.ok01) unsafeAtomicAdd(gp + t.o01, t.w01 * tt);
@@ -362,7 +380,7 @@ __global__ __launch_bounds__(256, 4) void dcn_bwd_dx_strip_kernel(const float *_
       for (int c = 0; c < nch; ++c) {
         const float v = acc[c][slot[0]][lane];
         acc[c][slot[0]][lane] = 0.f;
-        if (live && y >= 2) unsafeAtomicAdd(dx_base + (int64_t)c * P + (y - 2) * W + lane, v);
+        if (live && y >= 2) unsafeAtomicAdd(dx_base + (int64_t)c * P + (y - 2) * W + x, v);
       }
     }
     // ---- rows H - 2 and H - 1; the slots of rows >= H hold zeros (corners below the image have zero weight)
@@ -370,7 +388,7 @@ __global__ __launch_bounds__(256, 4) void dcn_bwd_dx_strip_kernel(const float *_
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int row = H - 2 + r;
-        if (live && row >= 0) unsafeAtomicAdd(dx_base + (int64_t)c * P + row * W + lane, acc[c][(row + 5) % 5][lane]);
+        if (live && row >= 0) unsafeAtomicAdd(dx_base + (int64_t)c * P + row * W + x, acc[c][(row + 5) % 5][lane]);
       }
   }
 }
@@ -793,9 +811,9 @@ int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, c
     return !(e && e[0] == '0');
   }();
   const bool edvr_sig = kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1;
-  if (scatter_hint == EDVR_DCN_SCATTER_STRIP && edvr_sig && W <= 64) {
+  if (scatter_hint == EDVR_DCN_SCATTER_STRIP && edvr_sig && dg * cdiv(W, 64) <= 65535) {
     // dX by the register-ring kernel (reads dcol before the next kernel rewrites it), then dOffset / dMask / columns without dX
-    hipLaunchKernelGGL(dcn_bwd_dx_strip_kernel, dim3(dg, B), dim3(256), 0, stream, offset, mask, col, dx, s);
+    hipLaunchKernelGGL(dcn_bwd_dx_strip_kernel, dim3(dg * cdiv(W, 64), B), dim3(256), 0, stream, offset, mask, col, dx, s);
     const int64_t total = (int64_t)B * dg * K * P;
     hipLaunchKernelGGL(dcn_bwd_coord_kernel<false>, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 1 << 20)), dim3(256), 0, stream,
                        x, offset, mask, col, static_cast<float *>(nullptr), doffset, dmask, s);

@@ -61,8 +61,7 @@ def halo_hint_from_absmean(absmean):
 def scatter_hint_from_absmean(absmean):
     """How the DCNv2 backward accumulates dx (include/edvr_amd.h EDVR_DCN_SCATTER_*), from the mean |offset| of the layer's
     latest forward.  Sub-pixel offsets (fresh or lightly trained conv_offset): the register-ring kernel, which needs no scatter
-    for taps with |offset| < 1 (training-patch widths; the library falls back to device atomics for wider images, where
-    neighbouring pixels still hit neighbouring addresses and the atomics coalesce).  Anything larger goes through the LDS
+    for taps with |offset| < 1 (one wave per 64-column strip of a channel plane).  Anything larger goes through the LDS
     window, whose cost does not depend on the offset field (6x faster than device atomics on a white-noise field)."""
     if absmean is None:
         return ops.DCN_SCATTER_LDS

@@ -153,7 +153,7 @@ int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, c
  *   EDVR_DCN_SCATTER_STRIP (3): no scatter at all for sub-pixel offsets - one wave owns whole channel planes, folds the 9 taps of a
  *       pixel into a 5x5 register patch, the patch onto its owner lanes with DPP wave shifts and the rows into a register ring;
  *       one uncontended atomic per dx element.  Taps with |offset| >= 1 fall back to device atomics one by one, so this is the
- *       choice for fresh / lightly trained offset convs.  3x3, stride 1, pad 1, dil 1 and W <= 64 (training patches); else DEVICE.
+ *       choice for fresh / lightly trained offset convs.  3x3, stride 1, pad 1, dil 1 (any size; one wave per 64-column strip); else DEVICE.
  *   EDVR_DCN_SCATTER_AUTO (0): LDS where applicable.
  * doffset_bstride / dmask_bstride (0 = contiguous): image strides of the two gradient outputs, so both can be
  * written straight into channel slices of one (B, 3*dg*K, Ho, Wo) buffer = the gradient of conv_offset's output. */

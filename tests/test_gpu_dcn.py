@@ -44,6 +44,8 @@ CASES = [
     (1, 48, 10, 13, 24, 3, 1, 1, 1, 1, 8, 0.4, {}),                 # 6 channels per deformable group (ragged channel quad)
     (1, 64, 8, 64, 32, 3, 1, 1, 1, 1, 2, 0.5, {}),                  # 32 channels per group: two quads per wave
     (1, 16, 1, 5, 16, 3, 1, 1, 1, 1, 4, 0.6, {}),                   # one row
+    (1, 32, 12, 150, 32, 3, 1, 1, 1, 1, 8, 0.4, {}),                # wider than a wave: three 64-column strips, ragged last one
+    (1, 16, 6, 128, 16, 3, 1, 1, 1, 1, 4, 1.2, {}),                 # two full strips, many taps outside the sub-pixel window
 ]
 
 
