@@ -1,4 +1,6 @@
 """CPU: host-side contract of the module API (no compute: there is no CPU path)."""
+import os
+
 import pytest
 import torch
 
@@ -71,3 +73,16 @@ def test_module_attributes_mirror_reference():
     assert m.weight.shape == (12, 8, 3, 3) and torch.all(m.bias == 0)
     bound = 1.0 / (8 * 9) ** 0.5
     assert m.weight.abs().max().item() <= bound
+
+
+def test_kernel_hints_from_offset_statistics():
+    """The two performance hints derived from mean |offset| (results do not depend on them; GPU tests run every variant)."""
+    from edvr_amd import functional as F_, ops
+    assert F_.scatter_hint_from_absmean(None) == ops.DCN_SCATTER_LDS       # unknown field: the offset-independent strategy
+    assert F_.scatter_hint_from_absmean(0.05) == ops.DCN_SCATTER_STRIP     # fresh conv_offset: sub-pixel, no scatter at all
+    assert F_.scatter_hint_from_absmean(0.6) == ops.DCN_SCATTER_DEVICE
+    assert F_.scatter_hint_from_absmean(3.0) == ops.DCN_SCATTER_LDS
+    assert (ops.DCN_SCATTER_AUTO, ops.DCN_SCATTER_DEVICE, ops.DCN_SCATTER_LDS, ops.DCN_SCATTER_STRIP) == (0, 1, 2, 3)
+    hdr = open(os.path.join(os.path.dirname(__file__), '..', 'include', 'edvr_amd.h')).read()
+    for name, val in (('AUTO', 0), ('DEVICE', 1), ('LDS', 2), ('STRIP', 3)):
+        assert f'#define EDVR_DCN_SCATTER_{name} {val}' in hdr
