@@ -105,6 +105,9 @@ class FusedAdam(torch.optim.Optimizer):
         _lib.check(_lib.lib().edvr_adam_multi_f32(table.data_ptr(), len(tab), float(beta1), float(beta2), float(self.param_groups[0]['eps']),
                                                   torch.cuda.current_stream(dev).cuda_stream), 'edvr_adam_multi_f32')
         self._keep = table  # the launch is asynchronous: keep the table alive until the next step replaces it
+        # The kernel wrote the parameters through raw pointers: tell autograd, like an in-place torch op would.  Everything keyed
+        # on a parameter's version - the packed-weight cache of ops.pack_conv_weight above all - has to see the update.
+        torch.autograd.graph.increment_version([p for p, _ in items])
         return loss
 
 

@@ -62,3 +62,25 @@ def test_fused_adam_refuses_what_it_does_not_implement(gpu):
     p.grad = torch.ones(2)
     with pytest.raises(NotImplementedError):
         FusedAdam([p]).step()  # CPU parameter
+
+
+def test_fused_adam_step_is_seen_by_the_next_forward(gpu):
+    """FusedAdam writes the parameters through raw pointers; the packed-weight cache of the conv launches is keyed on the
+    parameter version, so the step has to bump it.  After a step the module must compute with the NEW weights."""
+    import torch.nn.functional as F
+    from edvr_amd import functional as F_
+    from edvr_amd.optim import FusedAdam
+    torch.manual_seed(3)
+    conv = nn.Conv2d(64, 64, 3, 1, 1).to(gpu)
+    x = torch.randn(2, 64, 20, 24, device=gpu)
+    opt = FusedAdam(conv.parameters(), lr=1e-1, betas=(0.9, 0.99))  # large step: the outputs move far beyond rounding
+    for _ in range(3):
+        v0 = conv.weight._version
+        y = F_.conv(conv, x)
+        ref = F.conv2d(x, conv.weight.detach(), conv.bias.detach(), padding=1)
+        assert (y.detach() - ref).abs().max().item() < 1e-3 * ref.abs().max().item()
+        opt.zero_grad(set_to_none=True)
+        y.square().sum().backward()
+        before = conv.weight.detach().clone()
+        opt.step()
+        assert conv.weight._version > v0 and not torch.equal(before, conv.weight.detach())
