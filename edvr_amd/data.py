@@ -323,6 +323,39 @@ class VideoTestClips:
                 'border': self.data_info['border'][index], 'lq_path': self.data_info['lq_path'][index]}
 
 
+class VideoTestVimeo90KClips:
+    """VideoTestVimeo90KDataset (basicsr/data/video_test_dataset.py:150-233; options/test/EDVR/test_EDVR_L_x4_SR_Vimeo90K.yml):
+    one item per septuplet listed in `meta_info_file`, the `num_frame` centre frames `im{i}.png` of the sequence as LQ window and
+    `im4.png` as GT; same `data_info` and item keys as the reference, tensors decoded on the host and converted on the device."""
+
+    def __init__(self, opt, device='cuda'):
+        import os.path as osp
+        self.opt, self.device = opt, device
+        if opt['cache_data']:
+            raise NotImplementedError('cache_data in Vimeo90K-Test dataset is not implemented.')
+        assert dict(opt['io_backend'])['type'] != 'lmdb', 'No need to use lmdb during validation/test.'
+        self.gt_root, self.lq_root = opt['dataroot_gt'], opt['dataroot_lq']
+        self.data_info = {'lq_path': [], 'gt_path': [], 'folder': [], 'idx': [], 'border': []}
+        neighbor_list = [i + (9 - opt['num_frame']) // 2 for i in range(opt['num_frame'])]
+        with open(opt['meta_info_file'], 'r') as fin:
+            subfolders = [line.split(' ')[0] for line in fin]
+        for idx, subfolder in enumerate(subfolders):
+            self.data_info['gt_path'].append(osp.join(self.gt_root, subfolder, 'im4.png'))
+            self.data_info['lq_path'].append([osp.join(self.lq_root, subfolder, f'im{i}.png') for i in neighbor_list])
+            self.data_info['folder'].append('vimeo90k')
+            self.data_info['idx'].append(f'{idx}/{len(subfolders)}')
+            self.data_info['border'].append(0)
+
+    def __len__(self):
+        return len(self.data_info['gt_path'])
+
+    def __getitem__(self, index):
+        lq_path = self.data_info['lq_path'][index]
+        return {'lq': read_img_seq(lq_path, self.device), 'gt': read_img_seq([self.data_info['gt_path'][index]], self.device)[0],
+                'folder': self.data_info['folder'][index], 'idx': self.data_info['idx'][index],
+                'border': self.data_info['border'][index], 'lq_path': lq_path[self.opt['num_frame'] // 2]}
+
+
 def epoch_rng(seed, epoch):
     """The random stream of one epoch of one rank: a function of (seed, epoch) only, so an epoch is reproducible however far the
     prefetch of the previous one had run when reset() cut it."""

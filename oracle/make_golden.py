@@ -361,6 +361,16 @@ def video_test_case():
             assert torch.equal(lq8.float() / 255., it['lq']) and torch.equal(gt8.float() / 255., it['gt'])
             items.append(dict(index=index, lq_u8=lq8, gt_u8=gt8, folder=it['folder'], idx=it['idx'], border=it['border'], lq_path=rel(it['lq_path'])))
         out['runs'].append(dict(cache_data=cache, padding=padding, num_frame=nf, length=len(ds), data_info=info, items=items))
+    # VideoTestVimeo90KDataset of the same file: index lists only (its items are read_img_seq of those paths)
+    meta = os.path.join(root, 'vimeo_meta.txt')
+    with open(meta, 'w') as f:
+        f.writelines(f'{a:05d}/{b:04d} 7 (256,448,3)\n' for a, b in ((1, 266), (1, 268), (2, 10), (96, 1)))
+    out['vimeo'] = []
+    for nf in (7, 5, 3):
+        ds = vt.VideoTestVimeo90KDataset(dict(name='Vimeo90K-Test', dataroot_gt='/data/v/gt', dataroot_lq='/data/v/lq', meta_info_file=meta,
+                                              io_backend=dict(type='disk'), cache_data=False, num_frame=nf, padding='reflection_circle'))
+        out['vimeo'].append(dict(num_frame=nf, length=len(ds), data_info={k: list(v) for k, v in ds.data_info.items()}))
+    out['vimeo_meta'] = open(meta).read()
     torch.save(out, os.path.join(OUT, 'video_test.pt'))
     shutil.rmtree(root, ignore_errors=True)
     for k, m in saved.items():
