@@ -4,21 +4,28 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--mode infer|train]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path (EDVR forward, or forward+backward+Adam with --mode train)
-over one batch of synthetic REDS-shaped clips per GPU, inputs resident in HBM before timing.
-Clips are independent, so ranks shard them with no data-path collective (inference) or with
-the DDP gradient all-reduce over RCCL (training).  Rank 0 prints ONE JSON line.
+A "step" is one pass of the hot path (EDVR forward, or forward+backward+Adam with --mode train) over one batch of synthetic
+REDS-shaped clips per GPU, inputs resident in HBM before timing.  Clips are independent, so ranks shard them with no data-path
+collective (inference) or with the DDP gradient all-reduce over RCCL (training).  `--gpus N` without a torchrun environment
+re-launches this script as N ranks through torch.distributed.run.  Rank 0 prints ONE JSON line.
 
-Extra objects in the line:
-  roofline     - dominant kernel (fp32 MFMA 3x3 conv): algorithmic FLOPs of every launch of that
-                 kernel / its HIP-event time, measured live on the launch stream in an instrumented
-                 pass run right after the timed region (same launches, same shapes).
-  cpu_baseline - the CPU oracle (oracle/: reference network restated in torch CPU ops + C DCNv2)
-                 timed on a bounded sample of the same workload on this box's host cores.
+Objects in the line besides the contract's fields (everything below runs OUTSIDE the timed region):
+  roofline            dominant kernel of the timed step, from an instrumented pass (every launch bracketed by HIP events on the
+                      launch stream): `achieved` = flops the matrix cores EXECUTE / time, `frac` = achieved / 157.3 TF/s (<= 1);
+                      the algorithmic figure (2*9*Ci*Co per pixel, what SURVEY 8(d) counts) is kept next to it.
+  kernels             per-kernel table of that pass: launches, ms, TF/s (MFMA-bound) or GB/s (HBM-bound), share of the step.
+  train               BASELINE.json's second headline (training iters/sec) on the cfg4 per-GPU shape, run on ALL ranks (DDP).
+  parity              the headline workload's output on ONE clip vs the CPU oracle's output on the same clip.
+  cpu_baseline        the CPU oracle timed on that clip (median of 3) on this box's host cores.
+  stock_rocm_baseline SURVEY 8(d)'s second arm: the same network in stock PyTorch-ROCm ops (MIOpen / rocBLAS) with a pure-torch
+                      DCNv2 on this GPU - "what a user gets today" - and a third parity witness.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -29,19 +36,23 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
+PEAK_HBM_GBPS = 8000.0        # same guide: HBM3E ~8 TB/s
+PROFILE_ROUND = 'r2'
 
+L5 = dict(num_feat=128, num_frame=5, num_reconstruct_block=40, center_frame_idx=None)
 WORKLOADS = {
     # BASELINE.json metric: "EDVR-L x4 5-frame 720p clips/sec" -> EDVR-L, T=5, 180x320 LR -> 720x1280
-    'edvr_l_x4_t5_180x320': dict(net=dict(num_feat=128, num_frame=5, num_reconstruct_block=40, center_frame_idx=None),
-                                 shape=(5, 3, 180, 320), batch=4,
+    'edvr_l_x4_t5_180x320': dict(net=L5, shape=(5, 3, 180, 320), batch=4,
                                  desc='EDVR-L x4, 5 frames, 180x320 LR -> 720x1280, batch 4/GPU, inference'),
+    # BASELINE.json north_star "Target": x4 720p -> 4K, 5 frames, EDVR-L (67.7 TFLOP per clip)
+    'edvr_l_x4_t5_720x1280': dict(net=L5, shape=(5, 3, 720, 1280), batch=1,
+                                  desc='EDVR-L x4, 5 frames, 720x1280 LR -> 2880x5120 (4K), batch 1/GPU, inference'),
     # BASELINE.json configs[1]
     'edvr_m_x4_t5_180x320': dict(net=dict(num_feat=64, num_frame=5, num_reconstruct_block=10, center_frame_idx=2),
                                  shape=(5, 3, 180, 320), batch=4,
                                  desc='EDVR-M x4, 5 frames, 180x320 LR -> 720x1280, batch 4/GPU, inference'),
     # BASELINE.json configs[3]: EDVR-L training, 5 frames, 64x64 LR crops, 32 clips per GPU (global 256 on 8)
-    'edvr_l_train_t5_64x64': dict(net=dict(num_feat=128, num_frame=5, num_reconstruct_block=40, center_frame_idx=None),
-                                  shape=(5, 3, 64, 64), batch=32,
+    'edvr_l_train_t5_64x64': dict(net=L5, shape=(5, 3, 64, 64), batch=32,
                                   desc='EDVR-L x4 training, 5 frames, 64x64 LR crops (256x256 GT), 32 clips/GPU, '
                                        'Charbonnier(sum) + Adam(4e-4, betas 0.9/0.99), DDP'),
     # BASELINE.json configs[2]: EDVR-L, 7 frames, 180x320, batch 8, TSA on; with --mode train it is the fwd+bwd case
@@ -50,14 +61,16 @@ WORKLOADS = {
                                  shape=(7, 3, 180, 320), batch=8,
                                  desc='EDVR-L x4, 7 frames, 180x320 LR -> 720x1280, batch 8/GPU, TSA on'),
     # BASELINE.json configs[4]: EDVR-L deblur (hr_in + predeblur, no upscale), 5 frames of 1280x720, 32 clips over 8 GPUs
-    'edvr_l_deblur_t5_720x1280': dict(net=dict(num_feat=128, num_frame=5, num_reconstruct_block=40, center_frame_idx=None,
-                                               hr_in=True, with_predeblur=True),
+    'edvr_l_deblur_t5_720x1280': dict(net=dict(L5, hr_in=True, with_predeblur=True),
                                       shape=(5, 3, 720, 1280), batch=4, scale=1,
                                       desc='EDVR-L deblur (hr_in, predeblur), 5 frames, 1280x720 -> 1280x720, batch 4/GPU'),
     # BASELINE.json configs[0] (plumbing-sized)
     'edvr_m_x4_t5_64x64': dict(net=dict(num_feat=64, num_frame=5, num_reconstruct_block=10, center_frame_idx=2),
                                shape=(5, 3, 64, 64), batch=1, desc='EDVR-M x4, 5 frames, 64x64 LR crop, batch 1'),
 }
+MFMA_KERNELS = ('conv3x3_winograd_kernel', 'conv3x3_winograd_wgrad_kernel', 'conv2d_mfma_kernel', 'conv2d_wgrad_kernel',
+                'conv1x1_stream_kernel', 'dcnv2_fwd', 'dcnv2_bwd')
+WINOGRAD = ('conv3x3_winograd_kernel', 'conv3x3_winograd_wgrad_kernel')  # execute 16 instead of 36 multiplies per 2x2 tile
 
 
 def parse():
@@ -71,8 +84,11 @@ def parse():
     ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
                     help='infer: forward clips/s (default).  train: fwd + Charbonnier + bwd + grad all-reduce + Adam')
     ap.add_argument('--optimizer', default='fused', choices=['fused', 'torch'], help='train mode: edvr_amd FusedAdam or torch.optim.Adam')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true', help='skip cpu_baseline and parity (the CPU oracle legs)')
+    ap.add_argument('--no-stock-baseline', action='store_true', help='skip the stock PyTorch-ROCm arm')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-train-leg', action='store_true', help='infer mode: skip the training leg (the `train` object)')
+    ap.add_argument('--train-steps', type=int, default=5)
     return ap.parse_args()
 
 
@@ -83,8 +99,10 @@ def build_net(cfg, device):
     return randomize_offsets(EDVR(**cfg['net'])).eval().to(device)
 
 
-def instrumented_pass(net, x, steps):
-    """Re-run the step with every conv launch bracketed by events on the launch stream."""
+# ------------------------------------------------------------------------------------------------ instrumented pass
+def instrumented_pass(step, steps):
+    """Re-run `step` with every launch of edvr_amd.ops bracketed by events on the launch stream.
+    Returns {kernel: [launches, algorithmic flops, seconds, algorithmic bytes]} summed over `steps` steps."""
     from edvr_amd import ops
     records = []
 
@@ -97,9 +115,8 @@ def instrumented_pass(net, x, steps):
 
     ops.LAUNCH_HOOK = hook
     try:
-        with torch.no_grad():
-            for _ in range(steps):
-                net(x)
+        for _ in range(steps):
+            step()
         torch.cuda.synchronize()
     finally:
         ops.LAUNCH_HOOK = None
@@ -113,46 +130,248 @@ def instrumented_pass(net, x, steps):
     return per
 
 
+def _is_mfma(name):
+    return name.startswith(MFMA_KERNELS)
+
+
+def _executed(name, flops):
+    return flops / 2.25 if name.startswith(WINOGRAD) else flops
+
+
+def kernel_table(per, steps, step_seconds):
+    """Per-kernel roofline view of one step: MFMA-bound kernels in executed TF/s (fraction of 157.3), HBM-bound ones in
+    algorithmic GB/s (fraction of 8 TB/s)."""
+    rows = {}
+    for name, (n, flops, secs, nbytes) in sorted(per.items(), key=lambda kv: -kv[1][2]):
+        row = {'launches_per_step': round(n / steps, 1), 'ms_per_step': round(secs / steps * 1e3, 3),
+               'share_of_step': round(secs / steps / step_seconds, 4), 'avg_launch_us': round(secs / n * 1e6, 2)}
+        if _is_mfma(name) and flops > 0:
+            ex = _executed(name, flops) / secs / 1e12
+            row.update(bound='mfma', tflops_executed=round(ex, 2), frac_of_mfma_peak=round(ex / PEAK_F32_MFMA_TFLOPS, 4))
+            if name.startswith(WINOGRAD):
+                row['tflops_algorithmic'] = round(flops / secs / 1e12, 2)
+        else:
+            gbps = nbytes / secs / 1e9
+            row.update(bound='hbm', hbm_gbps=round(gbps, 1), frac_of_hbm_peak=round(gbps / PEAK_HBM_GBPS, 4))
+        rows[name] = row
+    return rows
+
+
 def measured_traffic(workload, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this same command
     (scripts/prof_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate --pmc passes, calibrated on known-size copies as
     MI355X_MICROARCH.md's HBM section prescribes).  PMC collection serialises kernels, so it is not redone inside the timed run."""
-    path = os.path.join(ROOT, 'profiles', 'r1', f'traffic_{workload}.json')
-    if not os.path.exists(path):
-        return None, None
-    rep = json.load(open(path))
-    base = kernel.split('<')[0]
-    for k, v in rep['kernels'].items():
-        if k.split('<')[0].endswith(base) and v.get('hbm_bytes_per_launch'):
-            return v, os.path.relpath(path, ROOT)
+    for rnd in (PROFILE_ROUND, 'r1'):
+        path = os.path.join(ROOT, 'profiles', rnd, f'traffic_{workload}.json')
+        if os.path.exists(path):
+            rep = json.load(open(path))
+            base = kernel.split('<')[0]
+            for k, v in rep['kernels'].items():
+                if k.split('<')[0].endswith(base) and v.get('hbm_bytes_per_launch'):
+                    return v, os.path.relpath(path, ROOT)
     return None, None
 
 
-def cpu_baseline(cfg):
-    """Oracle forward of ONE clip of the same workload on the host cores (bounded: ~10-30 s)."""
-    from oracle import dcn_oracle, edvr_oracle as EO
+def roofline_object(per, steps, step_seconds, workload, default_batch):
+    mf = {k: v for k, v in per.items() if _is_mfma(k) and v[1] > 0}
+    name = max(mf, key=lambda k: mf[k][2])
+    n, flops, secs, nbytes = per[name]
+    ex = _executed(name, flops) / secs / 1e12
+    tr, tr_src = measured_traffic(workload, name) if default_batch else (None, None)
+    wino = name.startswith(WINOGRAD)
+    return {
+        'bound': 'mfma', 'kernel': name, 'achieved': round(ex, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+        'frac': round(ex / PEAK_F32_MFMA_TFLOPS, 4),
+        'definition': 'achieved = flops the fp32 matrix cores execute (v_mfma_f32_32x32x2_f32 issues x 4096) / HIP-event time of '
+                      'the kernel; frac = achieved / peak',
+        'algorithm': 'winograd F(2x2,3x3), fp32: 16 instead of 36 multiplies per 2x2 tile and channel pair' if wino
+                     else 'direct implicit GEMM, fp32',
+        # SURVEY 8(d) counts ALGORITHMIC flops (2*9*Ci*Co per output pixel); Winograd executes 1/2.25 of them, so this figure can
+        # exceed the MFMA peak - it is the direct-algorithm-equivalent rate, not a roofline fraction:
+        'algorithmic_tflops': round(flops / secs / 1e12, 2),
+        'algorithmic_over_peak': round(flops / secs / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+        'launches_per_step': round(n / steps, 1), 'avg_launch_us': round(secs / n * 1e6, 2),
+        'gflop_per_launch_algorithmic': round(flops / n / 1e9, 3), 'share_of_step': round(secs / steps / step_seconds, 4),
+        'traffic': round(tr['hbm_bytes_per_launch']) if tr else None,
+        'traffic_detail': ({'unit': 'bytes per launch (average over the launches of this kernel in one step)',
+                            'fetch': round(tr['fetch_bytes_per_launch']), 'write': round(tr['write_bytes_per_launch']),
+                            'algorithmic': round(nbytes / n), 'source': tr_src} if tr else None),
+    }
+
+
+# ------------------------------------------------------------------------------------------------ baselines / parity
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def parity_inputs(cfg):
+    """One clip + weights + a synthetic ground truth, all from CPU generators (lq seed 0, gt seed 1)."""
     from edvr_amd import EDVR
     from util_edvr import randomize_offsets
     torch.manual_seed(10)
-    sd = randomize_offsets(EDVR(**cfg['net'])).state_dict()
+    net = randomize_offsets(EDVR(**cfg['net'])).eval()
     x = torch.rand(1, *cfg['shape'], generator=torch.Generator().manual_seed(0))
-    kw = dict(center=cfg['net'].get('center_frame_idx'))
+    sc = cfg.get('scale', 4)
+    gt = torch.rand(1, 3, sc * cfg['shape'][2], sc * cfg['shape'][3], generator=torch.Generator().manual_seed(1))
+    return net, x, gt
+
+
+def oracle_kw(cfg):
+    n = cfg['net']
+    return dict(center=n.get('center_frame_idx'), hr_in=n.get('hr_in', False), with_predeblur=n.get('with_predeblur', False))
+
+
+def cpu_baseline_and_parity(cfg, device, repeats=3):
+    """Oracle forward of ONE clip of the workload on the host cores (median of `repeats`), and the SAME clip through the HIP
+    path: max relative error and PSNR difference against a synthetic ground truth (north_star: within 1e-3 dB)."""
+    from oracle import dcn_oracle, edvr_oracle as EO
+    net, x, gt = parity_inputs(cfg)
+    sd = net.state_dict()
+    times, ref = [], None
     with torch.no_grad():
-        t0 = time.time()
-        EO.edvr_forward(sd, x, dcn=dcn_oracle.dcnv2_c, **kw)
-        dt = time.time() - t0
-    return dict(value=round(1.0 / dt, 5), unit='clips/s', cores=torch.get_num_threads(), kind='port',
-                sample='1 clip (one forward, batch 1) of the same workload: reference network restated in torch CPU ops '
-                       '(fp32, oneDNN) + C/OpenMP DCNv2 oracle; the reference itself has no CPU DCN path',
-                seconds=round(dt, 2), host_cpus=os.cpu_count())
+        for _ in range(repeats):
+            t0 = time.time()
+            ref = EO.edvr_forward(sd, x, dcn=dcn_oracle.dcnv2_c, **oracle_kw(cfg))
+            times.append(time.time() - t0)
+        ours = net.to(device)(x.to(device)).cpu()
+    dt = statistics.median(times)
+    base = dict(value=round(1.0 / dt, 5), unit='clips/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'1 clip (one forward, batch 1) of the same workload, median of {repeats} runs: reference network restated '
+                       'in torch CPU ops (fp32, oneDNN) + C/OpenMP DCNv2 oracle; the reference itself has no CPU DCN path',
+                seconds=round(dt, 2), all_seconds=[round(t, 2) for t in times], host_cpus=os.cpu_count(), cpu_model=cpu_model())
+    p_ours, p_ref = EO.psnr(ours, gt), EO.psnr(ref, gt)
+    par = dict(clip='lq seed 0 / gt seed 1 (uniform), weights manual_seed 10 + randomised conv_offset',
+               against='CPU oracle (fp32 torch ops + C DCNv2), same clip, same weights',
+               max_rel_err=float(((ours - ref).abs().max() / ref.abs().max()).item()),
+               psnr_ours=round(p_ours, 6), psnr_oracle=round(p_ref, 6), d_psnr=round(abs(p_ours - p_ref), 8),
+               tolerance={'max_rel_err': 2e-4, 'd_psnr_db': 1e-3},
+               ok=bool(((ours - ref).abs().max() / ref.abs().max()).item() < 2e-4 and abs(p_ours - p_ref) <= 1e-3))
+    return base, par, ours
+
+
+def stock_rocm_baseline(cfg, device, ours_cpu, repeats=3):
+    """SURVEY 8(d) second arm: the reference network in stock PyTorch-ROCm ops (F.conv2d -> MIOpen, einsum -> rocBLAS) with the
+    pure-torch floor/gather DCNv2 (oracle/dcn_oracle.py::dcnv2_torch) on THIS GPU, one clip.  Baseline + parity witness only."""
+    from oracle import dcn_oracle, edvr_oracle as EO
+    net, x, _ = parity_inputs(cfg)
+    sd = {k: v.to(device) for k, v in net.state_dict().items()}
+    xd = x.to(device)
+    times = []
+    with torch.no_grad():
+        ref = EO.edvr_forward(sd, xd, dcn=dcn_oracle.dcnv2_torch, **oracle_kw(cfg))  # warm-up (MIOpen find)
+        torch.cuda.synchronize()
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            ref = EO.edvr_forward(sd, xd, dcn=dcn_oracle.dcnv2_torch, **oracle_kw(cfg))
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+    dt = statistics.median(times)
+    ref = ref.cpu()
+    out = dict(value=round(1.0 / dt, 3), unit='clips/s', ms_per_clip=round(dt * 1e3, 2),
+               what='same network in stock torch ops (MIOpen / rocBLAS, fp32, cudnn.benchmark off) + pure-torch DCNv2, batch 1, '
+                    f'median of {repeats} after one warm-up, on this GPU')
+    if ours_cpu is not None:
+        out['max_rel_err_vs_ours'] = float(((ours_cpu - ref).abs().max() / ref.abs().max()).item())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ steps
+def make_train_step(net, cfg, batch, device, rank, optimizer, x=None):
+    from edvr_amd import dist as D
+    from edvr_amd.autograd import charbonnier_loss
+    from edvr_amd.optim import FusedAdam
+    net.train()
+    sc = cfg.get('scale', 4)
+    if x is None:
+        x = torch.rand(batch, *cfg['shape'], generator=torch.Generator().manual_seed(rank)).to(device)
+    gt = torch.rand(batch, 3, sc * cfg['shape'][2], sc * cfg['shape'][3], generator=torch.Generator().manual_seed(1000 + rank)).to(device)
+    model = D.wrap_ddp(net)  # RCCL gradient all-reduce, bucketed and overlapped with backward
+    dcn = [p for n, p in net.named_parameters() if 'dcn' in n]  # edvr_model.py:21-53 (two groups as with dcn_lr_mul != 1)
+    rest = [p for n, p in net.named_parameters() if 'dcn' not in n]
+    groups = [{'params': rest, 'lr': 4e-4}, {'params': dcn, 'lr': 4e-4 * 1}]
+    opt = (torch.optim.Adam if optimizer == 'torch' else FusedAdam)(groups, lr=4e-4, betas=(0.9, 0.99))
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = model(x)
+        loss = charbonnier_loss(out, gt)
+        loss.backward()
+        opt.step()
+        return loss.detach()
+    return step
+
+
+def timed(step, steps, warmup, dist, device):
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(out).all()
+    return elapsed
+
+
+def train_leg(args, device, rank, world, dist):
+    """BASELINE.json's second headline: EDVR-L training iterations/sec on the cfg4 per-GPU shape (32 clips of 5 x 64x64 per GPU)."""
+    cfg = WORKLOADS['edvr_l_train_t5_64x64']
+    net = build_net(cfg, device)
+    step = make_train_step(net, cfg, cfg['batch'], device, rank, 'fused')
+    elapsed = timed(step, args.train_steps, 2, dist, device)
+    out = {'workload': cfg['desc'], 'iters_per_sec': round(args.train_steps / elapsed, 4), 'ms_per_iter': round(elapsed / args.train_steps * 1e3, 2),
+           'clips_per_sec': round(cfg['batch'] * world * args.train_steps / elapsed, 2), 'steps': args.train_steps, 'warmup': 2,
+           'n_gpus': world, 'global_batch': cfg['batch'] * world,
+           'optimizer': 'edvr_amd.optim.FusedAdam', 'what': 'forward + Charbonnier(sum) + backward + DDP all-reduce + Adam step'}
+    if rank == 0 and not args.no_roofline and world == 1:  # (an extra DDP step on one rank alone would wait for its peers)
+        per = instrumented_pass(step, 1)
+        tab = kernel_table(per, 1, elapsed / args.train_steps)
+        out['dominant_kernels'] = {k: v for k, v in list(tab.items())[:8]}
+        for key, label in (('conv3x3_winograd_kernel', 'fwd_dgrad'), ('conv3x3_winograd_wgrad_kernel', 'wgrad')):
+            if key in tab:
+                out[f'{label}_mfma_frac'] = tab[key]['frac_of_mfma_peak']
+    return out, step
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` outside torchrun: run N ranks of this script on this node (RCCL over xGMI)."""
+    n = torch.cuda.device_count()
+    assert n >= args.gpus, f'--gpus {args.gpus} but only {n} GPU(s) visible'
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def main():
     args = parse()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        self_spawn(args)
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     assert torch.cuda.is_available(), 'bench.py needs a GPU (edvr_amd has no CPU path)'
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU'
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     dist = None
@@ -160,6 +379,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend='nccl', device_id=device)  # nccl == RCCL on ROCm
+        assert dist.get_world_size() == world
     from edvr_amd import _lib
     assert _lib.lib().edvr_check_device() == 0, _lib.lib().edvr_last_error().decode()
 
@@ -172,49 +392,13 @@ def main():
     x = torch.rand(batch, *cfg['shape'], generator=torch.Generator().manual_seed(rank)).to(device)
 
     if args.mode == 'train':
-        from edvr_amd import dist as D
-        from edvr_amd.autograd import charbonnier_loss
-        net.train()
-        sc = cfg.get('scale', 4)
-        gt = torch.rand(batch, 3, sc * cfg['shape'][2], sc * cfg['shape'][3], generator=torch.Generator().manual_seed(1000 + rank)).to(device)
-        model = D.wrap_ddp(net)  # RCCL gradient all-reduce, bucketed and overlapped with backward
-        from edvr_amd.optim import FusedAdam
-        dcn = [p for n, p in net.named_parameters() if 'dcn' in n]  # edvr_model.py:21-53 (two groups as with dcn_lr_mul != 1)
-        rest = [p for n, p in net.named_parameters() if 'dcn' not in n]
-        groups = [{'params': rest, 'lr': 4e-4}, {'params': dcn, 'lr': 4e-4 * 1}]
-        opt = (torch.optim.Adam if args.optimizer == 'torch' else FusedAdam)(groups, lr=4e-4, betas=(0.9, 0.99))
-
-        def step():
-            opt.zero_grad(set_to_none=True)
-            out = model(x)
-            loss = charbonnier_loss(out, gt)
-            loss.backward()
-            opt.step()
-            return loss.detach()
+        step = make_train_step(net, cfg, batch, device, rank, args.optimizer, x)
     else:
         def step():
             with torch.no_grad():
                 return net(x)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert torch.isfinite(out).all()
+    elapsed = timed(step, args.steps, args.warmup, dist, device)
 
     result = None
     if rank == 0:
@@ -234,38 +418,38 @@ def main():
             'manual_seed 10, conv_offset ~ N(0,0.02)/N(0,0.5) so taps are non-integer)',
             'config': {'workload': cfg['desc'], 'clips_per_gpu': batch, 'global_clips': batch * world,
                        'parallelism': (f'DDP x{world}: RCCL gradient all-reduce (82.5 MB fp32)' if args.mode == 'train'
-                                       else f'clip-sharded x{world}, no data-path collective')},
+                                       else f'clip-sharded x{world}, no data-path collective'),
+                       'world_size': world, 'backend': 'RCCL (torch.distributed nccl)' if world > 1 else 'single process'},
         }
         if args.mode == 'train':
             result['iters_per_sec'] = round(args.steps / elapsed, 4)
             result['optimizer'] = ('edvr_amd.optim.FusedAdam (one HIP launch for all tensors; arithmetic of torch.optim.Adam)'
                                    if args.optimizer == 'fused' else 'torch.optim.Adam')
-        if not args.no_roofline and args.mode == 'infer':
-            per = instrumented_pass(net, x, max(1, min(args.steps, 3)))
-            name = max(per, key=lambda k: per[k][2])
-            n, flops, secs, nbytes = per[name]
-            total_conv_s = sum(v[2] for v in per.values())
-            tr, tr_src = measured_traffic(args.workload, name) if batch == cfg['batch'] else (None, None)
-            wino = 'winograd' in name
-            result['roofline'] = {
-                'bound': 'mfma', 'kernel': name, 'achieved': round(flops / secs / 1e12, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': round(flops / secs / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                'traffic': round(tr['hbm_bytes_per_launch']) if tr else None,
-                'traffic_detail': ({'unit': 'bytes per launch (average over the launches of this kernel in one step)',
-                                    'fetch': round(tr['fetch_bytes_per_launch']), 'write': round(tr['write_bytes_per_launch']),
-                                    'algorithmic': round(nbytes / n), 'source': tr_src} if tr else None),
-                # `achieved` counts ALGORITHMIC flops (2*9*Ci*Co per output pixel).  Winograd F(2x2,3x3) issues
-                # 16 instead of 36 multiplies per 2x2 tile and channel pair, so the matrix cores execute achieved/2.25:
-                'algorithm': 'winograd F(2x2,3x3), fp32' if wino else 'direct implicit GEMM, fp32',
-                'mfma_executed_tflops': round(flops / secs / 1e12 / (2.25 if wino else 1.0), 2),
-                'mfma_executed_frac_of_peak': round(flops / secs / 1e12 / (2.25 if wino else 1.0) / PEAK_F32_MFMA_TFLOPS, 4),
-                'launches': n, 'avg_launch_us': round(secs / n * 1e6, 2), 'gflop_per_launch': round(flops / n / 1e9, 3),
-                'all_conv_kernels': {k: {'launches': v[0], 'tflops': round(v[1] / v[2] / 1e12, 2), 'ms': round(v[2] * 1e3, 3)}
-                                     for k, v in sorted(per.items(), key=lambda kv: -kv[1][2])},
-                'conv_time_share_of_step': round(total_conv_s / max(1, min(args.steps, 3)) / (elapsed / args.steps), 3),
-            }
-        if not args.no_cpu_baseline and args.mode == 'infer' and world == 1:  # the CPU leg runs at N = 1 only (rank 0's host cores)
-            result['cpu_baseline'] = cpu_baseline(cfg)
+    # ---- everything below is outside the timed region
+    if rank == 0 and not args.no_roofline and (args.mode == 'infer' or world == 1):
+        isteps = 1 if args.mode == 'train' else max(1, min(args.steps, 3))
+        per = instrumented_pass(step, isteps)
+        result['roofline'] = roofline_object(per, isteps, elapsed / args.steps, args.workload, batch == cfg['batch'])
+        result['kernels'] = kernel_table(per, isteps, elapsed / args.steps)
+    del step
+    if args.mode == 'infer' and not args.no_train_leg:
+        del net, x
+        torch.cuda.empty_cache()
+        tr, tstep = train_leg(args, device, rank, world, dist)  # all ranks: DDP collectives
+        del tstep
+        torch.cuda.empty_cache()
+        if rank == 0:
+            result['train'] = tr
+    if rank == 0 and args.mode == 'infer' and world == 1:  # the CPU / stock legs run at N = 1 only (rank 0's host cores)
+        ours = None
+        if not args.no_cpu_baseline:
+            result['cpu_baseline'], result['parity'], ours = cpu_baseline_and_parity(cfg, device)
+        if not args.no_stock_baseline:
+            try:
+                result['stock_rocm_baseline'] = stock_rocm_baseline(cfg, device, ours)
+            except Exception as e:  # a baseline arm must never take the measurement down (e.g. MIOpen workspace failure)
+                result['stock_rocm_baseline'] = {'error': f'{type(e).__name__}: {str(e)[:200]}'}
+    if rank == 0:
         print(json.dumps(result), flush=True)
     if dist:
         dist.barrier()

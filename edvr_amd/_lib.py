@@ -21,7 +21,7 @@ class ConvDesc(ctypes.Structure):
         ('x2_div', i32), ('x2_mul', i32), ('x2_add', i32), ('n', i32), ('h', i32), ('w', i32), ('wpk', vp),
         ('bias', vp), ('co', i32), ('ks', i32), ('stride', i32), ('act', i32), ('act_from', i32), ('res1', vp),
         ('res2', vp), ('res1_img_stride', i64), ('res2_img_stride', i64), ('y', vp), ('y_img_stride', i64),
-        ('out_mode', i32), ('algo', i32), ('gate', vp), ('gate_img_stride', i64), ('gate_slope', f32),
+        ('out_mode', i32), ('algo', i32), ('gate', vp), ('gate_img_stride', i64), ('gate_slope', f32), ('y_scale', f32),
     ]
 
 
@@ -33,11 +33,14 @@ PROTOTYPES = {
     'edvr_conv2d_packed_weight_elems': (sz, [i32, i32, i32]),
     'edvr_conv2d_pack_weight_f32': (i32, [vp, vp, i32, i32, i32, i32, vp]),
     'edvr_conv2d_f32': (i32, [ctypes.POINTER(ConvDesc), vp]),
+    'edvr_conv2d_gate_supported': (i32, [ctypes.POINTER(ConvDesc)]),
     'edvr_conv2d_kernel_name': (i32, [ctypes.POINTER(ConvDesc), ctypes.c_char_p, sz]),
     'edvr_dcnv2_fwd_ws_bytes': (sz, [i32] * 12),
     'edvr_dcnv2_fwd_f32': (i32, [vp] * 6 + [i32] * 12 + [i64, i64, i32, i32, vp, sz, vp]),
     'edvr_dcnv2_bwd_ws_bytes': (sz, [i32] * 12),
     'edvr_psnr_sse_f32': (i32, [vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, vp]),
+    'edvr_ssim_partials': (sz, [i32, i32, i32]),
+    'edvr_ssim_f32': (i32, [vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, vp]),
     'edvr_frames_u8_to_f32': (i32, [vp, vp, i32, i32, i32, i32, vp, i32, vp]),
     'edvr_adam_chunk_bytes': (sz, []),
     'edvr_adam_multi_f32': (i32, [vp, i32, ctypes.c_float, ctypes.c_float, ctypes.c_float, vp]),
@@ -55,6 +58,7 @@ PROTOTYPES = {
     'edvr_act_bwd_f32': (i32, [vp, vp, vp, vp, vp, i32, i32, i64, i32, i32, vp]),
     'edvr_conv2d_wgrad_ws_bytes': (sz, [i32] * 7),
     'edvr_conv2d_wgrad_algo': (i32, [i32]),
+    'edvr_conv2d_wgrad_kernel_name': (i32, [i32] * 8 + [ctypes.c_char_p, sz]),
     'edvr_conv2d_wgrad_f32': (i32, [vp] * 4 + [i32] * 8 + [i64, i64, i32, i32, i32, i64, i32, vp, vp, sz, vp]),
     'edvr_channel_sum_f32': (i32, [vp, vp, i32, i32, i64, i64, vp, sz, vp]),
     'edvr_pixel_unshuffle2_f32': (i32, [vp, vp, i32, i32, i32, i32, vp]),

@@ -28,13 +28,13 @@ def default_init_weights(module_list, scale=1, bias_fill=0, **kwargs):
         for m in top.modules():
             if isinstance(m, (nn.Conv2d, nn.Linear)):
                 init.kaiming_normal_(m.weight, **kwargs)
-                m.weight.data *= scale
+                m.weight.mul_(scale)  # in place on the Parameter (not .data): bumps the version the packed-weight cache checks
                 if m.bias is not None:
-                    m.bias.data.fill_(bias_fill)
+                    m.bias.fill_(bias_fill)
             elif isinstance(m, _BatchNorm):
                 init.constant_(m.weight, 1)
                 if m.bias is not None:
-                    m.bias.data.fill_(bias_fill)
+                    m.bias.fill_(bias_fill)
 
 
 def make_layer(basic_block, num_basic_block, **kwarg):
@@ -42,7 +42,7 @@ def make_layer(basic_block, num_basic_block, **kwarg):
 
 
 class ResidualBlockNoBN(nn.Module):
-    """x + res_scale * conv2(relu(conv1(x))): two MFMA launches, ReLU and the identity add fused in."""
+    """x + res_scale * conv2(relu(conv1(x))): two MFMA launches, ReLU, the scale and the identity add fused in."""
 
     def __init__(self, num_feat=64, res_scale=1, pytorch_init=False):
         super().__init__()
@@ -54,14 +54,12 @@ class ResidualBlockNoBN(nn.Module):
             default_init_weights([self.conv1, self.conv2], 0.1)
 
     def forward(self, x):
-        if self.res_scale != 1:
-            raise NotImplementedError('edvr_amd fuses the residual add; res_scale != 1 is not used by EDVR')
         c = self.conv1.out_channels
-        if (torch.is_grad_enabled() and (x.requires_grad or self.conv1.weight.requires_grad) and x.dim() == 4 and x.shape[3] > 16
-                and x.shape[2] >= 4 and c >= 48 and self.conv1.in_channels == c and F_.ops.CONV_ALGO != F_.ops.CONV_DIRECT):
-            from . import autograd as ag  # the sizes the Winograd kernel takes: the fused ReLU-backward gate lives in its epilogue
+        if (torch.is_grad_enabled() and (x.requires_grad or self.conv1.weight.requires_grad) and x.dim() == 4
+                and self.conv1.in_channels == c and F_.ops.conv_gate_supported(x.shape[0], c, x.shape[2], x.shape[3], c)):
+            from . import autograd as ag  # where the Winograd kernel applies: the fused ReLU-backward gate lives in its epilogue
             return ag.resblock(self, x)
-        return F_.conv(self.conv2, F_.conv(self.conv1, x, act=F_.ACT_RELU), res1=x)
+        return F_.conv(self.conv2, F_.conv(self.conv1, x, act=F_.ACT_RELU), res1=x, y_scale=float(self.res_scale))
 
 
 def warn_offset_absmean(value):

@@ -17,10 +17,12 @@ class ConvFn(Function):
 
     @staticmethod
     def forward(ctx, x, x2, weight, bias, res1, res2, cfg):
-        x2_map, act, act_from, out_mode, ks, stride = cfg
+        x2_map, act, act_from, out_mode, ks, stride, y_scale = cfg
         wpk = ops.pack_conv_weight(weight)
         y = ops.conv2d(x, wpk, bias.detach() if bias is not None else None, weight.shape[0], ks, x2=x2, x2_map=x2_map, stride=stride,
-                       act=act, act_from=act_from, res1=res1, res2=res2, out_mode=out_mode)
+                       act=act, act_from=act_from, res1=res1, res2=res2, out_mode=out_mode, y_scale=y_scale)
+        if y_scale != 1.0 and act != ACT_NONE:
+            raise NotImplementedError('y_scale together with a fused activation has no backward (not used by EDVR)')
         keep_y = act != ACT_NONE
         ctx.save_for_backward(x, x2, weight, y if keep_y else None, res1 if keep_y else None, res2 if keep_y else None)
         ctx.cfg = cfg
@@ -31,7 +33,7 @@ class ConvFn(Function):
     @once_differentiable
     def backward(ctx, dy):
         x, x2, weight, y, res1, res2 = ctx.saved_tensors
-        x2_map, act, act_from, out_mode, ks, stride = ctx.cfg
+        x2_map, act, act_from, out_mode, ks, stride, y_scale = ctx.cfg
         has_bias, has_r1, has_r2 = ctx.has
         need = ctx.needs_input_grad
         co = weight.shape[0]
@@ -47,12 +49,15 @@ class ConvFn(Function):
             dw, db = dw if want_db else (dw, None)
         else:
             dw, db = None, (ops.channel_sum(dz) if want_db else None)
+        if y_scale != 1.0:  # y = y_scale * (W x + b) + res: the parameter gradients are linear in the scale (tiny tensors)
+            dw = dw.mul_(y_scale) if dw is not None else None
+            db = db.mul_(y_scale) if db is not None else None
         dx = dx2 = None
         if need[0] or (x2 is not None and need[1]):
             c1 = x.shape[1]
             z = ops.zero_stuff2(dz, x.shape[2], x.shape[3]) if stride == 2 else dz
             wt = ops.pack_conv_weight(weight, transpose_flip=True)
-            dcat = ops.conv2d(z, wt, None, weight.shape[1], ks)  # data gradient = stride-1 conv with flipped W^T
+            dcat = ops.conv2d(z, wt, None, weight.shape[1], ks, y_scale=y_scale)  # data gradient = stride-1 conv with flipped W^T
             if need[0]:
                 dx = dcat[:, :c1] if x2 is not None else dcat
             if x2 is not None and need[1]:
@@ -74,12 +79,13 @@ class ResBlockFn(Function):
     gradient-accumulation add by the autograd engine)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2):
+    def forward(ctx, x, w1, b1, w2, b2, res_scale=1.0):
         c = w1.shape[0]
         h = ops.conv2d(x, ops.pack_conv_weight(w1), b1.detach() if b1 is not None else None, c, 3, act=ACT_RELU)
-        y = ops.conv2d(h, ops.pack_conv_weight(w2), b2.detach() if b2 is not None else None, c, 3, res1=x)
+        y = ops.conv2d(h, ops.pack_conv_weight(w2), b2.detach() if b2 is not None else None, c, 3, res1=x, y_scale=res_scale)
         ctx.save_for_backward(x, h, w1, w2)
         ctx.has_bias = (b1 is not None, b2 is not None)
+        ctx.res_scale = float(res_scale)
         return y
 
     @staticmethod
@@ -88,26 +94,30 @@ class ResBlockFn(Function):
         x, h, w1, w2 = ctx.saved_tensors
         need = ctx.needs_input_grad
         c = w1.shape[0]
+        s = ctx.res_scale
         dy = dy.contiguous()
         dw2 = db2 = dw1 = db1 = dx = None
         if need[3] or (need[4] and ctx.has_bias[1]):
             dw2, db2 = ops.conv2d_wgrad(h, None, None, dy, c, 3, 1, want_db=True)
-        # d(pre-activation of conv1) = (W2^T * dy) gated by relu'(z1) = [h > 0]
-        dz1 = ops.conv2d(dy, ops.pack_conv_weight(w2, transpose_flip=True), None, c, 3, gate=h, gate_slope=0.0)
+            if s != 1.0:  # the branch's output gradient is s * dy; dW2 / db2 are linear in it (two small tensors)
+                dw2.mul_(s)
+                db2.mul_(s)
+        # d(pre-activation of conv1) = s * (W2^T * dy) gated by relu'(z1) = [h > 0]
+        dz1 = ops.conv2d(dy, ops.pack_conv_weight(w2, transpose_flip=True), None, c, 3, gate=h, gate_slope=0.0, y_scale=s)
         if need[1] or (need[2] and ctx.has_bias[0]):
             dw1, db1 = ops.conv2d_wgrad(x, None, None, dz1, c, 3, 1, want_db=True)
         if need[0]:
             dx = ops.conv2d(dz1, ops.pack_conv_weight(w1, transpose_flip=True), None, c, 3, res1=dy)  # + identity branch
         return (dx, dw1 if need[1] else None, db1 if (need[2] and ctx.has_bias[0]) else None, dw2 if need[3] else None,
-                db2 if (need[4] and ctx.has_bias[1]) else None)
+                db2 if (need[4] and ctx.has_bias[1]) else None, None)
 
 
 def resblock(m, x):
-    return ResBlockFn.apply(x, m.conv1.weight, m.conv1.bias, m.conv2.weight, m.conv2.bias)
+    return ResBlockFn.apply(x, m.conv1.weight, m.conv1.bias, m.conv2.weight, m.conv2.bias, float(m.res_scale))
 
 
-def conv(m, x, x2, x2_map, act, act_from, res1, res2, out_mode, ks, stride):
-    return ConvFn.apply(x, x2, m.weight, m.bias, res1, res2, (x2_map, act, act_from, out_mode, ks, stride))
+def conv(m, x, x2, x2_map, act, act_from, res1, res2, out_mode, ks, stride, y_scale=1.0):
+    return ConvFn.apply(x, x2, m.weight, m.bias, res1, res2, (x2_map, act, act_from, out_mode, ks, stride, float(y_scale)))
 
 
 class DcnFromPackedFn(Function):

@@ -251,7 +251,17 @@ __global__ __launch_bounds__(256, EDVR_CONV_MINWAVES) void conv2d_mfma_kernel(co
       }                                                                            \
     }                                                                              \
   }
-  if (d.out_mode == EDVR_OUT_PIXEL_SHUFFLE2) {
+  const float ys = d.y_scale == 0.f ? 1.f : d.y_scale;
+  if (ys != 1.f || d.gate) {  // generic variant: scale, gate (activation backward of a data-gradient conv), residuals; NCHW only
+    const float *gt = d.gate ? d.gate + (int64_t)img * d.gate_img_stride : nullptr;
+    EDVR_STORE_LOOP({
+      v *= ys;
+      if (gt) v = gt[o] > 0.f ? v : d.gate_slope * v;
+      if (r1) v += r1[o];
+      if (r2) v += r2[o];
+      y[o] = v;
+    })
+  } else if (d.out_mode == EDVR_OUT_PIXEL_SHUFFLE2) {
     EDVR_STORE_LOOP({
       (void)o;
       y[(co >> 2) * plane * 4 + (2 * oy + ((co >> 1) & 1)) * (2 * a.wo) + 2 * ox + (co & 1)] = v;
@@ -348,11 +358,16 @@ int conv2d_launch(const edvr_conv2d_desc &d, hipStream_t stream) {
   a.wo = (d.w + 2 * pad - d.ks) / d.stride + 1;
   a.tiles_x = a.tiles_y = 0;
   a.co_start = 0;
-  if (d.gate && !winograd_eligible(d)) {
-    set_error("conv2d: gate is only supported by the Winograd 3x3 kernel (no residuals / sigmoid / pixel-shuffle, algo != DIRECT)");
+  const bool scaled = d.y_scale != 0.f && d.y_scale != 1.f;
+  if ((d.gate || scaled) && (d.ks != 3 || d.out_mode != EDVR_OUT_NCHW)) {
+    set_error("conv2d: gate / y_scale need a 3x3 kernel and the NCHW output mode");
     return EDVR_ERR_UNSUPPORTED;
   }
-  if (!d.gate && conv_small_eligible(d)) return conv_small_launch(d, stream);
+  if (d.gate && d.act == EDVR_ACT_SIGMOID) {
+    set_error("conv2d: gate together with a sigmoid epilogue is not supported");
+    return EDVR_ERR_UNSUPPORTED;
+  }
+  if (!d.gate && !scaled && conv_small_eligible(d)) return conv_small_launch(d, stream);
   if (winograd_eligible(d)) return winograd_launch(d, d.wpk + direct_packed_elems(d.co, a.ci, 3), round_up(d.co, 64), stream);
   if (d.ks == 3 && d.stride == 1) return launch_mt<3, 1>(a, stream);
   if (d.ks == 3 && d.stride == 2) return launch_mt<3, 2>(a, stream);
@@ -402,6 +417,13 @@ int edvr_conv2d_kernel_name(const edvr_conv2d_desc *d, char *buf, size_t buf_len
   const int mt = d->co >= 128 ? 4 : edvr::cdiv(d->co, 32);  // the launch carrying most of the work
   snprintf(buf, buf_len, "conv2d_mfma_kernel<%d, %d, %d, %d>", d->ks, d->stride, mt, edvr::use_sw16(ho, wo) ? 16 : 32);
   return EDVR_OK;
+}
+
+int edvr_conv2d_gate_supported(const edvr_conv2d_desc *d) {
+  if (!d) return 0;
+  edvr_conv2d_desc q = *d;
+  if (!q.gate) q.gate = q.x1;  // any non-null pointer: only the eligibility rules are evaluated
+  return edvr::winograd_eligible(q) ? 1 : 0;  // (the direct kernel takes a gate too - correct, slower; this asks for the fused-fast path)
 }
 
 int edvr_conv2d_f32(const edvr_conv2d_desc *d, edvr_stream_t stream) {

@@ -377,6 +377,19 @@ int edvr_conv2d_wgrad_f32(const float *x1, const float *x2, const float *dz, flo
   return edvr_channel_sum_f32(dz, dbias, n, co, (int64_t)a.ho * a.wo, dz_img_stride, ws, ws_bytes, stream_);
 }
 
+int edvr_conv2d_wgrad_kernel_name(int n, int c1, int c2, int h, int w, int co, int ks, int stride, char *buf, size_t buf_len) {
+  using namespace edvr;
+  EDVR_REQUIRE(buf && buf_len > 0, "wgrad_kernel_name: bad arguments");
+  int splits = 0;
+  if (winograd_wgrad_get_algo() == EDVR_CONV_AUTO && wgrad_small_plan(n, c1, c2, h, w, co, ks, stride, &splits))
+    snprintf(buf, buf_len, "wgrad3x3_smallco_kernel");
+  else if (winograd_wgrad_plan(n, c1, c2, h, w, co, ks, stride, &splits))
+    snprintf(buf, buf_len, "conv3x3_winograd_wgrad_kernel");
+  else
+    snprintf(buf, buf_len, "conv2d_wgrad_kernel<%d, %d, %d>", ks, stride, wgrad_mw(co, stride));
+  return EDVR_OK;
+}
+
 int edvr_conv2d_wgrad_algo(int algo) {
   if (algo != EDVR_CONV_AUTO && algo != EDVR_CONV_DIRECT && algo != EDVR_CONV_WINOGRAD) {
     edvr::set_error("wgrad_algo: unknown algorithm %d", algo);

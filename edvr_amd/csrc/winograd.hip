@@ -37,6 +37,8 @@ struct WinoArgs {
   edvr_conv2d_desc d;
   const float *U;  // [ci_pad][16][cop]
   int ci, ci_real, cop, tiles_x, tiles_y, items;  // ci: rounded up to 16 (U has all-zero rows there), ci_real = c1 + c2
+  float ys, ys_gs;  // y_scale (0 -> 1) and y_scale * gate_slope, resolved on the host: kernel arguments live in SGPRs, a select or
+                    // a product computed in the kernel would occupy vector registers this kernel does not have
 };
 
 // Accumulators are plain vector values: with 128 of them per wave (two waves per SIMD share the unified 512-register file,
@@ -368,6 +370,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_kernel(const WinoArgs
     };
     if (res_fast) load_res(0);
     const float sgn = ph ? -1.f : 1.f;  // Y[0] = (t0 + t1) + t2,  Y[1] = -(t2 + t3) + t1
+    // y_scale rides on instructions the residual / gate variants already issue (add -> fma, gate select picks between two
+    // constants): bit-identical results for y_scale = 1, no cost; the other variants do not take a scale (winograd_eligible)
+    const float ys = a.ys, ys_gs = a.ys_gs;
 #ifndef WINO_EXP_NOXCHG
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
@@ -428,8 +433,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_kernel(const WinoArgs
             float v = mine[r][xx] + bias_r[r];
             if (SIG) v = (co >= d.act_from) ? __builtin_amdgcn_rcpf(1.f + __expf(-v)) : v;
             else v = fmaxf(v, sl * v);
-            if (RES == 1) v += rr[ri][xx];
-            if (RES == 2) v = rr[ri][xx] > 0.f ? v : d.gate_slope * v;
+            if (RES == 1) v = __builtin_fmaf(v, ys, rr[ri][xx]);
+            if (RES == 2) v *= rr[ri][xx] > 0.f ? ys : ys_gs;
             o[xx] = v;
           }
           if (SHF) {
@@ -528,6 +533,7 @@ bool winograd_eligible(const edvr_conv2d_desc &d) {
       (d.out_mode != EDVR_OUT_NCHW && has_res))
     return false;
   if (d.algo == EDVR_CONV_DIRECT) return false;
+  if (d.y_scale != 0.f && d.y_scale != 1.f && !d.res1 && !d.gate) return false;  // the scale lives in the residual / gate epilogues
   const bool applicable = d.ks == 3 && d.stride == 1;  // any channel count: the loop runs over ci rounded up to 16
   if (d.algo == EDVR_CONV_WINOGRAD) return applicable;  // explicit request: any size the kernel can do
   return enabled && applicable && d.co >= 48 && d.c1 + d.c2 >= 32 && d.w > 16 && d.h >= 4;  // auto: only where it beats the direct kernel
@@ -540,6 +546,8 @@ int winograd_launch(const edvr_conv2d_desc &d, const float *U, int cop, hipStrea
   a.ci_real = d.c1 + d.c2;
   a.ci = (a.ci_real + 15) / 16 * 16;
   a.cop = cop;
+  a.ys = d.y_scale == 0.f ? 1.f : d.y_scale;
+  a.ys_gs = a.ys * d.gate_slope;
   a.tiles_x = cdiv(d.w, 32);
   a.tiles_y = cdiv(d.h, 8);
   a.items = a.tiles_x * a.tiles_y * cdiv(d.co, 64) * d.n;

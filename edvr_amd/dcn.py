@@ -70,12 +70,15 @@ class ModulatedDeformConv(nn.Module):
             self.register_parameter('bias', None)
         self.init_weights()
 
+    @torch.no_grad()
     def init_weights(self):
+        # in-place ops on the Parameters themselves (not on .data): they bump the version counter the packed-weight cache
+        # of ops.pack_conv_weight is keyed on, so a re-initialisation after a first forward is seen by the kernels
         fan = self.in_channels * self.kernel_size[0] * self.kernel_size[1]
         bound = 1.0 / math.sqrt(fan)
-        self.weight.data.uniform_(-bound, bound)
+        self.weight.uniform_(-bound, bound)
         if self.bias is not None:
-            self.bias.data.zero_()
+            self.bias.zero_()
 
     def forward(self, x, offset, mask):
         return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation,
@@ -95,11 +98,12 @@ class ModulatedDeformConvPack(ModulatedDeformConv):
                                      bias=True)
         self.init_weights()
 
+    @torch.no_grad()
     def init_weights(self):
         super().init_weights()
         if hasattr(self, 'conv_offset'):
-            self.conv_offset.weight.data.zero_()
-            self.conv_offset.bias.data.zero_()
+            self.conv_offset.weight.zero_()
+            self.conv_offset.bias.zero_()
 
     def forward(self, x):
         from . import functional as F_
@@ -172,12 +176,13 @@ class DeformConv(nn.Module):
         self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // self.groups, *self.kernel_size))
         self.reset_parameters()
 
+    @torch.no_grad()
     def reset_parameters(self):
         n = self.in_channels
         for k in self.kernel_size:
             n *= k
         stdv = 1. / math.sqrt(n)
-        self.weight.data.uniform_(-stdv, stdv)
+        self.weight.uniform_(-stdv, stdv)
 
     def forward(self, x, offset):
         # the reference pads inputs smaller than the kernel (deform_conv.py:234-250); same shim, same crop
@@ -205,9 +210,10 @@ class DeformConvPack(DeformConv):
                                      dilation=_pair(self.dilation), bias=True)
         self.init_offset()
 
+    @torch.no_grad()
     def init_offset(self):
-        self.conv_offset.weight.data.zero_()
-        self.conv_offset.bias.data.zero_()
+        self.conv_offset.weight.zero_()
+        self.conv_offset.bias.zero_()
 
     def forward(self, x):
         from . import functional as F_

@@ -24,8 +24,8 @@ def _needs_grad(*ts):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
 
 
-def conv(m, x, *, x2=None, x2_map=None, act=ACT_NONE, act_from=0, res1=None, res2=None, out_mode=OUT_NCHW):
-    """act(conv(cat(x, x2)) + bias) + res1 + res2 with the parameters of nn.Conv2d `m`."""
+def conv(m, x, *, x2=None, x2_map=None, act=ACT_NONE, act_from=0, res1=None, res2=None, out_mode=OUT_NCHW, y_scale=1.0):
+    """y_scale * act(conv(cat(x, x2)) + bias) + res1 + res2 with the parameters of nn.Conv2d `m`."""
     ks, stride = _conv_geometry(m)
     if x.dim() != 4:
         raise ValueError(f'expected a 4-D input, got {tuple(x.shape)}')
@@ -35,11 +35,11 @@ def conv(m, x, *, x2=None, x2_map=None, act=ACT_NONE, act_from=0, res1=None, res
     ops.require_gpu(x, x2, m.weight)
     if _needs_grad(x, x2, m.weight, m.bias, res1, res2):
         from . import autograd as ag
-        return ag.conv(m, x, x2, x2_map, act, act_from, res1, res2, out_mode, ks, stride)
+        return ag.conv(m, x, x2, x2_map, act, act_from, res1, res2, out_mode, ks, stride, y_scale)
     wpk = ops.pack_conv_weight(m.weight)
     bias = m.bias.detach() if m.bias is not None else None
     return ops.conv2d(x, wpk, bias, m.out_channels, ks, x2=x2, x2_map=x2_map, stride=stride, act=act, act_from=act_from,
-                      res1=res1, res2=res2, out_mode=out_mode)
+                      res1=res1, res2=res2, out_mode=out_mode, y_scale=y_scale)
 
 
 def offset_mask_conv(conv_offset, feat):

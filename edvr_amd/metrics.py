@@ -3,7 +3,8 @@
 Mirrors xinntao/EDVR (BasicSR v1.2.0): tensor2img (basicsr/utils/img_util.py:36-98) followed by calculate_psnr
 (basicsr/metrics/psnr_ssim.py:7-51), which VideoBaseModel.dist_validation (video_base_model.py:60-98) runs per frame in NumPy
 after copying the frame to the host.  Here the clamp-round-uint8 conversion and the squared differences happen in one HIP
-kernel (csrc/metrics.hip) and only one double per image leaves the GPU.  SSIM (psnr_ssim.py:54-141) is not implemented.
+kernel (csrc/metrics.hip) and only one double per image leaves the GPU.  calculate_ssim (psnr_ssim.py:54-141) likewise: the
+11x11 Gaussian moments and the SSIM map are computed in float64 on the device, a few partial sums per image leave it.
 
 validate_clip() is the batched form of that loop for one clip: every frame's window of `num_frame` neighbours is built with
 generate_frame_indices (basicsr/data/data_util.py:35-88, the padding modes of the REDS4 / Vid4 test sets), windows run through
@@ -44,6 +45,29 @@ def calculate_psnr(pred, gt, crop_border=0, test_y_channel=False):
         mse = s / count
         out.append(float('inf') if mse == 0 else 20.0 * math.log10(255.0 / math.sqrt(mse)))
     return out
+
+
+def calculate_ssim(pred, gt, crop_border=0, test_y_channel=False):
+    """calculate_ssim(tensor2img(pred), tensor2img(gt), crop_border, test_y_channel=...) of the reference (psnr_ssim.py:90-141)
+    for every image of the batch, as a list of floats.  pred, gt: (n, c, h, w) or (c, h, w) fp32 CUDA tensors, RGB, c = 3 or 1."""
+    ops.require_gpu(pred, gt)
+    if pred.shape != gt.shape:
+        raise AssertionError(f'Image shapes are differnet: {tuple(pred.shape)}, {tuple(gt.shape)}.')  # psnr_ssim.py:118-119
+    if pred.dim() == 3:
+        pred, gt = pred[None], gt[None]
+    pred, gt = pred.contiguous(), gt.contiguous()
+    n, c, h, w = pred.shape
+    L = _lib.lib()
+    tiles = L.edvr_ssim_partials(h, w, int(crop_border))
+    if tiles == 0:
+        raise ValueError(f'calculate_ssim: {h}x{w} with crop_border {crop_border} leaves no 11x11 window')
+    y = 1 if (test_y_channel and c == 3) else 0
+    chans = 1 if y else c
+    partial = torch.empty(n, chans, tiles, dtype=torch.float64, device=pred.device)
+    _lib.check(L.edvr_ssim_f32(pred.data_ptr(), gt.data_ptr(), partial.data_ptr(), n, c, h, w, c * h * w, c * h * w, int(crop_border), y,
+                               torch.cuda.current_stream(pred.device).cuda_stream), 'edvr_ssim_f32')
+    count = (h - 2 * crop_border - 10) * (w - 2 * crop_border - 10)
+    return (partial.sum(2) / count).mean(1).cpu().tolist()
 
 
 def generate_frame_indices(crt_idx, max_frame_num, num_frames, padding='reflection'):

@@ -47,6 +47,19 @@ def _img_stride(t):
     return t.stride(0) if t.shape[0] > 1 else t.shape[1] * t.shape[2] * t.shape[3]
 
 
+def _run(name, launch, flops=0.0, nbytes=0.0):
+    """Every launch of this module goes through here: LAUNCH_HOOK (bench.py's instrumented pass) brackets it with events on
+    the launch stream and books `flops` / `nbytes` (ALGORITHMIC work of the call: each input / output element once) under `name`."""
+    if LAUNCH_HOOK is not None:
+        LAUNCH_HOOK(name, float(flops), launch, float(nbytes))
+    else:
+        launch()
+
+
+def _nb(*ts):
+    return 4.0 * sum(t.numel() for t in ts if t is not None)
+
+
 # ------------------------------------------------------------------------------------------------ workspace
 _WS = {}
 
@@ -94,6 +107,13 @@ def pack_conv_weight(weight, transpose_flip=False):
     return out
 
 
+def invalidate_packed_weights():
+    """Drop every cached packed weight.  The cache follows a parameter's autograd version and storage pointer, which in-place
+    torch ops, optimizers and load_state_dict maintain; a write through `.data` (or through a raw pointer that does not call
+    torch.autograd.graph.increment_version afterwards) does not - call this after such a write."""
+    _PACKED.clear()
+
+
 # ------------------------------------------------------------------------------------------------ conv
 DCN_SCATTER_AUTO, DCN_SCATTER_DEVICE, DCN_SCATTER_LDS, DCN_SCATTER_STRIP = 0, 1, 2, 3  # include/edvr_amd.h EDVR_DCN_SCATTER_*
 LAUNCH_HOOK = None  # callable(kernel_name, algorithmic_flops, launch_fn, algorithmic_bytes) or None
@@ -101,13 +121,14 @@ CONV_ALGO = CONV_AUTO  # default algorithm request of conv2d(); tests flip it to
 
 
 def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NONE, act_from=0, res1=None, res2=None,
-           out_mode=OUT_NCHW, out=None, algo=None, gate=None, gate_slope=0.0):
-    """y = act(conv(cat(x1, x2)) + bias) + res1 + res2 on the fp32 MFMA kernel.
+           out_mode=OUT_NCHW, out=None, algo=None, gate=None, gate_slope=0.0, y_scale=1.0):
+    """y = y_scale * act(conv(cat(x1, x2)) + bias) + res1 + res2 on the fp32 MFMA kernel.
     algo: CONV_AUTO (default; module-level CONV_ALGO overrides it, used by tests), CONV_DIRECT or CONV_WINOGRAD.
 
     x2_map = (div, mul, add): image i of x2 is (i // div) * mul + add (broadcast of a reference frame).
     gate (n, co, ho, wo): y *= gate > 0 ? 1 : gate_slope - the backward of a ReLU / LeakyReLU fused into the data-gradient conv
-    (3x3 stride 1 on the Winograd kernel only; raises where that kernel does not apply).
+    (3x3 kernels; in the Winograd kernel's epilogue where that kernel applies, else in the direct kernel's).
+    y_scale: ResidualBlockNoBN's res_scale (arch_util.py:95), 3x3 kernels only.
     """
     require_gpu(x1, x2, wpk, bias, res1, res2)
     L = _lib.lib()
@@ -149,18 +170,28 @@ def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NON
         assert tuple(gate.shape) == (n, co, ho, wo), f'gate shape {tuple(gate.shape)}'
         d.gate, d.gate_img_stride, d.gate_slope = _ptr(gate), _img_stride(gate), float(gate_slope)
     d.y, d.y_img_stride, d.out_mode = _ptr(out), _img_stride(out), out_mode
+    d.y_scale = float(y_scale)
     d.algo = CONV_ALGO if algo is None else algo
+    name, flops, nbytes = 'conv2d', 0.0, 0.0
     if LAUNCH_HOOK is not None:  # measurement only (bench.py): brackets the launch with events on this stream
         buf = ctypes.create_string_buffer(96)
         L.edvr_conv2d_kernel_name(ctypes.byref(d), buf, 96)
+        name = buf.value.decode()
         flops = 2.0 * n * ho * wo * co * (c1 + d.c2) * ks * ks
-        # algorithmic HBM bytes: every input / residual / output element once, plus the weights
-        nbytes = 4.0 * (n * (c1 + d.c2) * h * w + n * co * ho * wo * (1 + (res1 is not None) + (res2 is not None))
+        # algorithmic HBM bytes: every input / residual / gate / output element once, plus the weights
+        nbytes = 4.0 * (n * (c1 + d.c2) * h * w + n * co * ho * wo * (1 + (res1 is not None) + (res2 is not None) + (gate is not None))
                         + co * (c1 + d.c2) * ks * ks)
-        LAUNCH_HOOK(buf.value.decode(), flops, lambda: _lib.check(L.edvr_conv2d_f32(ctypes.byref(d), _stream()), 'edvr_conv2d_f32'), nbytes)
-    else:
-        _lib.check(L.edvr_conv2d_f32(ctypes.byref(d), _stream()), 'edvr_conv2d_f32')
+    _run(name, lambda: _lib.check(L.edvr_conv2d_f32(ctypes.byref(d), _stream()), 'edvr_conv2d_f32'), flops, nbytes)
     return out
+
+
+def conv_gate_supported(n, c, h, w, co, algo=None):
+    """Would conv2d(..., gate=...) of a 3x3 / stride-1 conv on (n, c, h, w) -> co channels be accepted?  (C-side rules: the
+    Winograd kernel must apply - sizes, algorithm request, EDVR_CONV_WINOGRAD=0 switch.)"""
+    d = _lib.ConvDesc()
+    d.c1, d.n, d.h, d.w, d.co, d.ks, d.stride = c, n, h, w, co, 3, 1
+    d.algo = CONV_ALGO if algo is None else algo
+    return bool(_lib.lib().edvr_conv2d_gate_supported(ctypes.byref(d)))
 
 
 # ------------------------------------------------------------------------------------------------ DCNv1
@@ -175,8 +206,9 @@ def dcnv1_forward(x, offset, weight, stride, pad, dil, groups, dg, halo_hint=0):
     y = torch.empty(B, Co, ho, wo, dtype=torch.float32, device=x.device)
     nbytes = L.edvr_dcnv1_fwd_ws_bytes(*dims)
     ws = workspace(nbytes, x.device)
-    _lib.check(L.edvr_dcnv1_fwd_f32(_ptr(x), _ptr(offset), _ptr(weight), _ptr(y), *dims, _bstride(offset), halo_hint, _ptr(ws), nbytes,
-                                    _stream()), 'edvr_dcnv1_fwd_f32')
+    _run('dcnv1_fwd', lambda: _lib.check(L.edvr_dcnv1_fwd_f32(_ptr(x), _ptr(offset), _ptr(weight), _ptr(y), *dims, _bstride(offset), halo_hint, _ptr(ws), nbytes,
+                                    _stream()),
+                                       'edvr_dcnv1_fwd_f32'), 2.0 * B * Co * ho * wo * weight.shape[1] * kh * kw, _nb(x, offset, weight, y))
     return y
 
 
@@ -192,8 +224,9 @@ def dcnv1_backward(x, offset, weight, dy, stride, pad, dil, groups, dg, scatter_
     dw = torch.empty_like(weight)
     nbytes = L.edvr_dcnv1_bwd_ws_bytes(*dims)
     ws = workspace(nbytes, x.device)
-    _lib.check(L.edvr_dcnv1_bwd_f32(_ptr(x), _ptr(offset), _ptr(weight), _ptr(dy), _ptr(dx), _ptr(doff), _ptr(dw), *dims,
-                                    _bstride(offset), _bstride(doff), int(scatter_hint), _ptr(ws), nbytes, _stream()), 'edvr_dcnv1_bwd_f32')
+    _run('dcnv1_bwd', lambda: _lib.check(L.edvr_dcnv1_bwd_f32(_ptr(x), _ptr(offset), _ptr(weight), _ptr(dy), _ptr(dx), _ptr(doff), _ptr(dw), *dims,
+                                    _bstride(offset), _bstride(doff), int(scatter_hint), _ptr(ws), nbytes, _stream()),
+                                       'edvr_dcnv1_bwd_f32'), 6.0 * dy.numel() * weight[0].numel(), _nb(x, offset, weight, dy, dx, doff, dw))
     return dx, doff, dw
 
 
@@ -228,8 +261,9 @@ def dcnv2_forward(x, offset, mask, weight, bias, stride, pad, dil, groups, dg, a
     y = torch.empty(B, Co, Ho, Wo, dtype=torch.float32, device=x.device)
     nbytes = L.edvr_dcnv2_fwd_ws_bytes(*dims)
     ws = workspace(nbytes, x.device)
-    _lib.check(L.edvr_dcnv2_fwd_f32(_ptr(x), _ptr(offset), _ptr(mask), _ptr(weight), _ptr(bias), _ptr(y), *dims,
-                                    _bstride(offset), _bstride(mask), act, halo_hint, _ptr(ws), nbytes, _stream()), 'edvr_dcnv2_fwd_f32')
+    _run('dcnv2_fwd', lambda: _lib.check(L.edvr_dcnv2_fwd_f32(_ptr(x), _ptr(offset), _ptr(mask), _ptr(weight), _ptr(bias), _ptr(y), *dims,
+                                    _bstride(offset), _bstride(mask), act, halo_hint, _ptr(ws), nbytes, _stream()),
+                                       'edvr_dcnv2_fwd_f32'), 2.0 * B * Co * Ho * Wo * weight.shape[1] * kh * kw, _nb(x, offset, mask, weight, y))
     return y
 
 
@@ -250,9 +284,10 @@ def dcnv2_backward(x, offset, mask, weight, dy, with_bias, stride, pad, dil, gro
     db = torch.empty(weight.shape[0], dtype=torch.float32, device=x.device) if with_bias else None
     nbytes = L.edvr_dcnv2_bwd_ws_bytes(*dims)
     ws = workspace(nbytes, x.device)
-    _lib.check(L.edvr_dcnv2_bwd_f32(_ptr(x), _ptr(offset), _ptr(mask), _ptr(weight), _ptr(dy), _ptr(dx), _ptr(doff), _ptr(dmsk),
+    _run('dcnv2_bwd', lambda: _lib.check(L.edvr_dcnv2_bwd_f32(_ptr(x), _ptr(offset), _ptr(mask), _ptr(weight), _ptr(dy), _ptr(dx), _ptr(doff), _ptr(dmsk),
                                     _ptr(dw), _ptr(db), *dims, _bstride(offset), _bstride(mask), _bstride(doff), _bstride(dmsk),
-                                    int(scatter_hint), _ptr(ws), nbytes, _stream()), 'edvr_dcnv2_bwd_f32')
+                                    int(scatter_hint), _ptr(ws), nbytes, _stream()),
+                                       'edvr_dcnv2_bwd_f32'), 6.0 * dy.numel() * weight[0].numel(), _nb(x, offset, mask, weight, dy, dx, doff, dmsk, dw))
     return dx, doff, dmsk, dw, db
 
 
@@ -264,8 +299,9 @@ def tsa_temporal(emb, emb_ref, aligned, want_prob=False):
     emb, emb_ref, aligned = emb.contiguous(), emb_ref.contiguous(), aligned.contiguous()
     out = torch.empty_like(aligned)
     prob = torch.empty(b, t, h, w, dtype=torch.float32, device=aligned.device) if want_prob else None
-    _lib.check(_lib.lib().edvr_tsa_temporal_f32(_ptr(emb), _ptr(emb_ref), _ptr(aligned), _ptr(out), _ptr(prob), b, t, c, h * w,
-                                                _stream()), 'edvr_tsa_temporal_f32')
+    _run('tsa_temporal', lambda: _lib.check(_lib.lib().edvr_tsa_temporal_f32(_ptr(emb), _ptr(emb_ref), _ptr(aligned), _ptr(out), _ptr(prob), b, t, c, h * w,
+                                                _stream()),
+                                       'edvr_tsa_temporal_f32'), 0, _nb(emb, emb_ref, aligned, out, prob))
     return (out, prob) if want_prob else out
 
 
@@ -274,7 +310,8 @@ def pool_maxavg(x):
     x = x.contiguous()
     n, c, h, w = x.shape
     y = torch.empty(n, 2 * c, (h - 1) // 2 + 1, (w - 1) // 2 + 1, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().edvr_pool_maxavg_3x3s2_f32(_ptr(x), _ptr(y), n, c, h, w, _stream()), 'edvr_pool_maxavg_3x3s2_f32')
+    _run('pool_maxavg_3x3s2', lambda: _lib.check(_lib.lib().edvr_pool_maxavg_3x3s2_f32(_ptr(x), _ptr(y), n, c, h, w, _stream()),
+                                       'edvr_pool_maxavg_3x3s2_f32'), 0, _nb(x, y))
     return y
 
 
@@ -283,7 +320,8 @@ def upsample2x(x, scale=1.0):
     x = x.contiguous()
     n, c, h, w = x.shape
     y = torch.empty(n, c, 2 * h, 2 * w, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().edvr_upsample2x_f32(_ptr(x), _ptr(y), n * c, h, w, float(scale), _stream()), 'edvr_upsample2x_f32')
+    _run('upsample2x', lambda: _lib.check(_lib.lib().edvr_upsample2x_f32(_ptr(x), _ptr(y), n * c, h, w, float(scale), _stream()),
+                                       'edvr_upsample2x_f32'), 0, _nb(x, y))
     return y
 
 
@@ -291,8 +329,8 @@ def tsa_combine(feat, attn, attn_add):
     require_gpu(feat, attn, attn_add)
     feat, attn, attn_add = feat.contiguous(), attn.contiguous(), attn_add.contiguous()
     y = torch.empty_like(feat)
-    _lib.check(_lib.lib().edvr_tsa_combine_f32(_ptr(feat), _ptr(attn), _ptr(attn_add), _ptr(y), feat.numel(), _stream()),
-               'edvr_tsa_combine_f32')
+    _run('tsa_combine', lambda: _lib.check(_lib.lib().edvr_tsa_combine_f32(_ptr(feat), _ptr(attn), _ptr(attn_add), _ptr(y), feat.numel(), _stream()),
+                                       'edvr_tsa_combine_f32'), 0, _nb(feat, attn, attn_add, y))
     return y
 
 
@@ -302,7 +340,8 @@ def upsample4x_add_(y, base):
     base = base.contiguous()
     n, c, h, w = base.shape
     assert y.is_contiguous() and tuple(y.shape) == (n, c, 4 * h, 4 * w)
-    _lib.check(_lib.lib().edvr_upsample4x_add_f32(_ptr(base), _ptr(y), n * c, h, w, _stream()), 'edvr_upsample4x_add_f32')
+    _run('upsample4x_add', lambda: _lib.check(_lib.lib().edvr_upsample4x_add_f32(_ptr(base), _ptr(y), n * c, h, w, _stream()),
+                                       'edvr_upsample4x_add_f32'), 0, _nb(base, y, y))
     return y
 
 
@@ -311,7 +350,8 @@ def add(a, b):
     a, b = a.contiguous(), b.contiguous()
     assert a.shape == b.shape
     y = torch.empty_like(a)
-    _lib.check(_lib.lib().edvr_add_f32(_ptr(a), _ptr(b), _ptr(y), a.numel(), _stream()), 'edvr_add_f32')
+    _run('add', lambda: _lib.check(_lib.lib().edvr_add_f32(_ptr(a), _ptr(b), _ptr(y), a.numel(), _stream()),
+                                       'edvr_add_f32'), 0, _nb(a, b, y))
     return y
 
 
@@ -323,8 +363,9 @@ def act_backward(dy, y, act, act_from=0, res1=None, res2=None):
     res2 = res2.contiguous() if res2 is not None else None
     n, c = y.shape[:2]
     dz = torch.empty_like(dy)
-    _lib.check(_lib.lib().edvr_act_bwd_f32(_ptr(dy), _ptr(y), _ptr(res1), _ptr(res2), _ptr(dz), n, c, y[0, 0].numel(), act, act_from,
-                                           _stream()), 'edvr_act_bwd_f32')
+    _run('act_bwd', lambda: _lib.check(_lib.lib().edvr_act_bwd_f32(_ptr(dy), _ptr(y), _ptr(res1), _ptr(res2), _ptr(dz), n, c, y[0, 0].numel(), act, act_from,
+                                           _stream()),
+                                       'edvr_act_bwd_f32'), 0, _nb(dy, y, res1, res2, dz))
     return dz
 
 
@@ -353,9 +394,17 @@ def conv2d_wgrad(x1, x2, x2_map, dz, co, ks, stride, want_db=False):
     nbytes = L.edvr_conv2d_wgrad_ws_bytes(n, c1 + c2, h, w, co, ks, stride)
     ws = workspace(nbytes, x1.device)
     db = torch.empty(co, dtype=torch.float32, device=x1.device) if want_db else None
-    _lib.check(L.edvr_conv2d_wgrad_f32(_ptr(x1), _ptr(x2), _ptr(dz), _ptr(dw), c1, c2, n, h, w, co, ks, stride, _img_stride(x1),
-                                       _img_stride(x2) if x2 is not None else 0, div, mul, add, _img_stride(dz), 0, _ptr(db), _ptr(ws),
-                                       nbytes, _stream()), 'edvr_conv2d_wgrad_f32')
+    name = 'conv2d_wgrad'
+    if LAUNCH_HOOK is not None:
+        buf = ctypes.create_string_buffer(96)
+        L.edvr_conv2d_wgrad_kernel_name(n, c1, c2, h, w, co, ks, stride, buf, 96)
+        name = buf.value.decode()
+    pad = ks // 2
+    ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
+    _run(name, lambda: _lib.check(L.edvr_conv2d_wgrad_f32(
+        _ptr(x1), _ptr(x2), _ptr(dz), _ptr(dw), c1, c2, n, h, w, co, ks, stride, _img_stride(x1), _img_stride(x2) if x2 is not None else 0,
+        div, mul, add, _img_stride(dz), 0, _ptr(db), _ptr(ws), nbytes, _stream()), 'edvr_conv2d_wgrad_f32'),
+        2.0 * n * ho * wo * co * (c1 + c2) * ks * ks, _nb(x1, dz, dw) + (4.0 * n * c2 * h * w if x2 is not None else 0.0))
     return (dw, db) if want_db else dw
 
 
@@ -366,8 +415,8 @@ def channel_sum(x):
     out = torch.empty(c, dtype=torch.float32, device=x.device)
     nbytes = 64 * c * 4
     ws = workspace(nbytes, x.device)
-    _lib.check(_lib.lib().edvr_channel_sum_f32(_ptr(x), _ptr(out), n, c, h * w, _img_stride(x), _ptr(ws), nbytes, _stream()),
-               'edvr_channel_sum_f32')
+    _run('channel_sum', lambda: _lib.check(_lib.lib().edvr_channel_sum_f32(_ptr(x), _ptr(out), n, c, h * w, _img_stride(x), _ptr(ws), nbytes, _stream()),
+                                       'edvr_channel_sum_f32'), 0, _nb(x))
     return out
 
 
@@ -376,7 +425,8 @@ def pixel_unshuffle2(x):
     x = x.contiguous()
     n, c, h2, w2 = x.shape
     y = torch.empty(n, 4 * c, h2 // 2, w2 // 2, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().edvr_pixel_unshuffle2_f32(_ptr(x), _ptr(y), n, c, h2 // 2, w2 // 2, _stream()), 'edvr_pixel_unshuffle2_f32')
+    _run('pixel_unshuffle2', lambda: _lib.check(_lib.lib().edvr_pixel_unshuffle2_f32(_ptr(x), _ptr(y), n, c, h2 // 2, w2 // 2, _stream()),
+                                       'edvr_pixel_unshuffle2_f32'), 0, _nb(x, y))
     return y
 
 
@@ -385,7 +435,8 @@ def zero_stuff2(dz, H, W):
     dz = dz.contiguous()
     n, c, ho, wo = dz.shape
     z = torch.empty(n, c, H, W, dtype=torch.float32, device=dz.device)
-    _lib.check(_lib.lib().edvr_zero_stuff2_f32(_ptr(dz), _ptr(z), n * c, H, W, ho, wo, _stream()), 'edvr_zero_stuff2_f32')
+    _run('zero_stuff2', lambda: _lib.check(_lib.lib().edvr_zero_stuff2_f32(_ptr(dz), _ptr(z), n * c, H, W, ho, wo, _stream()),
+                                       'edvr_zero_stuff2_f32'), 0, _nb(dz, z))
     return z
 
 
@@ -394,8 +445,8 @@ def frame_reduce_add_(src, dst, t, center):
     require_gpu(src, dst)
     src = src.contiguous()
     assert dst.is_contiguous() and src.shape == dst.shape and src.shape[0] % t == 0
-    _lib.check(_lib.lib().edvr_frame_reduce_add_f32(_ptr(src), _ptr(dst), src.shape[0] // t, t, center, src[0].numel(), _stream()),
-               'edvr_frame_reduce_add_f32')
+    _run('frame_reduce_add', lambda: _lib.check(_lib.lib().edvr_frame_reduce_add_f32(_ptr(src), _ptr(dst), src.shape[0] // t, t, center, src[0].numel(), _stream()),
+                                       'edvr_frame_reduce_add_f32'), 0, _nb(src) + 8.0 * src.numel() / t)
     return dst
 
 
@@ -404,8 +455,8 @@ def upsample2x_backward(dy, scale=1.0):
     dy = dy.contiguous()
     n, c, h2, w2 = dy.shape
     dx = torch.empty(n, c, h2 // 2, w2 // 2, dtype=torch.float32, device=dy.device)
-    _lib.check(_lib.lib().edvr_upsample2x_bwd_f32(_ptr(dy), _ptr(dx), n * c, h2 // 2, w2 // 2, float(scale), _stream()),
-               'edvr_upsample2x_bwd_f32')
+    _run('upsample2x_bwd', lambda: _lib.check(_lib.lib().edvr_upsample2x_bwd_f32(_ptr(dy), _ptr(dx), n * c, h2 // 2, w2 // 2, float(scale), _stream()),
+                                       'edvr_upsample2x_bwd_f32'), 0, _nb(dy, dx))
     return dx
 
 
@@ -414,8 +465,8 @@ def pool_maxavg_backward(x, dy):
     x, dy = x.contiguous(), dy.contiguous()
     n, c, h, w = x.shape
     dx = torch.empty_like(x)
-    _lib.check(_lib.lib().edvr_pool_maxavg_3x3s2_bwd_f32(_ptr(x), _ptr(dy), _ptr(dx), n, c, h, w, _stream()),
-               'edvr_pool_maxavg_3x3s2_bwd_f32')
+    _run('pool_maxavg_3x3s2_bwd', lambda: _lib.check(_lib.lib().edvr_pool_maxavg_3x3s2_bwd_f32(_ptr(x), _ptr(dy), _ptr(dx), n, c, h, w, _stream()),
+                                       'edvr_pool_maxavg_3x3s2_bwd_f32'), 0, _nb(x, dy, dx))
     return dx
 
 
@@ -424,8 +475,9 @@ def tsa_temporal_backward(emb, emb_ref, aligned, dout):
     emb, emb_ref, aligned, dout = emb.contiguous(), emb_ref.contiguous(), aligned.contiguous(), dout.contiguous()
     b, t, c, h, w = aligned.shape
     d_emb, d_ref, d_al = torch.empty_like(emb), torch.empty_like(emb_ref), torch.empty_like(aligned)
-    _lib.check(_lib.lib().edvr_tsa_temporal_bwd_f32(_ptr(emb), _ptr(emb_ref), _ptr(aligned), _ptr(dout), _ptr(d_emb), _ptr(d_ref),
-                                                    _ptr(d_al), b, t, c, h * w, _stream()), 'edvr_tsa_temporal_bwd_f32')
+    _run('tsa_temporal_bwd', lambda: _lib.check(_lib.lib().edvr_tsa_temporal_bwd_f32(_ptr(emb), _ptr(emb_ref), _ptr(aligned), _ptr(dout), _ptr(d_emb), _ptr(d_ref),
+                                                    _ptr(d_al), b, t, c, h * w, _stream()),
+                                       'edvr_tsa_temporal_bwd_f32'), 0, _nb(emb, emb_ref, aligned, dout, d_emb, d_ref, d_al))
     return d_emb, d_ref, d_al
 
 
@@ -433,8 +485,8 @@ def tsa_combine_backward(feat, attn, dy):
     require_gpu(feat, attn, dy)
     feat, attn, dy = feat.contiguous(), attn.contiguous(), dy.contiguous()
     dfeat, dattn = torch.empty_like(feat), torch.empty_like(attn)
-    _lib.check(_lib.lib().edvr_tsa_combine_bwd_f32(_ptr(feat), _ptr(attn), _ptr(dy), _ptr(dfeat), _ptr(dattn), feat.numel(), _stream()),
-               'edvr_tsa_combine_bwd_f32')
+    _run('tsa_combine_bwd', lambda: _lib.check(_lib.lib().edvr_tsa_combine_bwd_f32(_ptr(feat), _ptr(attn), _ptr(dy), _ptr(dfeat), _ptr(dattn), feat.numel(), _stream()),
+                                       'edvr_tsa_combine_bwd_f32'), 0, _nb(feat, attn, dy, dfeat, dattn))
     return dfeat, dattn
 
 
@@ -445,8 +497,9 @@ def charbonnier(pred, target, eps=1e-12, want_grad=True, grad_scale=1.0):
     assert pred.shape == target.shape
     loss = torch.empty(1, dtype=torch.float32, device=pred.device)
     dpred = torch.empty_like(pred) if want_grad else None
-    _lib.check(_lib.lib().edvr_charbonnier_f32(_ptr(pred), _ptr(target), _ptr(loss), _ptr(dpred), pred.numel(), float(eps),
-                                               float(grad_scale), _stream()), 'edvr_charbonnier_f32')
+    _run('charbonnier', lambda: _lib.check(_lib.lib().edvr_charbonnier_f32(_ptr(pred), _ptr(target), _ptr(loss), _ptr(dpred), pred.numel(), float(eps),
+                                               float(grad_scale), _stream()),
+                                       'edvr_charbonnier_f32'), 0, _nb(pred, target, dpred))
     return loss, dpred
 
 
@@ -456,7 +509,8 @@ def abs_sum_per_image(x):
     x = _as_planes(x)
     n, c, h, w = x.shape
     out = torch.empty(n, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().edvr_abs_sum_f32(_ptr(x), _ptr(out), n, c * h * w, _img_stride(x), _stream()), 'edvr_abs_sum_f32')
+    _run('abs_sum', lambda: _lib.check(_lib.lib().edvr_abs_sum_f32(_ptr(x), _ptr(out), n, c * h * w, _img_stride(x), _stream()),
+                                       'edvr_abs_sum_f32'), 0, _nb(x))
     return out
 
 

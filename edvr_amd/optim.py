@@ -45,6 +45,9 @@ class FusedAdam(torch.optim.Optimizer):
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self._static = None  # the moment buffers were replaced
+        for st in self.state.values():  # a resume file loaded with map_location=device puts 'step' on the GPU: float(step) in
+            if torch.is_tensor(st.get('step')) and st['step'].is_cuda:  # step() would then cost one host sync per parameter
+                st['step'] = st['step'].cpu()
 
     def _init_state(self, p):
         st = self.state[p]
@@ -73,7 +76,12 @@ class FusedAdam(torch.optim.Optimizer):
         if not items:
             return loss
         dev = items[0][0].device
-        key = tuple(id(p) for p, _ in items)
+        # The table holds RAW device pointers.  The key therefore carries them too: net.to() / .float() / `p.data = ...` /
+        # load_state_dict replace a parameter's (or a moment's) storage while the Parameter object - and id(p) - survive, and a
+        # table keyed on ids alone would keep writing through the stale pointers.
+        for p, _ in items:
+            self._init_state(p)
+        key = tuple((id(p), p.data_ptr(), self.state[p]['exp_avg'].data_ptr(), self.state[p]['exp_avg_sq'].data_ptr()) for p, _ in items)
         if self._static is None or self._static[0] != key:
             recs, owner = [], []
             for idx, (p, _) in enumerate(items):

@@ -104,6 +104,8 @@ typedef struct edvr_conv2d_desc {
                            * not together with residuals, sigmoid or PixelShuffle: EDVR_ERR_UNSUPPORTED otherwise. */
   int64_t gate_img_stride;
   float gate_slope;
+  float y_scale;          /* y = y_scale * act(conv + bias) [gated] + res1 + res2; 0 means 1.  ResidualBlockNoBN's res_scale
+                           * (arch_util.py:95).  3x3 convs only (EDVR_ERR_UNSUPPORTED for 1x1 / <= 4 output channels / PixelShuffle). */
 } edvr_conv2d_desc;
 
 size_t edvr_conv2d_packed_weight_elems(int co, int ci, int ks);
@@ -112,6 +114,10 @@ size_t edvr_conv2d_packed_weight_elems(int co, int ci, int ks);
 int edvr_conv2d_pack_weight_f32(const float *w, float *wpk, int co, int ci, int ks, int transpose_flip,
                                 edvr_stream_t stream);
 int edvr_conv2d_f32(const edvr_conv2d_desc *d, edvr_stream_t stream);
+/* 1 if edvr_conv2d_f32 would accept `d` with a `gate` (the Winograd kernel applies under d->algo, the sizes and the
+ * EDVR_CONV_WINOGRAD environment switch), else 0.  Callers that fuse an activation backward into a data-gradient conv ask
+ * first and keep the two-launch form otherwise. */
+int edvr_conv2d_gate_supported(const edvr_conv2d_desc *d);
 /* Name of the kernel template instantiation edvr_conv2d_f32 would launch for `d` (as rocprofv3 prints it),
  * written to buf; returns 0 or EDVR_ERR_*.  Measurement aid only. */
 int edvr_conv2d_kernel_name(const edvr_conv2d_desc *d, char *buf, size_t buf_len);
@@ -208,6 +214,8 @@ int edvr_conv2d_wgrad_f32(const float *x1, const float *x2, const float *dz, flo
                           int co, int ks, int stride, int64_t x1_img_stride, int64_t x2_img_stride, int x2_div, int x2_mul,
                           int x2_add, int64_t dz_img_stride, int accumulate, float *dbias, void *ws, size_t ws_bytes,
                           edvr_stream_t stream);
+/* Name of the kernel edvr_conv2d_wgrad_f32 would launch for this layer (as rocprofv3 prints it).  Measurement aid only. */
+int edvr_conv2d_wgrad_kernel_name(int n, int c1, int c2, int h, int w, int co, int ks, int stride, char *buf, size_t buf_len);
 /* dbias (nullable): also db[co] = sum_{n,pixel} dz (the bias gradient).  The Winograd-domain kernel holds every dz value in
  * registers already and adds it to its two launches; the direct kernel runs edvr_channel_sum_f32 afterwards. */
 
@@ -246,6 +254,15 @@ int edvr_charbonnier_f32(const float *pred, const float *target, float *loss, fl
  * (metric_util.py:34-47; float32, not rounded), one value per pixel. */
 int edvr_psnr_sse_f32(const float *a, const float *b, double *partial, int n, int c, int h, int w, int64_t a_img_stride,
                       int64_t b_img_stride, int crop_border, int y_channel, int blocks, edvr_stream_t stream);
+
+/* Validation SSIM on the device <- tensor2img + calculate_ssim / _ssim (basicsr/metrics/psnr_ssim.py:54-141): per channel, 11x11
+ * Gaussian window (sigma 1.5) over the clamp-round-uint8 images in float64, valid region only, mean of the SSIM map.  a, b as
+ * for edvr_psnr_sse_f32.  partial[(img * channels + ch) * tiles + k], tiles = edvr_ssim_partials(h, w, crop_border), channels =
+ * 1 when y_channel (and c == 3) else c, receives the k-th partial SUM of the SSIM map: add them, divide by
+ * (h - 2 crop - 10) * (w - 2 crop - 10), average over channels.  Images without room for one window -> EDVR_ERR_ARG. */
+size_t edvr_ssim_partials(int h, int w, int crop_border);
+int edvr_ssim_f32(const float *a, const float *b, double *partial, int n, int c, int h, int w, int64_t a_img_stride,
+                  int64_t b_img_stride, int crop_border, int y_channel, edvr_stream_t stream);
 
 /* Input pipeline, device side <- imfrombytes(float32=True) (basicsr/utils/img_util.py:101-123: uint8 -> float32 / 255.), augment
  * (basicsr/data/transforms.py:84-151: hflip, then vflip, then transpose, the same state for every image of a clip), img2tensor

@@ -201,6 +201,39 @@ def psnr_cropped(pred, gt, crop_border=0, test_y_channel=False):
     return float('inf') if mse == 0 else float(20. * math.log10(255. / math.sqrt(mse)))
 
 
+def ssim_cropped(pred, gt, crop_border=0, test_y_channel=False):
+    """calculate_ssim(tensor2img(pred), tensor2img(gt), crop_border, 'HWC', test_y_channel) restated in NumPy for ONE image
+    (c, h, w), RGB channel order (psnr_ssim.py:54-141): per channel, cv2.getGaussianKernel(11, 1.5) outer window correlated
+    over the float64 images, valid region [5:-5, 5:-5], mean of the SSIM map; mean over channels."""
+    import numpy as np
+    a = tensor2img_uint8(pred).numpy().astype(np.float64)
+    b = tensor2img_uint8(gt).numpy().astype(np.float64)
+    if crop_border:
+        a, b = a[:, crop_border:-crop_border, crop_border:-crop_border], b[:, crop_border:-crop_border, crop_border:-crop_border]
+    if test_y_channel and a.shape[0] == 3:
+        def to_y(img):  # to_y_channel: float32 / 255, BGR dot + 16, / 255 in float32, x 255 (metric_util.py:34-47)
+            f = img.astype(np.float32) / 255.
+            y = np.dot(np.moveaxis(f[::-1], 0, -1), [24.966, 128.553, 65.481]) + 16.0
+            return ((y / 255.).astype(np.float32) * 255.)[None].astype(np.float64)
+        a, b = to_y(a), to_y(b)
+    k = np.exp(-0.5 / 1.5 ** 2 * (np.arange(11) - 5.0) ** 2)
+    k = k / k.sum()
+    win = np.outer(k, k)
+    C1, C2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+
+    def filt(img):  # cv2.filter2D(img, -1, window)[5:-5, 5:-5] = plain correlation over the valid region
+        v = np.lib.stride_tricks.sliding_window_view(img, (11, 11))
+        return np.einsum('ijkl,kl->ij', v, win)
+
+    vals = []
+    for i in range(a.shape[0]):
+        x, y = a[i], b[i]
+        mu1, mu2 = filt(x), filt(y)
+        s1, s2, s12 = filt(x * x) - mu1 ** 2, filt(y * y) - mu2 ** 2, filt(x * y) - mu1 * mu2
+        vals.append((((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 ** 2 + mu2 ** 2 + C1) * (s1 + s2 + C2))).mean())
+    return float(np.array(vals).mean())
+
+
 def charbonnier_sum(pred, target, eps=1e-12):
     """basicsr/models/losses/losses.py:23-25 with reduction='sum'."""
     return torch.sqrt((pred - target) ** 2 + eps).sum()

@@ -124,6 +124,59 @@ def psnr_case():
     torch.save(dict(pred=pred, gt=gt, cases=cases), os.path.join(OUT, 'psnr.pt'))
 
 
+def ssim_case():
+    """SSIM of the reference's own calculate_ssim (basicsr/metrics/psnr_ssim.py:54-141) on the tensors of psnr.pt.  cv2 is absent:
+    its two calls are supplied from their documented definitions - getGaussianKernel(11, 1.5) = normalised exp(-(i-5)^2 / 2 sigma^2),
+    filter2D = correlation with BORDER_REFLECT_101 (scipy.ndimage.correlate, mode 'mirror'; only the valid region is used)."""
+    import sys
+    import types
+    import importlib.util
+    import numpy as np
+    from scipy import ndimage
+    cv2 = types.ModuleType('cv2')
+
+    def gk(ksize, sigma):
+        x = np.arange(ksize, dtype=np.float64) - (ksize - 1) * 0.5
+        k = np.exp(-0.5 / (sigma * sigma) * x * x)
+        return (k / k.sum()).reshape(-1, 1)
+    cv2.getGaussianKernel = gk
+    cv2.filter2D = lambda img, ddepth, kernel: ndimage.correlate(img, kernel, mode='mirror')
+    saved = sys.modules.get('cv2')
+    sys.modules['cv2'] = cv2
+    for pkg in ('basicsr', 'basicsr.utils', 'basicsr.metrics'):
+        if pkg not in sys.modules:
+            m = types.ModuleType(pkg)
+            m.__path__ = []
+            sys.modules[pkg] = m
+
+    def load(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join('/root/reference', rel))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+        return mod
+    load('basicsr.utils.matlab_functions', 'basicsr/utils/matlab_functions.py')
+    load('basicsr.metrics.metric_util', 'basicsr/metrics/metric_util.py')
+    calculate_ssim = load('basicsr.metrics.psnr_ssim', 'basicsr/metrics/psnr_ssim.py').calculate_ssim
+    from oracle import edvr_oracle as EO
+    d = torch.load(os.path.join(OUT, 'psnr.pt'))
+    pred, gt = d['pred'], d['gt']
+
+    def hwc_bgr(t):
+        u = EO.tensor2img_uint8(t).numpy()
+        return u[::-1].transpose(1, 2, 0) if u.shape[0] == 3 else u.transpose(1, 2, 0)
+    cases = []
+    for crop in (0, 2):
+        for ych in (False, True):
+            cases.append(dict(crop_border=crop, test_y_channel=ych, gray=False,
+                              ssim=[float(calculate_ssim(hwc_bgr(pred[i]), hwc_bgr(gt[i]), crop, 'HWC', ych)) for i in range(3)]))
+    cases.append(dict(crop_border=1, test_y_channel=False, gray=True,
+                      ssim=[float(calculate_ssim(hwc_bgr(pred[i, :1]), hwc_bgr(gt[i, :1]), 1, 'HWC', False)) for i in range(3)]))
+    torch.save(dict(cases=cases, note='inputs: pred / gt of psnr.pt'), os.path.join(OUT, 'ssim.pt'))
+    if saved is not None:
+        sys.modules['cv2'] = saved
+
+
 def frame_indices_case():
     """generate_frame_indices of the reference (basicsr/data/data_util.py:35-88), executed from its source text (the module
     itself imports cv2 / lmdb helpers): every centre index of sequences of 7, 10 and 100 frames, 5- and 7-frame windows."""
@@ -389,6 +442,7 @@ def main():
         torch.save(dcn1_case(name), os.path.join(OUT, f'dcn1_{name}.pt'))
     lr_sched_case()
     psnr_case()
+    ssim_case()
     frame_indices_case()
     data_case()
     video_test_case()

@@ -48,7 +48,7 @@ def train(args, log=print):
                                   cache_data=True, num_frame=args.num_frame, padding='reflection_circle'), device=device)
     it, epoch = 0, 0
     if args.resume:
-        state = torch.load(args.resume, map_location=device)
+        state = torch.load(args.resume, map_location='cpu')  # optimizer 'step' counters stay host-side (no per-parameter sync in step())
         resume_training(state, [opt], [sched])
         it, epoch = state['iter'], state['epoch']
         loader.reset(epoch)
@@ -64,7 +64,7 @@ def train(args, log=print):
             log(f'iter {it}: trainable parameter set changed (TSA schedule)')
         opt.zero_grad(set_to_none=True)
         out = model(batch['lq'])
-        loss = charbonnier_loss(out, batch['gt']) / out.numel()  # CharbonnierLoss(reduction='mean') of the EDVR configs
+        loss = charbonnier_loss(out, batch['gt'])  # CharbonnierLoss, loss_weight 1.0, reduction: sum (options/train/EDVR/*.yml pixel_opt)
         loss.backward()
         opt.step()
         sched.step()

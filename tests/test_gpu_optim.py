@@ -84,3 +84,34 @@ def test_fused_adam_step_is_seen_by_the_next_forward(gpu):
         before = conv.weight.detach().clone()
         opt.step()
         assert conv.weight._version > v0 and not torch.equal(before, conv.weight.detach())
+
+
+def test_fused_adam_follows_replaced_storage(gpu):
+    """The chunk table holds raw device pointers (round-1 advisor finding): replacing a parameter's storage while the Parameter
+    object survives (net.to(), .float(), `p.data = ...`, load_state_dict of the optimizer) must not leave stale pointers behind."""
+    from edvr_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(3)
+    ps = [torch.nn.Parameter(torch.randn(257, 33, generator=g).to(gpu)), torch.nn.Parameter(torch.randn(70000, generator=g).to(gpu))]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt, ropt = FusedAdam(ps, lr=1e-2), torch.optim.Adam(ref, lr=1e-2)
+
+    def step():
+        for p, r in zip(ps, ref):
+            gr = torch.randn(p.shape, generator=g).to(gpu)
+            p.grad, r.grad = gr.clone(), gr.clone()
+        opt.step()
+        ropt.step()
+
+    step()
+    old = [p.data for p in ps]
+    old_vals = [o.clone() for o in old]
+    for p in ps:
+        p.data = p.data.clone()  # same Parameter object, new storage (what net.to() / .float() do)
+    step()
+    for o, ov in zip(old, old_vals):
+        assert torch.equal(o, ov)  # the abandoned storage was not written
+    sd = opt.state_dict()
+    opt.load_state_dict(sd)  # replaces the moment buffers
+    step()
+    for p, r in zip(ps, ref):
+        assert (p - r).abs().max().item() < 1e-6

@@ -35,38 +35,52 @@ def conv_algo(request):
     ops.CONV_ALGO = ops.CONV_AUTO
 
 
+KINK_BAND = 1e-4  # |pre-activation| below this is "on the kink" of ReLU / LeakyReLU (fp32 forward error is ~1e-6 of max|z|)
+
+
+def _move_off_the_kink(m64, xin, act_from):
+    """Round-1 flake, root-caused (profiles/r2/flake_rootcause_*.log, scripts/flake_hunt.py): the derivative of ReLU / LeakyReLU
+    jumps at z = 0; the HIP path takes it from the sign of its fp32 output, fp64 autograd from its own.  When a pre-activation is
+    smaller than the forward rounding error the two pick different sides and ONE such element changes dz by 0.9 dy there (5e-2
+    relative gradient error; seed 659 of 1500: |z| = 3.2e-8; the oracle run with the HIP forward's sides agrees to 3e-7).  The
+    kernels themselves are bit-reproducible (profiles/r2/repeat_hunt_400x16.log).  A gradient comparison is only meaningful away
+    from the kink, so the bias of any channel with a pre-activation inside KINK_BAND is nudged until none is left."""
+    with torch.no_grad():
+        for _ in range(50):
+            near = m64(xin).abs() < KINK_BAND
+            near[:, :act_from] = False
+            ch = near.any(0).any(-1).any(-1)
+            if not ch.any():
+                return
+            m64.bias[ch] += 3.7e-3
+    raise AssertionError('could not move the test inputs off the activation kink')
+
+
 @pytest.mark.parametrize('case', CONV_CASES)
 def test_conv_gradients(gpu, case, conv_algo):
-    """Forward + all gradients of one fused conv launch against fp64 autograd.
-
-    One unexplained failure of [winograd-case0] was seen in ~25 executions of this test during round 1 (same binary passed
-    immediately before and after; 60 repeats with NaN-poisoned free memory, scripts/flake_hunt.py, were clean).  Until it is
-    understood, a failed attempt is repeated ONCE and, if the repeat passes, reported as a warning with the first attempt's
-    error instead of stopping the suite - a second failure fails the test."""
-    import warnings
-    try:
-        _conv_gradients(gpu, case)
-    except AssertionError as first:
-        torch.cuda.synchronize()
-        _conv_gradients(gpu, case)
-        warnings.warn(f'test_conv_gradients{case} ({conv_algo}) failed once and passed on repeat: {str(first)[:300]}')
-
-
-def _conv_gradients(gpu, case):
+    """Forward + all gradients of one fused conv launch against fp64 autograd (strict: no retry)."""
     from edvr_amd import functional as F_
     n, c1, c2, h, w, co, ks, stride, actn, nres, out_mode = case
+    torch.manual_seed(1234 + CONV_CASES.index(case))  # nn.Conv2d's init draws from the GLOBAL generator: pin it
     g = torch.Generator().manual_seed(11)
-    m = torch.nn.Conv2d(c1 + c2, co, ks, stride, ks // 2)
+    m64 = torch.nn.Conv2d(c1 + c2, co, ks, stride, ks // 2).double()
     x1 = torch.randn(n, c1, h, w, generator=g)
     x2 = torch.randn(n, c2, h, w, generator=g) if c2 else None
     act, act_from = {'none': (0, 0), 'relu': (1, 0), 'lrelu': (2, 0), 'sigmoid_from': (3, 2 * co // 3)}[actn]
     ho, wo = (h + 2 * (ks // 2) - ks) // stride + 1, (w + 2 * (ks // 2) - ks) // stride + 1
     res = [torch.randn(n, co, ho, wo, generator=g) for _ in range(nres)]
-    # oracle (fp64 autograd)
-    m64 = torch.nn.Conv2d(c1 + c2, co, ks, stride, ks // 2).double()
-    m64.load_state_dict({k: v.double() for k, v in m.state_dict().items()})
+    # oracle (fp64 autograd) on parameters that are exactly representable in fp32
+    with torch.no_grad():
+        for p_ in m64.parameters():
+            p_.copy_(p_.float().double())
     leaves = [t.double().requires_grad_() for t in [x1] + ([x2] if c2 else []) + res]
     xin = torch.cat(leaves[:2], 1) if c2 else leaves[0]
+    if actn in ('relu', 'lrelu'):
+        _move_off_the_kink(m64, xin.detach(), act_from)
+        with torch.no_grad():
+            m64.bias.copy_(m64.bias.float().double())
+    m = torch.nn.Conv2d(c1 + c2, co, ks, stride, ks // 2)
+    m.load_state_dict({k: v.float() for k, v in m64.state_dict().items()})
     y = m64(xin)
     if actn == 'relu':
         y = F.relu(y)
@@ -115,29 +129,60 @@ def test_conv_gate_epilogue(gpu, shape, slope):
     assert torch.equal(gated, ref)
 
 
-def test_conv_gate_needs_the_winograd_kernel(gpu):
+@pytest.mark.parametrize('res', [False, True])
+def test_conv_gate_on_the_direct_kernel(gpu, res):
+    """Where the Winograd kernel does not apply (or is switched off) the direct kernel's generic store variant takes the gate."""
     from edvr_amd import ops
-    x = torch.randn(1, 64, 8, 8, device=gpu)
-    wpk = ops.pack_conv_weight(torch.randn(64, 64, 3, 3, device=gpu))
-    with pytest.raises(RuntimeError):
-        ops.conv2d(x, wpk, None, 64, 3, gate=x, algo=ops.CONV_DIRECT)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 64, 9, 14, generator=g).to(gpu)
+    wpk = ops.pack_conv_weight((torch.randn(64, 64, 3, 3, generator=g) * 0.05).to(gpu))
+    gate = torch.randn(2, 64, 9, 14, generator=g).relu().to(gpu)
+    r1 = torch.randn(2, 64, 9, 14, generator=g).to(gpu) if res else None
+    plain = ops.conv2d(x, wpk, None, 64, 3, algo=ops.CONV_DIRECT)
+    gated = ops.conv2d(x, wpk, None, 64, 3, gate=gate, gate_slope=0.1, res1=r1, algo=ops.CONV_DIRECT)
+    ref = torch.where(gate > 0, plain, 0.1 * plain)
+    assert torch.equal(gated, ref + r1 if res else ref)
+    assert not ops.conv_gate_supported(2, 64, 9, 14, 64, ops.CONV_DIRECT) and ops.conv_gate_supported(2, 64, 20, 36, 64)
+
+
+@pytest.mark.parametrize('algo', ['direct', 'winograd'])
+@pytest.mark.parametrize('scale', [0.2, -1.5])
+def test_conv_y_scale(gpu, algo, scale):
+    """y = y_scale * (conv + bias) + res1 (+ gate): the scalar lives in the residual / gate epilogues of both kernels."""
+    from edvr_amd import ops
+    a = {'direct': ops.CONV_DIRECT, 'winograd': ops.CONV_WINOGRAD}[algo]
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 64, 20, 36, generator=g).to(gpu)
+    wpk = ops.pack_conv_weight((torch.randn(64, 64, 3, 3, generator=g) * 0.05).to(gpu))
+    b = torch.randn(64, generator=g).to(gpu)
+    r1 = torch.randn(2, 64, 20, 36, generator=g).to(gpu)
+    gate = torch.randn(2, 64, 20, 36, generator=g).relu().to(gpu)
+    plain = ops.conv2d(x, wpk, b, 64, 3, algo=a)
+    assert _rel(ops.conv2d(x, wpk, b, 64, 3, res1=r1, y_scale=scale, algo=a).cpu(), (scale * plain + r1).double().cpu()) < 1e-6
+    assert _rel(ops.conv2d(x, wpk, b, 64, 3, y_scale=scale, algo=a).cpu(), (scale * plain).double().cpu()) < 1e-6
+    got = ops.conv2d(x, wpk, b, 64, 3, gate=gate, gate_slope=0.1, y_scale=scale, algo=a)
+    assert _rel(got.cpu(), (scale * torch.where(gate > 0, plain, 0.1 * plain)).double().cpu()) < 1e-6
+    with pytest.raises(RuntimeError):  # 1x1 kernels take no scale
+        ops.conv2d(x, ops.pack_conv_weight(torch.randn(64, 64, 1, 1, device=gpu)), None, 64, 1, y_scale=scale)
 
 
 @pytest.mark.parametrize('shape', [(2, 64, 20, 36), (1, 128, 10, 24)])
 @pytest.mark.parametrize('frozen', [False, True])
-def test_residual_block_fused_backward(gpu, shape, frozen):
-    """ResidualBlockNoBN as one autograd node (ReLU backward + identity gradient fused into the dgrad launches) vs fp64 autograd."""
+@pytest.mark.parametrize('res_scale', [1, 0.2])
+def test_residual_block_fused_backward(gpu, shape, frozen, res_scale):
+    """ResidualBlockNoBN as one autograd node (ReLU backward + identity gradient fused into the dgrad launches) vs fp64 autograd;
+    res_scale != 1 (arch_util.py:95) rides in the same epilogues."""
     from edvr_amd.arch_util import ResidualBlockNoBN
     n, c, h, w = shape
     g = torch.Generator().manual_seed(17)
-    blk = ResidualBlockNoBN(c)
+    blk = ResidualBlockNoBN(c, res_scale=res_scale)
     for p_ in blk.parameters():
         p_.data = torch.randn(p_.shape, generator=g) * 0.05
     x = torch.randn(n, c, h, w, generator=g)
     dy = torch.randn(n, c, h, w, generator=g)
     w1, b1, w2, b2 = [p_.detach().double().requires_grad_() for p_ in (blk.conv1.weight, blk.conv1.bias, blk.conv2.weight, blk.conv2.bias)]
     x64 = x.double().requires_grad_()
-    y64 = x64 + F.conv2d(F.relu(F.conv2d(x64, w1, b1, padding=1)), w2, b2, padding=1)
+    y64 = x64 + res_scale * F.conv2d(F.relu(F.conv2d(x64, w1, b1, padding=1)), w2, b2, padding=1)
     y64.backward(dy.double())
     blk = blk.to(gpu)
     if frozen:  # TSA-only phase: trunk weights frozen, gradient still flows to the input
@@ -154,6 +199,60 @@ def test_residual_block_fused_backward(gpu, shape, frozen):
     else:
         for ours, ref in [(blk.conv1.weight, w1), (blk.conv1.bias, b1), (blk.conv2.weight, w2), (blk.conv2.bias, b2)]:
             assert _rel(ours.grad, ref.grad) < GRAD_RTOL
+
+
+@pytest.mark.parametrize('res_scale', [1, 0.3])
+def test_residual_block_unfused_path(gpu, res_scale):
+    """Sizes the Winograd kernel does not take (w <= 16): two ConvFn nodes on the direct kernel, res_scale through ConvFn."""
+    from edvr_amd.arch_util import ResidualBlockNoBN
+    g = torch.Generator().manual_seed(18)
+    blk = ResidualBlockNoBN(32, res_scale=res_scale)
+    with torch.no_grad():
+        for p_ in blk.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g) * 0.05)
+    x, dy = torch.randn(2, 32, 10, 12, generator=g), torch.randn(2, 32, 10, 12, generator=g)
+    ps = [p_.detach().double().requires_grad_() for p_ in blk.parameters()]
+    x64 = x.double().requires_grad_()
+    y64 = x64 + res_scale * F.conv2d(F.relu(F.conv2d(x64, ps[0], ps[1], padding=1)), ps[2], ps[3], padding=1)
+    y64.backward(dy.double())
+    blk = blk.to(gpu)
+    xd = x.to(gpu).requires_grad_()
+    y = blk(xd)
+    assert not type(y.grad_fn).__name__.startswith('ResBlockFn')
+    assert _rel(y.detach(), y64.detach()) < 2e-5
+    y.backward(dy.to(gpu))
+    assert _rel(xd.grad, x64.grad) < GRAD_RTOL
+    for ours, ref in zip(blk.parameters(), ps):
+        assert _rel(ours.grad, ref.grad) < GRAD_RTOL
+
+
+def test_training_backward_with_the_winograd_kernel_switched_off():
+    """EDVR_CONV_WINOGRAD=0 (the documented fallback switch) is read once per process: a child process trains one residual block
+    on the direct kernels only (round-1 advisor finding: the fused ReLU-backward gate used to raise there)."""
+    import os
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    code = (
+        'import torch, torch.nn.functional as F\n'
+        'from edvr_amd.arch_util import ResidualBlockNoBN\n'
+        'from edvr_amd import ops\n'
+        'assert not ops.conv_gate_supported(2, 64, 20, 36, 64)\n'
+        'torch.manual_seed(3)\n'
+        'blk = ResidualBlockNoBN(64); x = torch.randn(2, 64, 20, 36); dy = torch.randn(2, 64, 20, 36)\n'
+        'ps = [p.detach().double().requires_grad_() for p in blk.parameters()]\n'
+        'x64 = x.double().requires_grad_()\n'
+        '(x64 + F.conv2d(F.relu(F.conv2d(x64, ps[0], ps[1], padding=1)), ps[2], ps[3], padding=1)).backward(dy.double())\n'
+        'blk = blk.cuda(); xd = x.cuda().requires_grad_(); blk(xd).backward(dy.cuda())\n'
+        'rel = lambda a, r: ((a.double().cpu() - r).abs().max() / r.abs().max()).item()\n'
+        'errs = [rel(xd.grad, x64.grad)] + [rel(p.grad, r.grad) for p, r in zip(blk.parameters(), ps)]\n'
+        'assert max(errs) < 5e-4, errs\n'
+        'print("ok", max(errs))\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, EDVR_CONV_WINOGRAD='0', PYTHONPATH=root), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and 'ok' in r.stdout, r.stdout + r.stderr
 
 
 def test_conv_gradient_with_reference_frame_map(gpu):
@@ -234,7 +333,7 @@ def test_charbonnier(gpu):
     assert _rel(pg.grad, p64.grad) < 1e-5
 
 
-@pytest.mark.parametrize('name', ['M_T5', 'L_deblur_hr', 'M_noTSA'])
+@pytest.mark.parametrize('name', ['M_T5', 'L_deblur_hr', 'M_noTSA', 'L_T7'])
 def test_edvr_parameter_gradients_match_oracle(gpu, name, conv_algo):
     """Whole network: d(Charbonnier sum)/d(every parameter), HIP fp32 vs oracle autograd fp64.
     The bound is calibrated per tensor against the fp32 noise floor of the oracle itself (same algorithm in fp32 on the
