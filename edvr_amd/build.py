@@ -16,11 +16,8 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libedvr_amd.so')
 OBJDIR = os.path.join(HERE, 'build')
-SOURCES = ['api.hip', 'conv2d.hip', 'dcn.hip', 'elementwise.hip', 'wgrad.hip', 'backward.hip', 'dcn_fused.hip', 'winograd.hip', 'winograd_wgrad.hip', 'blas.hip', 'optim.hip', 'metrics.hip', 'conv_small.hip', 'conv1x1.hip', 'data.hip']
-# rocBLAS: the two plain GEMMs of the DCNv2 backward (csrc/blas.hip).  In a PyTorch process the already-loaded librocblas.so.5
-# of torch satisfies the dependency; stand-alone C hosts get it from the ROCm install.
-LINK = ['-L' + os.path.join(os.environ.get('ROCM_PATH', '/opt/rocm'), 'lib'), '-lrocblas',
-        '-Wl,-rpath,' + os.path.join(os.environ.get('ROCM_PATH', '/opt/rocm'), 'lib')]
+SOURCES = ['api.hip', 'conv2d.hip', 'dcn.hip', 'elementwise.hip', 'wgrad.hip', 'backward.hip', 'dcn_fused.hip', 'winograd.hip', 'winograd_wgrad.hip', 'optim.hip', 'metrics.hip', 'conv_small.hip', 'conv1x1.hip', 'data.hip']
+LINK = []  # no library dependencies beyond the HIP runtime: every kernel of the path is in csrc/
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-ffp-contract=fast']
 
 

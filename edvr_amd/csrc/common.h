@@ -53,9 +53,6 @@ int wgrad_small_launch(const float *x, const float *dz, float *ws, int ci, int c
 bool conv1x1_eligible(const edvr_conv2d_desc &d);
 int conv1x1_launch(const edvr_conv2d_desc &d, hipStream_t stream);
 
-// blas.hip: row-major strided-batched fp32 GEMM on rocBLAS (plain GEMMs only: the DCNv2 backward's dcol and dW)
-int blas_gemm_rowmajor(const float *A, const float *B, float *C, int M, int N, int K, bool a_trans, bool b_trans, int64_t lda,
-                       int64_t ldb, int64_t ldc, int64_t stride_a, int64_t stride_b, int64_t stride_c, int batch, hipStream_t stream);
 // wgrad.hip: out[i] (+)= sum_k ws[k * total + i]
 int reduce_partials_launch(const float *ws, float *out, int64_t total, int parts, int accumulate, hipStream_t stream,
                            const float *ws2 = nullptr, float *out2 = nullptr, int total2 = 0, int parts2 = 0);  // second, small array in the same launch

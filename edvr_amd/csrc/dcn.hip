@@ -25,8 +25,9 @@
 //   * backward: one fused kernel produces dOffset, dMask, dX and rewrites the dY-columns buffer in place with the forward
 //     columns needed by dW (the reference runs three kernels and a 25-iteration window scan per column entry, .cu:677-691).
 //     dX is scattered either with device atomics or through a per-tile LDS window (scatter_hint), right-hand bilinear
-//     corners merged into the neighbouring lane by a DPP shift first.  The two plain GEMMs (dcol = W^T dY, dW = sum dY col^T,
-//     deterministic sum over the batch) run on rocBLAS (blas.hip); DCNv1 entry points at the end of the file reuse all of it.
+//     corners merged into the neighbouring lane by a DPP shift first.  dcol = W^T dY is a 1x1 convolution of dY (conv1x1.hip),
+//     dW = sum dY col^T the split-K MFMA GEMM below (deterministic sum over images and pixels); DCNv1 entry points at the end
+//     of the file reuse all of it.
 #include <cstdlib>
 
 #include "common.h"
@@ -517,9 +518,13 @@ __global__ __launch_bounds__(256) void dcn_bwd_coord_tile_kernel(const float *__
 }
 
 // ---------------------------------------------------------------------------------------------
-// C[M,N] (+)= sum_batches A_b[M,K] * B_b[N,K]^T, K contiguous (pixel axis).  fp32 MFMA 32x32x2,
-// 64x64 block tile (4 waves as 2x2), K staged through LDS in chunks of 32, deterministic split-K
-// into ws[split][M][N] followed by gemm_reduce_kernel.
+// C[M,N] (+)= sum_batches A_b[M,K] * B_b[N,K]^T, K contiguous in both (the pixel axis): dW = sum_{b,p} dY col^T of the backward
+// (deform_conv_cuda.cpp:664-672).  fp32 MFMA 32x32x2; a 256-thread workgroup owns a 128 x 128 tile of C (4 waves as 2 x 2, each
+// 64 x 64 = four accumulator tiles, so every LDS operand read feeds two MFMAs), K staged in chunks of 32 through a
+// double-buffered LDS pair with odd row strides (conflict-free for the float4 -> 4 x b32 staging writes and for the operand
+// reads), global loads of chunk c + 1 issued into registers before the 64 MFMAs of chunk c, one barrier per chunk.
+// Deterministic split-K over (image, pixel chunk) into ws[split][M][N], summed by reduce_partials_launch.
+// (Round 1 ran this product on rocBLAS; its own first instance had one accumulator tile per wave and a barrier pair per 16 MFMAs.)
 constexpr int GK = 32;
 struct GemmNT {
   const float *A, *B;
@@ -529,57 +534,96 @@ struct GemmNT {
   int chunks_per_batch, total_chunks, splits;
 };
 
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT g) {
-  __shared__ float as[64][GK + 1];
-  __shared__ float bs[64][GK + 1];
+template <bool VEC>  // VEC: every row start is 16-byte aligned and K % 4 == 0 (float4 loads), else scalar loads
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT g) {
+  constexpr int BM = 128, BN = 128, LDK = GK + 1;
+  __shared__ float as[2][BM * LDK];
+  __shared__ float bs[2][BN * LDK];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, j = lane & 31;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64, split = blockIdx.z;
-  const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, split = blockIdx.z;
+  const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
   const int c_begin = (int)((int64_t)g.total_chunks * split / g.splits);
   const int c_end = (int)((int64_t)g.total_chunks * (split + 1) / g.splits);
-  f32x16 acc;
+  f32x16 acc[2][2];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const int lk = tid & 31, lr = tid >> 5;
-  for (int c = c_begin; c < c_end; ++c) {
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  // staging role: 4 consecutive k of row (tid >> 3) + 32 i, i = 0..3, of both operands
+  const int k4 = (tid & 7) * 4, row0 = tid >> 3;
+  float ar[4][4], br[4][4];
+  auto load = [&](int c) {
     const int b = c / g.chunks_per_batch;
-    const int64_t k0 = (int64_t)(c - b * g.chunks_per_batch) * GK;
+    const int64_t k = (int64_t)(c - b * g.chunks_per_batch) * GK + k4;
     const float *Ab = g.A + (int64_t)b * g.a_bs, *Bb = g.B + (int64_t)b * g.b_bs;
-    __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int r = lr + it * 8;
-      const bool kok = (k0 + lk) < g.K;
-      as[r][lk] = (kok && (m0 + r) < g.M) ? Ab[(int64_t)(m0 + r) * g.lda + k0 + lk] : 0.f;
-      bs[r][lk] = (kok && (n0 + r) < g.N) ? Bb[(int64_t)(n0 + r) * g.ldb + k0 + lk] : 0.f;
+    for (int i = 0; i < 4; ++i) {
+      const int row = row0 + 32 * i;
+      const bool aok = m0 + row < g.M, bok = n0 + row < g.N;
+      const float *pa = Ab + (int64_t)(aok ? m0 + row : 0) * g.lda, *pb = Bb + (int64_t)(bok ? n0 + row : 0) * g.ldb;
+      if (VEC) {
+        const bool kok = k < g.K;  // K % 4 == 0: the four elements are valid together
+        const float4 va = *reinterpret_cast<const float4 *>(pa + (kok ? k : 0)), vb = *reinterpret_cast<const float4 *>(pb + (kok ? k : 0));
+        ar[i][0] = (aok && kok) ? va.x : 0.f; ar[i][1] = (aok && kok) ? va.y : 0.f; ar[i][2] = (aok && kok) ? va.z : 0.f; ar[i][3] = (aok && kok) ? va.w : 0.f;
+        br[i][0] = (bok && kok) ? vb.x : 0.f; br[i][1] = (bok && kok) ? vb.y : 0.f; br[i][2] = (bok && kok) ? vb.z : 0.f; br[i][3] = (bok && kok) ? vb.w : 0.f;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool kok = k + q < g.K;
+          const float va = pa[kok ? k + q : 0], vb = pb[kok ? k + q : 0];
+          ar[i][q] = (aok && kok) ? va : 0.f;
+          br[i][q] = (bok && kok) ? vb : 0.f;
+        }
+      }
     }
-    __syncthreads();
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        as[buf][(row0 + 32 * i) * LDK + k4 + q] = ar[i][q];
+        bs[buf][(row0 + 32 * i) * LDK + k4 + q] = br[i][q];
+      }
+  };
+  if (c_begin < c_end) {
+    load(c_begin);
+    commit(0);
+  }
+  __syncthreads();
+  for (int c = c_begin; c < c_end; ++c) {
+    const int buf = (c - c_begin) & 1;
+    const bool more = c + 1 < c_end;
+    if (more) load(c + 1);
+    const float *pa = as[buf] + (wm + j) * LDK + half, *pb = bs[buf] + (wn + j) * LDK + half;
 #pragma unroll
     for (int kk = 0; kk < GK; kk += 2) {
-      const float av = as[wm + j][kk + half];
-      const float bv = bs[wn + j][kk + half];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+      const float a0 = pa[kk], a1 = pa[32 * LDK + kk], b0 = pb[kk], b1 = pb[32 * LDK + kk];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
     }
+    if (more) commit(buf ^ 1);  // the idle buffer: last read one iteration ago, a barrier since
+    __syncthreads();
   }
   float *out = g.ws + (int64_t)split * g.M * g.N;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * half, n = n0 + wn + j;
-    if (m < g.M && n < g.N) out[(int64_t)m * g.N + n] = acc[r];
-  }
-}
-
-__global__ void gemm_reduce_kernel(const float *__restrict__ ws, float *__restrict__ C, int64_t mn, int splits, int accumulate) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < mn; i += (int64_t)gridDim.x * blockDim.x) {
-    float s = accumulate ? C[i] : 0.f;
-    for (int k = 0; k < splits; ++k) s += ws[(int64_t)k * mn + i];
-    C[i] = s;
-  }
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, n = n0 + wn + b * 32 + j;
+        if (m < g.M && n < g.N) out[(int64_t)m * g.N + n] = acc[a][b][r];
+      }
 }
 
 static int gemm_splits(int M, int N, int64_t total_chunks) {
-  const int tiles = cdiv(M, 64) * cdiv(N, 64);
-  int s = cdiv(1024, tiles);  // ~4 workgroups per CU
+  const int tiles = cdiv(M, 128) * cdiv(N, 128);
+  int s = cdiv(512, tiles);  // two workgroups per CU
   if (s > total_chunks) s = (int)total_chunks;
   if (s < 1) s = 1;
   if (s > 256) s = 256;
@@ -593,14 +637,13 @@ static int gemm_nt_batched(const float *A, const float *B, float *C, int M, int 
   g.chunks_per_batch = (int)cdiv64(K, GK);
   g.total_chunks = g.chunks_per_batch * nb;
   g.splits = gemm_splits(M, N, g.total_chunks);
-  dim3 grid(cdiv(N, 64), cdiv(M, 64), g.splits);
-  hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(256), 0, stream, g);
+  dim3 grid(cdiv(N, 128), cdiv(M, 128), g.splits);
+  const bool vec = ((K | lda | ldb | a_bs | b_bs) & 3) == 0 && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
+  if (vec) hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, dim3(256), 0, stream, g);
+  else hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, dim3(256), 0, stream, g);
   int rc = check_launch("gemm_nt_kernel");
   if (rc) return rc;
-  const int64_t mn = (int64_t)M * N;
-  hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(mn, 256), 2048)), dim3(256), 0, stream, ws, C,
-                     mn, g.splits, accumulate ? 1 : 0);
-  return check_launch("gemm_reduce_kernel");
+  return reduce_partials_launch(ws, C, (int64_t)M * N, g.splits, accumulate ? 1 : 0, stream);
 }
 
 static size_t gemm_nt_ws_elems_b(int M, int N, int64_t K, int nb) {
@@ -769,20 +812,11 @@ int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, c
   float *wpk = reinterpret_cast<float *>(static_cast<char *>(ws) + wsz.wpk);
   float *gws = reinterpret_cast<float *>(static_cast<char *>(ws) + wsz.gemm);
   const int cig = C / groups, cog = Co / groups;
-  // 1. dcol[b, g] (cig*K x P) = W[g]^T (cig*K x cog) dY[b, g] (cog x P): plain GEMM, rocBLAS (blas.hip)
-  static const bool use_blas = []() {
-    const char *e = getenv("EDVR_DCN_BLAS");  // "0": the library's own GEMM kernels (A/B)
-    return !(e && e[0] == '0');
-  }();
+  // 1. dcol[b, g] (cig*K x P) = W[g]^T (cig*K x cog) dY[b, g] (cog x P): a 1x1 convolution of dY with cog -> cig*K channels, on the
+  //    streaming-GEMM kernel of conv1x1.hip (B operand = dY straight from global memory, W slab in LDS)
   const size_t wpk_g = edvr_conv2d_packed_weight_elems(cig * K, cog, 1);
   for (int g = 0; g < groups; ++g) {
     const float *wg = weight + (size_t)g * cog * cig * K;
-    if (use_blas) {
-      rc = blas_gemm_rowmajor(wg, dy + (int64_t)g * cog * P, col + (int64_t)g * cig * K * P, cig * K, (int)P, cog, /*a_trans=*/true,
-                              false, cig * K, P, P, 0, (int64_t)Co * P, (int64_t)C * K * P, B, stream);
-      if (rc) return rc;
-      continue;
-    }
     const float *wuse = wg;
     if ((cog % 32) != 0 || ((cig * K) % 32) != 0) {  // W (cog x cig*K, row-major) is already the packed layout when aligned
       rc = edvr_conv2d_pack_weight_f32(wg, wpk + g * wpk_g, cig * K, cog, 1, 1, stream_);
@@ -832,15 +866,6 @@ int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, c
   if (rc) return rc;
   // 3. dW[g] = sum_{b,p} dY[b, g] col[b, g]^T ; db = sum dY
   for (int g = 0; g < groups; ++g) {
-    if (use_blas) {  // per-image partials dY[b, g] col[b, g]^T (batched GEMM), then a deterministic sum over the batch
-      const int64_t wsz_g = (int64_t)cog * cig * K;
-      rc = blas_gemm_rowmajor(dy + (int64_t)g * cog * P, col + (int64_t)g * cig * K * P, gws, cog, cig * K, (int)P, false,
-                              /*b_trans=*/true, P, P, cig * K, (int64_t)Co * P, (int64_t)C * K * P, wsz_g, B, stream);
-      if (rc) return rc;
-      rc = reduce_partials_launch(gws, dweight + (size_t)g * wsz_g, wsz_g, B, 0, stream);
-      if (rc) return rc;
-      continue;
-    }
     rc = gemm_nt_batched(dy + (int64_t)g * cog * P, col + (int64_t)g * cig * K * P, dweight + (size_t)g * cog * cig * K, cog, cig * K, P,
                          P, P, B, (int64_t)Co * P, (int64_t)C * K * P, false, gws, stream);
     if (rc) return rc;

@@ -63,6 +63,13 @@ def wrap_ddp(net, find_unused_parameters=False, bucket_cap_mb=25):
                                    bucket_cap_mb=bucket_cap_mb)
 
 
+def rewrap_ddp(model, find_unused_parameters=False, bucket_cap_mb=25):
+    """A fresh DDP wrapper around the same network (e.g. without find_unused_parameters once the TSA warm-up is over - see
+    optim.tsa_freeze_schedule for why the flag cannot be flipped on a live wrapper).  No-op for an unwrapped net."""
+    bare = model.module if hasattr(model, 'module') else model
+    return wrap_ddp(bare, find_unused_parameters=find_unused_parameters, bucket_cap_mb=bucket_cap_mb)
+
+
 def reduce_scalar(value, device, op='mean'):
     """All-reduce a python scalar (loss logging, base_model.py:306-331) without a per-iteration .item() chain."""
     rank, world = get_dist_info()

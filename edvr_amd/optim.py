@@ -179,8 +179,16 @@ class CosineAnnealingRestartLR(_LRScheduler):
 
 def tsa_freeze_schedule(net, current_iter, tsa_iter):
     """EDVRModel.optimize_parameters (edvr_model.py:55-69): at iteration 1 freeze everything whose name does not contain
-    'fusion' (only the TSA module trains), at iteration `tsa_iter` unfreeze everything.  Returns True when the set of
-    trainable parameters changed (a DDP wrapper must then drop `find_unused_parameters`, as the reference does)."""
+    'fusion' (only the TSA module trains), at iteration `tsa_iter` unfreeze everything.  Returns True when the set of trainable
+    parameters changed.
+
+    DDP: wrap the net BEFORE iteration 1 (all parameters trainable, as base_model.py:63-69 does at construction) with
+    find_unused_parameters=True; the frozen ones are then "unused" and skipped by the reducer.  At `tsa_iter` the reference
+    sets `net_g.find_unused_parameters = False` on the live wrapper (edvr_model.py:66-68).  That relied on the reducer of its
+    PyTorch generation returning early for an empty output list; in PyTorch 2.x the C++ reducer keeps the constructor's flag,
+    receives no outputs to search, declares EVERY parameter unused and raises "Expected to mark a variable ready only once" at
+    the first gradient hook (reproduced with two nn.Linear layers over gloo).  So the wrapper is left untouched here: keep it
+    (costs one autograd-graph walk per iteration) or re-wrap with `edvr_amd.dist.rewrap_ddp(model)` when this returns True."""
     if not tsa_iter:
         return False
     bare = net.module if hasattr(net, 'module') else net
@@ -192,8 +200,6 @@ def tsa_freeze_schedule(net, current_iter, tsa_iter):
     if current_iter == tsa_iter:
         for p in bare.parameters():
             p.requires_grad = True
-        if hasattr(net, 'find_unused_parameters'):
-            net.find_unused_parameters = False
         return True
     return False
 

@@ -62,6 +62,8 @@ def train(args, log=print):
         it += 1
         if tsa_freeze_schedule(model, it, args.tsa_iter):
             log(f'iter {it}: trainable parameter set changed (TSA schedule)')
+            if it == args.tsa_iter and world > 1:
+                model = D.rewrap_ddp(model, find_unused_parameters=False)  # all parameters train from here on
         opt.zero_grad(set_to_none=True)
         out = model(batch['lq'])
         loss = charbonnier_loss(out, batch['gt'])  # CharbonnierLoss, loss_weight 1.0, reduction: sum (options/train/EDVR/*.yml pixel_opt)

@@ -47,15 +47,16 @@ def _worker(rank, world, port, q):
     dist.init_process_group(backend='gloo')  # CUDA tensors over gloo: both ranks live on cuda:0
     dev = torch.device('cuda:0')
     net = _build().to(dev)
-    tsa_freeze_schedule(net, 1, tsa_iter=3)  # iteration 1: only `fusion.*` trains (edvr_model.py:57-62)
-    ddp = D.wrap_ddp(net, find_unused_parameters=True)
+    ddp = D.wrap_ddp(net, find_unused_parameters=True)  # wrapped with every parameter trainable, as base_model.py:63-69
     assert type(ddp).__name__ == 'DistributedDataParallel'
+    tsa_freeze_schedule(ddp, 1, tsa_iter=3)  # iteration 1: only `fusion.*` trains (edvr_model.py:57-62)
     x, gt = _data(rank)
     x, gt = x.to(dev), gt.to(dev)
     out = {}
     for it, phase in ((1, 'tsa_only'), (3, 'all')):
         if it == 3:
-            assert tsa_freeze_schedule(ddp, 3, tsa_iter=3) and ddp.find_unused_parameters is False
+            assert tsa_freeze_schedule(ddp, 3, tsa_iter=3)
+            ddp = D.rewrap_ddp(ddp, find_unused_parameters=False)  # (the reference flips the flag in place: breaks on PyTorch 2.x)
         ddp.zero_grad(set_to_none=True)
         charbonnier_loss(ddp(x), gt).backward()
         out[phase] = {k: (None if v is None else v.numpy()) for k, v in _grads(net).items()}
@@ -71,7 +72,17 @@ def test_ddp_two_ranks_one_gpu_tsa_warmup(gpu):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=600) for _ in range(world))
+    import queue as _queue
+    import time
+    got, deadline = {}, time.time() + 420
+    while len(got) < world:
+        assert time.time() < deadline, 'DDP workers did not report in time'  # fail fast if a worker died (a blocking get would sit out its whole timeout on the GPU box)
+        try:
+            rank, out = q.get(timeout=5)
+            got[rank] = out
+        except _queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            assert not dead, f'DDP worker exited with {dead}'
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
