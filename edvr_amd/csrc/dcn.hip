@@ -623,7 +623,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT g) {
 
 static int gemm_splits(int M, int N, int64_t total_chunks) {
   const int tiles = cdiv(M, 128) * cdiv(N, 128);
-  int s = cdiv(512, tiles);  // two workgroups per CU
+  int s = 512 / tiles;  // two workgroups per CU, ONE round: rounding up (57 x 9 = 513 workgroups) left one workgroup for a second round
   if (s > total_chunks) s = (int)total_chunks;
   if (s < 1) s = 1;
   if (s > 256) s = 256;

@@ -8,6 +8,9 @@ from edvr_amd.autograd import charbonnier_loss
 from oracle import dcn_oracle as O, edvr_oracle as EO
 
 name = sys.argv[1] if len(sys.argv) > 1 else 'M_T5'
+if len(sys.argv) > 2:
+    from edvr_amd import ops
+    ops.CONV_ALGO = {'direct': ops.CONV_DIRECT, 'winograd': ops.CONV_WINOGRAD, 'auto': ops.CONV_AUTO}[sys.argv[2]]
 net, x, kwargs = build(name)
 net.train()
 def oracle_grads(dt):
@@ -26,7 +29,12 @@ rows = []
 for k, p in net.named_parameters():
     if g64[k].abs().max() == 0: continue
     rows.append((rel(p.grad, g64[k]), rel(g32[k], g64[k]), k))
+order = [k for k, _ in net.named_parameters()]
+print('--- in network order (every 6th tensor)')
+for o, f, k in sorted(rows, key=lambda r: order.index(r[2]))[::6]:
+    print(f'{o:.2e}  floor {f:.2e}  {k}')
 rows.sort(reverse=True)
+print('--- worst')
 for o, f, k in rows[:12]:
     print(f'{o:.2e}  floor {f:.2e}  ratio {o / max(f, 1e-12):5.1f}  {k}')
 import statistics

@@ -32,7 +32,7 @@ def test_pool_maxavg(gpu, hw):
     assert _rel(ops.pool_maxavg(x.to(gpu)), ref) < TOL
 
 
-@pytest.mark.parametrize('hw', [(8, 8), (45, 80), (5, 3)])
+@pytest.mark.parametrize('hw', [(8, 8), (45, 80), (5, 3), (6, 2), (1, 4), (3, 130)])
 def test_upsample2x_and_4x_add(gpu, hw):
     from edvr_amd import ops
     g = torch.Generator().manual_seed(3)
@@ -52,6 +52,10 @@ def test_combine_add_abs_sum_act_bwd(gpu):
     assert _rel(ops.add(a.to(gpu), b.to(gpu)), a.double() + b.double()) < TOL
     big = torch.randn(3, 12, 6, 10, generator=g)
     assert _rel(ops.abs_sum_per_image(big.to(gpu)[:, :8]), big[:, :8].double().abs().sum((1, 2, 3))) < 1e-5
+    odd = torch.randn(2, 3, 7, 9, generator=g)  # element count not a multiple of 4: scalar path
+    assert _rel(ops.abs_sum_per_image(odd.to(gpu)), odd.double().abs().sum((1, 2, 3))) < 1e-5
+    wide = torch.randn(2, 144, 45, 80, generator=g)  # many blocks per image, 16-byte loads
+    assert _rel(ops.abs_sum_per_image(wide.to(gpu)), wide.double().abs().sum((1, 2, 3))) < 1e-5
     y = F.leaky_relu(a, 0.1)
     assert _rel(ops.act_backward(b.to(gpu), y.to(gpu), ops.ACT_LRELU), torch.where(a > 0, b, 0.1 * b).double()) < TOL
     s = torch.sigmoid(a)
