@@ -48,16 +48,24 @@ __device__ __noinline__ float dcn_sample_global(const float *plane, float h, flo
 
 template <int MT, int R>
 __global__ __launch_bounds__(256, 2) void dcn_fused_fwd_kernel(const DcnFusedArgs a) {
-  constexpr int TH = 4, TW = 32, KK = 9, CK = 8;
+  constexpr int TH = 4, TW = 32, KK = 9, CK = 8, WCK = 4;  // x tile: chunks of 8 input channels; weight slab: sub-chunks of 4
   constexpr int IH = TH + 2 + 2 * R, IW = TW + 2 + 2 * R;  // R = 3: 12 x 40 halo tile; R = 7: 20 x 48
   constexpr int RS = IW, CHS = IH * RS;
-  constexpr int MB = 32 * MT, WROWS = CK * KK;
-  constexpr int XS_ELEMS = (CK * CHS + 3) / 4 * 4;
-  __shared__ __attribute__((aligned(16))) float smem[XS_ELEMS + WROWS * MB];
-  float *xs = smem;
-  float *wsm = smem + XS_ELEMS;
+  constexpr int MB = 32 * MT, WROWS = WCK * KK;            // 36 weight rows (channel, tap) of MB floats per sub-chunk
+  constexpr int XS_ELEMS = (CK * CHS + 3) / 4 * 4, WS_ELEMS = WROWS * MB;
+  // LDS: the x halo tile and the weight slab are BOTH double-buffered (R = 3, MT = 4: 2 x 15 KB + 2 x 18 KB = 66 KB, two
+  // workgroups per CU).  Round 1 staged the 36 KB weight slab of a chunk through 36 registers per thread (global -> register
+  // -> LDS between two barriers): at 256 VGPRs the compiler spilled exactly those registers, i.e. the "prefetch" waited for
+  // its loads and went through scratch.  Weights now travel global -> LDS directly (global_load_lds_dwordx4: no registers, no
+  // ds_write pass), one 4-channel sub-chunk ahead of the MFMAs that read it.
+  // (the R = 7 halo with >= 96 output channels would need 89-98 KB that way: there the x tile keeps ONE buffer and is committed
+  //  at the chunk boundary between two barriers, as in round 1)
+  constexpr bool XDB = (2 * XS_ELEMS + 2 * WS_ELEMS) * 4 <= 80 * 1024;
+  __shared__ __attribute__((aligned(16))) float smem[(XDB ? 2 : 1) * XS_ELEMS + 2 * WS_ELEMS];
+  float *xs0 = smem, *ws0 = smem + (XDB ? 2 : 1) * XS_ELEMS;
 
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, j = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, j = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int tile, blk_y, img;
   xcd_block_index(tile, blk_y, img);  // neighbouring tiles share one XCD's L2 (common.h)
   const int ty0 = (tile / a.tiles_x) * TH, tx0 = (tile % a.tiles_x) * TW;
@@ -79,10 +87,8 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_fwd_kernel(const DcnFusedArg
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
-  // ---- staging pipeline state (see conv2d.hip)
+  // ---- x tile: register prefetch (all loads unconditional: clamped address + select), committed to the idle buffer mid-chunk
   constexpr int NXK = (CHS + 255) / 256;
-  constexpr int V4_PER_ROW = MB / 4, ROWS_PER_PASS = 256 / V4_PER_ROW;
-  constexpr int NW = (WROWS + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
   int xoff[NXK];
 #pragma unroll
   for (int k = 0; k < NXK; ++k) {
@@ -91,18 +97,8 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_fwd_kernel(const DcnFusedArg
     const int gy = hy0 + iy, gx = wx0 + ix;
     xoff[k] = (q < CHS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? gy * a.W + gx : -1;
   }
-  const int wrow0 = tid / V4_PER_ROW, wc4 = tid - wrow0 * V4_PER_ROW;
-  const bool w_active = wrow0 < ROWS_PER_PASS;
-  const int woff0 = w_active ? wrow0 * a.cop + wc4 * 4 : 0;
   float xr[CK * NXK];
-  f32x4 wr[NW];
-  auto prefetch = [&](int c0) {
-    const float *wsrc = a.wpk + (int64_t)c0 * KK * a.cop + co_blk + woff0;
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-      const bool ok = (i + 1) * ROWS_PER_PASS <= WROWS || wrow0 + i * ROWS_PER_PASS < WROWS;
-      wr[i] = *reinterpret_cast<const f32x4 *>(wsrc + (ok ? i * ROWS_PER_PASS * a.cop : 0));
-    }
+  auto prefetch_x = [&](int c0) {
 #pragma unroll
     for (int ch = 0; ch < CK; ++ch) {
       const float *src = x + (int64_t)(c0 + ch) * P;
@@ -114,23 +110,34 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_fwd_kernel(const DcnFusedArg
       }
     }
   };
-  auto commit = [&]() {
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-      const int row = wrow0 + i * ROWS_PER_PASS;
-      if (w_active && ((i + 1) * ROWS_PER_PASS <= WROWS || row < WROWS)) *reinterpret_cast<f32x4 *>(wsm + row * MB + wc4 * 4) = wr[i];
-    }
+  auto commit_x = [&](float *xs) {
 #pragma unroll
     for (int ch = 0; ch < CK; ++ch)
 #pragma unroll
       for (int k = 0; k < NXK; ++k)
         if ((k + 1) * 256 <= CHS || tid + k * 256 < CHS) xs[ch * CHS + tid + k * 256] = xr[ch * NXK + k];
   };
+  // ---- weight sub-chunk (channels cb .. cb + 3, all taps) -> LDS buffer `dst`, asynchronously.  One wave instruction moves
+  //      64 x 16 B to a CONTIGUOUS 1 KB of LDS (wave-uniform base + lane x 16); the slab is dense row-major [row][MB], so lane q
+  //      of instruction i carries float4 number i * 64 + q of the slab: row (i * 64 + q) / (MB / 4) of the packed weights.
+  auto dma_w = [&](float *dst, int cb) {
+    constexpr int Q = MB / 4, TOTAL = WROWS * Q;
+    const float *src = a.wpk + (int64_t)cb * KK * a.cop + co_blk;
+    for (int i = wave; i * 64 < TOTAL; i += 4) {
+      const int q = i * 64 + lane;
+      if (q < TOTAL) {
+        const int row = q / Q, c4 = q - row * Q;
+        typedef __attribute__((address_space(1))) void gvoid;
+        typedef __attribute__((address_space(3))) void lvoid;
+        __builtin_amdgcn_global_load_lds((gvoid *)(src + (int64_t)row * a.cop + c4 * 4), (lvoid *)(dst + i * 256), 16, 0, 0);
+      }
+    }
+  };
 
   // ---- per-(pixel, group, tap) sampling state, refreshed when the chunk enters a new deformable group
   float w00[KK], w01[KK], w10[KK], w11[KK];
-  float hs[KK], wsx[KK];  // sampling position (slow path only)
-  int taddr[KK];
+  int taddr[KK];  // (the slow path re-reads its offsets from global memory: 18 registers of sampling positions kept for a rare
+                  //  branch were spilling state of the hot loop)
   unsigned slow = 0;  // bit t: the 2x2 cell of tap t is not fully inside the staged halo
   auto load_taps = [&](int g) {
 #pragma unroll
@@ -143,8 +150,6 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_fwd_kernel(const DcnFusedArg
       const float fh = floorf(h), fw = floorf(w);
       const float lh = h - fh, lw = w - fw;
       const float mm = valid ? m : 0.f;
-      hs[t] = h;
-      wsx[t] = w;
       w00[t] = (1.f - lh) * (1.f - lw) * mm;
       w01[t] = (1.f - lh) * lw * mm;
       w10[t] = lh * (1.f - lw) * mm;
@@ -156,39 +161,89 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_fwd_kernel(const DcnFusedArg
     }
   };
 
+  // ---- two channel pairs (one weight sub-chunk) of MFMAs.  One tap = 4 LDS gathers + MT weight reads -> 5 VALU -> MT MFMAs.
+  //      A wave issues in order and an MFMA only issues once the matrix pipe accepts it (every 64 cycles), so reads placed
+  //      AFTER the MT MFMAs of the previous tap leave the wave at T + 64 (MT - 1) at the earliest and their LDS latency sits
+  //      behind the last MFMA (round 1: matrix pipe 48 % busy).  Here the operands of tap t + 1 are requested BEFORE the MFMAs
+  //      of tap t (two static register sets, schedule pinned): they return while those MFMAs drain.
   const int abase = half * KK * MB + j;
-  prefetch(0);
-  commit();
-  load_taps(0);
-  __syncthreads();
-  for (int c0 = 0; c0 < a.C; c0 += CK) {
-    const bool more = (c0 + CK) < a.C;
-    if (more) prefetch(c0 + CK);
-#pragma unroll 1
-    for (int cp = 0; cp < CK / 2; ++cp) {
+  auto run_half = [&](const float *xs, const float *wsb, int c0, int cp0) {
+    float cv[2][4], av[2][MT];
+    auto issue = [&](int q, int t, float (&c)[4], float (&aw)[MT]) {  // q = channel pair inside this half (0 / 1)
+      const float *cell = xs + taddr[t] + 2 * (cp0 + q) * CHS;
+      c[0] = cell[0];
+      c[1] = cell[1];
+      c[2] = cell[RS];
+      c[3] = cell[RS + 1];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) aw[m] = wsb[abase + (2 * q * KK + t) * MB + m * 32];
+    };
+    issue(0, 0, cv[0], av[0]);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
 #pragma unroll
       for (int t = 0; t < KK; ++t) {
-        float av[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) av[m] = wsm[abase + (2 * cp * KK + t) * MB + m * 32];
-        const float *cell = xs + taddr[t] + 2 * cp * CHS;
-        float bv = w00[t] * cell[0] + w01[t] * cell[1] + w10[t] * cell[RS] + w11[t] * cell[RS + 1];
+        const int cur = (q * KK + t) & 1, nxt = cur ^ 1;
+#ifdef DCNF_EXP_NOPIPE  /* ablation: operands requested right before their use */
+        if (!(q == 0 && t == 0)) issue(q, t, cv[cur], av[cur]);
+#else
+        if (t + 1 < KK) issue(q, t + 1, cv[nxt], av[nxt]);
+        else if (q == 0) issue(1, 0, cv[nxt], av[nxt]);
+#endif
+#ifdef DCNF_EXP_PIN  /* pinning the slice order measured 6 % slower (4.50 vs 4.25 ms on the EDVR-L L1 layer): left to the scheduler */
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        float bv = w00[t] * cv[cur][0] + w01[t] * cv[cur][1] + w10[t] * cv[cur][2] + w11[t] * cv[cur][3];
         if (__any(slow >> t & 1u)) {  // wave-uniform: some lane's cell left the halo -> gather from global
           if (slow >> t & 1u) {
-            const float m = msk_b[(int64_t)((c0 / cpg) * 9 + t) * P + p];
-            bv = dcn_sample_global(x + (int64_t)(c0 + 2 * cp + half) * P, hs[t], wsx[t], m, a.H, a.W);
+            const int g = c0 / cpg;
+            const float m = msk_b[(int64_t)(g * 9 + t) * P + p];
+            const float hsp = (float)(oy - 1 + t / 3) + off_b[(int64_t)(g * 18 + 2 * t) * P + p];
+            const float wsp = (float)(ox - 1 + t % 3) + off_b[(int64_t)(g * 18 + 2 * t + 1) * P + p];
+            bv = dcn_sample_global(x + (int64_t)(c0 + 2 * (cp0 + q) + half) * P, hsp, wsp, m, a.H, a.W);
           }
         }
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv, acc[m], 0, 0, 0);
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][m], bv, acc[m], 0, 0, 0);
+#ifdef DCNF_EXP_PIN  /* pinning the slice order measured 6 % slower (4.50 vs 4.25 ms on the EDVR-L L1 layer): left to the scheduler */
+        __builtin_amdgcn_sched_barrier(0);
+#endif
       }
     }
-    if (more) {
-      __syncthreads();
-      commit();
-      if ((c0 + CK) % cpg == 0) load_taps((c0 + CK) / cpg);
+  };
+  // every wave waits for ITS OWN outstanding loads (the LDS-DMA pieces it issued, its x registers) before the barrier: past
+  // the barrier everything that was in flight has landed
+  auto settle = [&]() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+
+  // ---- schedule (chunk = 8 channels = weight sub-chunks A, B of 4):
+  //   boundary : [settle]  A(c), x(c) valid; nobody reads B any more   -> DMA B(c); x(c+8) -> registers;  MFMAs on A(c)
+  //   middle   : [settle]  B(c) valid; nobody reads A any more         -> DMA A(c+8); x registers -> idle x buffer;  MFMAs on B(c)
+  dma_w(ws0, 0);
+  prefetch_x(0);
+  commit_x(xs0);
+  load_taps(0);
+  for (int c0 = 0; c0 < a.C; c0 += CK) {
+    const bool more = (c0 + CK) < a.C;
+    const int xb = XDB ? (c0 / CK) & 1 : 0;
+    const float *xs = xs0 + xb * XS_ELEMS;
+    settle();
+    if (!XDB && c0 > 0) {  // single x buffer: the registers loaded during the previous chunk land now
+      commit_x(xs0);
       __syncthreads();
     }
+    dma_w(ws0 + WS_ELEMS, c0 + WCK);
+    if (more) prefetch_x(c0 + CK);
+    run_half(xs, ws0, c0, 0);
+    settle();
+    if (more) {
+      dma_w(ws0, c0 + CK);
+      if (XDB) commit_x(xs0 + (xb ^ 1) * XS_ELEMS);
+    }
+    run_half(xs, ws0 + WS_ELEMS, c0, 2);
+    if (more && (c0 + CK) % cpg == 0) load_taps((c0 + CK) / cpg);
   }
 
   // ---- epilogue: bias, activation, store

@@ -24,14 +24,46 @@ import torch.nn.functional as F
 from . import dcn_oracle
 
 
+# ---- test aid: "follow" another run of the same network at its DISCRETE decisions (see _follow below).  ReLU / LeakyReLU pick a
+# side per element; the derivative jumps at 0, and a pre-activation smaller than the forward rounding error lands on different
+# sides in an fp32 run and in this oracle (root cause of round 1's intermittent test failure, profiles/r2/flake_rootcause_*.log).
+# One flip right below `aligned` moves every PCD gradient by ~1e-3.  With _ACT_SIDES = {layer name: bool tensor "the other run
+# took the positive side"} every activation of this oracle takes the other run's side and keeps its own derivative there.
+_ACT_SIDES = None
+_FRAME = None  # (frame index, frames per clip) while the per-frame PCD loop runs: the other run batches all frames of a clip
+
+
+def _tag(y, name):
+    y._edvr_name = name  # which layer produced this tensor (read by the activation that follows)
+    return y
+
+
+def _side(z, name):
+    name = name or getattr(z, '_edvr_name', None)
+    if _ACT_SIDES is None or name is None or name not in _ACT_SIDES:
+        return None
+    s = _ACT_SIDES[name]
+    if s.shape[0] != z.shape[0]:  # (b * t, ...) in the other run, frame i of every clip here
+        i, t = _FRAME
+        s = s.reshape(z.shape[0], t, *s.shape[1:])[:, i]
+    assert s.shape == z.shape, (name, tuple(s.shape), tuple(z.shape))
+    return s
+
+
 def _conv(sd, name, x, stride=1, padding=None):
     w = sd[name + '.weight']
     pad = (w.shape[-1] // 2) if padding is None else padding
-    return F.conv2d(x, w, sd.get(name + '.bias'), stride, pad)
+    return _tag(F.conv2d(x, w, sd.get(name + '.bias'), stride, pad), name)
 
 
-def _lrelu(x):
-    return F.leaky_relu(x, 0.1)
+def _lrelu(x, name=None):
+    side = _side(x, name)
+    return F.leaky_relu(x, 0.1) if side is None else torch.where(side, x, 0.1 * x)
+
+
+def _relu(x, name=None):
+    side = _side(x, name)
+    return F.relu(x) if side is None else torch.where(side, x, torch.zeros_like(x))
 
 
 def _up2(x):
@@ -39,20 +71,24 @@ def _up2(x):
 
 
 def resblock(sd, name, x):
-    return x + _conv(sd, name + '.conv2', F.relu(_conv(sd, name + '.conv1', x)))
+    return x + _conv(sd, name + '.conv2', _relu(_conv(sd, name + '.conv1', x)))
 
 
-def dcn_pack(sd, name, x, feat, dg, dcn, stats=None):
+def dcn_pack(sd, name, x, feat, dg, dcn, stats=None, forced_offset=None):
+    """forced_offset (test aid, see _follow): the offsets ANOTHER run of the network fed to this DCN.  d/d(offset) is the
+    one-sided derivative inside the cell floor() selects; where a sampling position sits within rounding error of an integer,
+    an fp32 run and this oracle select different cells and the gradient jumps."""
     out = _conv(sd, name + '.conv_offset', feat)
     k3 = out.shape[1] // 3
-    offset, mask = out[:, :2 * k3], torch.sigmoid(out[:, 2 * k3:])
+    offset, mask = _follow(out[:, :2 * k3], forced_offset), torch.sigmoid(out[:, 2 * k3:])
     if stats is not None:
         stats.append(offset.abs().mean().item())
-    return dcn(x, offset.contiguous(), mask.contiguous(), sd[name + '.weight'], sd.get(name + '.bias'), 1, 1, 1, 1, dg)
+    return _tag(dcn(x, offset.contiguous(), mask.contiguous(), sd[name + '.weight'], sd.get(name + '.bias'), 1, 1, 1, 1, dg), name)
 
 
-def pcd_align(sd, pre, nbr, ref, dg, dcn, stats=None):
-    """nbr/ref: [L1, L2, L3] feature lists, each (n, C, h, w)."""
+def pcd_align(sd, pre, nbr, ref, dg, dcn, stats=None, forced_offsets=None):
+    """nbr/ref: [L1, L2, L3] feature lists, each (n, C, h, w).  forced_offsets: {'l3' | 'l2' | 'l1' | 'cas': offsets} or None."""
+    fo = forced_offsets or {}
     up_off = up_feat = feat = None
     for lv in (3, 2, 1):
         L = f'l{lv}'
@@ -62,7 +98,7 @@ def pcd_align(sd, pre, nbr, ref, dg, dcn, stats=None):
         else:
             off = _lrelu(_conv(sd, f'{pre}offset_conv2.{L}', torch.cat([off, up_off], 1)))
             off = _lrelu(_conv(sd, f'{pre}offset_conv3.{L}', off))
-        feat = dcn_pack(sd, f'{pre}dcn_pack.{L}', nbr[lv - 1], off, dg, dcn, stats)
+        feat = dcn_pack(sd, f'{pre}dcn_pack.{L}', nbr[lv - 1], off, dg, dcn, stats, fo.get(L))
         if lv < 3:
             feat = _conv(sd, f'{pre}feat_conv.{L}', torch.cat([feat, up_feat], 1))
         if lv > 1:
@@ -71,10 +107,22 @@ def pcd_align(sd, pre, nbr, ref, dg, dcn, stats=None):
             up_feat = _up2(feat)
     off = torch.cat([feat, ref[0]], 1)
     off = _lrelu(_conv(sd, f'{pre}cas_offset_conv2', _lrelu(_conv(sd, f'{pre}cas_offset_conv1', off))))
-    return _lrelu(dcn_pack(sd, f'{pre}cas_dcnpack', feat, off, dg, dcn, stats))
+    return _lrelu(dcn_pack(sd, f'{pre}cas_dcnpack', feat, off, dg, dcn, stats, fo.get('cas')))
 
 
-def tsa_fusion(sd, pre, aligned, center, taps=None):
+def _follow(x, forced):
+    """Value of `forced` (another run's tensor at this point), gradient of `x`: the discrete decisions taken downstream (which
+    element a max-pool window routes its gradient to, which cell a deformable tap's floor() selects) then follow the other
+    run, the derivative stays this run's."""
+    return x if forced is None else x + (forced.to(x) - x).detach()
+
+
+def tsa_fusion(sd, pre, aligned, center, taps=None, pool_inputs=None):
+    """pool_inputs (test aid): the two max-pool inputs of ANOTHER forward run of the same network.  MaxPool2d's gradient is
+    discontinuous where two window elements tie; an fp32 run and this oracle can pick different elements when they differ by
+    less than the forward rounding error, and one such flip at the 1/2- or 1/4-resolution attention maps moves every gradient
+    upstream of the fusion module by ~1e-3 (profiles/r2/grad_bisect_L_T7_direct_vs_winograd.log).  With the other run's values
+    substituted (straight-through: its values, this run's derivative) both take the same routing decisions."""
     b, t, c, h, w = aligned.shape
     emb_ref = _conv(sd, pre + 'temporal_attn1', aligned[:, center])
     emb = _conv(sd, pre + 'temporal_attn2', aligned.reshape(-1, c, h, w)).view(b, t, -1, h, w)
@@ -83,10 +131,10 @@ def tsa_fusion(sd, pre, aligned, center, taps=None):
     if taps is not None:
         taps['tsa_modulated'] = al
     feat = _lrelu(_conv(sd, pre + 'feat_fusion', al))
-    attn = _lrelu(_conv(sd, pre + 'spatial_attn1', al))
+    attn = _follow(_lrelu(_conv(sd, pre + 'spatial_attn1', al)), pool_inputs[0] if pool_inputs else None)
     pooled = torch.cat([F.max_pool2d(attn, 3, 2, 1), F.avg_pool2d(attn, 3, 2, 1)], 1)
     attn = _lrelu(_conv(sd, pre + 'spatial_attn2', pooled))
-    lvl = _lrelu(_conv(sd, pre + 'spatial_attn_l1', attn))
+    lvl = _follow(_lrelu(_conv(sd, pre + 'spatial_attn_l1', attn)), pool_inputs[1] if pool_inputs else None)
     pooled = torch.cat([F.max_pool2d(lvl, 3, 2, 1), F.avg_pool2d(lvl, 3, 2, 1)], 1)
     lvl = _lrelu(_conv(sd, pre + 'spatial_attn_l2', pooled))
     lvl = _up2(_lrelu(_conv(sd, pre + 'spatial_attn_l3', lvl)))
@@ -121,8 +169,19 @@ def _count(sd, prefix):
 
 
 def edvr_forward(sd, x, center=None, hr_in=False, with_predeblur=False, with_tsa=True, dg=8, dcn=None, taps=None,
-                 stats=None):
-    """x: (b, t, 3, h, w) -> (b, 3, 4h, 4w)  [or (b, 3, h, w) when hr_in]."""
+                 stats=None, pool_inputs=None, dcn_offsets=None, act_sides=None):
+    """x: (b, t, 3, h, w) -> (b, 3, 4h, 4w)  [or (b, 3, h, w) when hr_in].
+    pool_inputs / dcn_offsets / act_sides: test aids, the discrete decisions of another run (see _follow, _ACT_SIDES)."""
+    global _ACT_SIDES, _FRAME
+    _ACT_SIDES = act_sides
+    try:
+        return _edvr_forward(sd, x, center, hr_in, with_predeblur, with_tsa, dg, dcn, taps, stats, pool_inputs, dcn_offsets)
+    finally:
+        _ACT_SIDES, _FRAME = None, None
+
+
+def _edvr_forward(sd, x, center, hr_in, with_predeblur, with_tsa, dg, dcn, taps, stats, pool_inputs, dcn_offsets):
+    global _FRAME
     dcn = dcn or dcn_oracle.dcnv2_c
     b, t, c, h, w = x.shape
     center = t // 2 if center is None else center
@@ -141,12 +200,20 @@ def edvr_forward(sd, x, center=None, hr_in=False, with_predeblur=False, with_tsa
     f2 = f2.view(b, t, -1, h // 2, w // 2)
     f3 = f3.view(b, t, -1, h // 4, w // 4)
     ref = [f1[:, center], f2[:, center], f3[:, center]]
-    aligned = torch.stack(
-        [pcd_align(sd, 'pcd_align.', [f1[:, i], f2[:, i], f3[:, i]], ref, dg, dcn, stats) for i in range(t)], 1)
+    # dcn_offsets (test aid): {'l3' | 'l2' | 'l1' | 'cas': (b * t, 2 * dg * 9, h_l, w_l)} offsets of another run, frames batched
+    # as image b_idx * t + t_idx (the layout edvr_amd's one-pass PCD alignment uses)
+    def frame_offsets(i):
+        return None if dcn_offsets is None else {k: v.reshape(b, t, *v.shape[1:])[:, i] for k, v in dcn_offsets.items()}
+    frames = []
+    for i in range(t):
+        _FRAME = (i, t)
+        frames.append(pcd_align(sd, 'pcd_align.', [f1[:, i], f2[:, i], f3[:, i]], ref, dg, dcn, stats, frame_offsets(i)))
+    _FRAME = None
+    aligned = torch.stack(frames, 1)
     if taps is not None:
         taps['aligned'] = aligned
     if with_tsa:
-        feat = tsa_fusion(sd, 'fusion.', aligned, center, taps)
+        feat = tsa_fusion(sd, 'fusion.', aligned, center, taps, pool_inputs)
     else:
         feat = _conv(sd, 'fusion', aligned.reshape(b, -1, h, w))
     if taps is not None:
@@ -156,8 +223,8 @@ def edvr_forward(sd, x, center=None, hr_in=False, with_predeblur=False, with_tsa
         out = resblock(sd, f'reconstruction.{i}', out)
     if taps is not None:
         taps['trunk'] = out
-    out = _lrelu(F.pixel_shuffle(_conv(sd, 'upconv1', out), 2))
-    out = _lrelu(F.pixel_shuffle(_conv(sd, 'upconv2', out), 2))
+    out = _lrelu(F.pixel_shuffle(_conv(sd, 'upconv1', out), 2), 'upconv1')
+    out = _lrelu(F.pixel_shuffle(_conv(sd, 'upconv2', out), 2), 'upconv2')
     out = _conv(sd, 'conv_last', _lrelu(_conv(sd, 'conv_hr', out)))
     base = xc if hr_in else F.interpolate(xc, scale_factor=4, mode='bilinear', align_corners=False)
     return out + base

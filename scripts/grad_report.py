@@ -13,17 +13,23 @@ if len(sys.argv) > 2:
     ops.CONV_ALGO = {'direct': ops.CONV_DIRECT, 'winograd': ops.CONV_WINOGRAD, 'auto': ops.CONV_AUTO}[sys.argv[2]]
 net, x, kwargs = build(name)
 net.train()
+state = {k: v.detach().clone() for k, v in net.state_dict().items()}
+dev = torch.device('cuda')
+from util_edvr import DecisionRecorder
+net = net.to(dev)
+with DecisionRecorder(net) as rec:
+    out_hip = net(x.to(dev))
+rec.bind(net)
+follow = '--nofollow' not in sys.argv
 def oracle_grads(dt):
-    sd = {k: v.detach().to(dt).requires_grad_() for k, v in net.state_dict().items()}
-    out = EO.edvr_forward(sd, x.to(dt), dcn=O.dcnv2_c, **oracle_kwargs(kwargs))
+    sd = {k: v.to(dt).requires_grad_() for k, v in state.items()}
+    out = EO.edvr_forward(sd, x.to(dt), dcn=O.dcnv2_c, **(rec.oracle_kwargs() if follow else {}), **oracle_kwargs(kwargs))
     gt = torch.rand(out.shape, generator=torch.Generator().manual_seed(1))
     EO.charbonnier_sum(out, gt.to(dt)).backward()
     return gt, {k: v.grad for k, v in sd.items()}
 gt, g64 = oracle_grads(torch.float64)
 _, g32 = oracle_grads(torch.float32)
-dev = torch.device('cuda')
-net = net.to(dev)
-charbonnier_loss(net(x.to(dev)), gt.to(dev)).backward()
+charbonnier_loss(out_hip, gt.to(dev)).backward()
 rel = lambda a, r: ((a.double().cpu() - r).abs().max() / r.abs().max().clamp_min(1e-30)).item()
 rows = []
 for k, p in net.named_parameters():

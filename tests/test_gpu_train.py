@@ -337,28 +337,42 @@ def test_charbonnier(gpu):
 def test_edvr_parameter_gradients_match_oracle(gpu, name, conv_algo):
     """Whole network: d(Charbonnier sum)/d(every parameter), HIP fp32 vs oracle autograd fp64.
     The bound is calibrated per tensor against the fp32 noise floor of the oracle itself (same algorithm in fp32 on the
-    CPU vs fp64): ours must be within max(1e-3, 4 x that floor) of the fp64 truth, relative to max|grad|."""
+    CPU vs fp64): ours must be within max(1e-3, 4 x that floor) of the fp64 truth, relative to max|grad|.
+
+    EDVR is only piecewise differentiable: ReLU / LeakyReLU sides, the element a max-pool window routes to, the cell floor()
+    picks for a deformable tap.  An fp32 run and the fp64 oracle (or two fp32 kernels) decide differently wherever a value sits
+    within the forward rounding error of a boundary, and the gradients then differ by a finite jump, not by rounding: EDVR-L /
+    T7 under the direct kernel had ONE LeakyReLU flip right below `aligned`, which moved every PCD gradient by ~1e-3 (median over
+    tensors 4.3e-4 vs 2e-6 for the Winograd run of the same network; scripts/grad_bisect.py, scripts/grad_taps.py,
+    profiles/r2/grad_bisect_L_T7_direct_vs_winograd.log).  The oracle therefore takes the HIP run's discrete decisions
+    (tests/util_edvr.py::DecisionRecorder -> edvr_oracle._follow / _ACT_SIDES) and computes its own fp64 derivative on them:
+    what is compared is the derivative arithmetic of every kernel, on identical branches."""
     from edvr_amd.autograd import charbonnier_loss
     from oracle import dcn_oracle as O, edvr_oracle as EO
+    from util_edvr import DecisionRecorder
     net, x, kwargs = build(name)
     net.train()
+    state = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.to(gpu)
+    with DecisionRecorder(net) as rec:
+        out = net(x.to(gpu))
+    rec.bind(net)
+    assert len(rec.pool_inputs) == (2 if kwargs.get('with_tsa', True) else 0) and len(rec.oms) == 4 and len(rec.sides) > 20
 
     def oracle_grads(dt):
-        sd = {k: v.detach().to(dt).requires_grad_() for k, v in net.state_dict().items()}
-        out = EO.edvr_forward(sd, x.to(dt), dcn=O.dcnv2_c, **oracle_kwargs(kwargs))
-        gt = torch.rand(out.shape, generator=torch.Generator().manual_seed(1))
-        EO.charbonnier_sum(out, gt.to(dt)).backward()
-        return out.detach(), gt, {k: v.grad for k, v in sd.items()}
+        sd = {k: v.to(dt).requires_grad_() for k, v in state.items()}
+        o = EO.edvr_forward(sd, x.to(dt), dcn=O.dcnv2_c, **rec.oracle_kwargs(), **oracle_kwargs(kwargs))
+        gt = torch.rand(o.shape, generator=torch.Generator().manual_seed(1))
+        EO.charbonnier_sum(o, gt.to(dt)).backward()
+        return o.detach(), gt, {k: v.grad for k, v in sd.items()}
 
     out64, gt, g64 = oracle_grads(torch.float64)
     _, _, g32 = oracle_grads(torch.float32)
-    net = net.to(gpu)
-    out = net(x.to(gpu))
     assert _rel(out.detach(), out64) < 2e-4
     charbonnier_loss(out, gt.to(gpu)).backward()
-    # Offsets are data: where fp32 rounding moves a sampling position across an integer, floor() picks the other cell and
-    # the one-sided derivative changes discretely (the fp32 ORACLE shows the same jumps vs fp64, up to ~6e-3 on the
-    # conv_offset tensors).  So: tight median, tight calibrated bound for >= 95 % of tensors, loose cap for the rest.
+    # What is left after sharing the decisions: the fp32 ORACLE itself differs from fp64 by up to ~6e-3 on the conv_offset
+    # tensors (sampling positions are formed in the compute precision), so each tensor is held to the calibrated bound
+    # max(1e-3, 4 x its own fp32 floor) - ALL of them (round 1 allowed 5 % outliers) - with a tight median.
     ours_all, within = [], 0
     worst = (0.0, 0.0, '')
     for k, p in net.named_parameters():
@@ -375,6 +389,6 @@ def test_edvr_parameter_gradients_match_oracle(gpu, name, conv_algo):
         assert ours < 2e-2, (k, ours, floor)
     ours_all.sort()
     assert ours_all[len(ours_all) // 2] < 5e-5, ours_all[len(ours_all) // 2]
-    assert within >= 0.95 * len(ours_all), (within, len(ours_all))
+    assert within == len(ours_all), (within, len(ours_all), worst)
     print(f'{name}: median {ours_all[len(ours_all) // 2]:.1e}; worst {worst[0]:.2e} (fp32-oracle floor {worst[1]:.2e}) at {worst[2]}; '
           f'{within}/{len(ours_all)} tensors within max(1e-3, 4 x floor)')

@@ -39,3 +39,75 @@ def oracle_kwargs(kwargs):
     return dict(center=kwargs.get('center_frame_idx'), hr_in=kwargs.get('hr_in', False),
                 with_predeblur=kwargs.get('with_predeblur', False), with_tsa=kwargs.get('with_tsa', True),
                 dg=kwargs.get('deformable_groups', 8))
+
+
+class DecisionRecorder:
+    """Records the DISCRETE decisions of one HIP forward pass of `net` so that the fp64 oracle can take the same ones
+    (oracle/edvr_oracle.py: _follow, _ACT_SIDES): the side every ReLU / LeakyReLU element landed on, the inputs of the two
+    max-pools, the offsets fed to the four DCNs.  A gradient comparison is only defined away from those discontinuities; with
+    the decisions shared, fp32-vs-fp64 differences are rounding only.  Usage: `with DecisionRecorder(net) as rec: out = net(x)`,
+    then EO.edvr_forward(..., **rec.oracle_kwargs())."""
+
+    def __init__(self, net):
+        self.names = {id(m): n for n, m in net.named_modules()}
+        self.sides, self.pool_inputs, self.oms = {}, [], []
+
+    def __enter__(self):
+        from edvr_amd import autograd as ag, functional as F_
+        self._F, self._ag = F_, ag
+        self._saved = (F_.conv, F_.dcn_from_packed, F_.pool_maxavg, F_.offset_mask_conv, ag.ResBlockFn.forward)
+        conv, dcn, pool, omc, rbf = self._saved
+        rec = self
+
+        def conv_w(m, x, **k):
+            y = conv(m, x, **k)
+            if k.get('act', F_.ACT_NONE) in (F_.ACT_RELU, F_.ACT_LRELU):
+                v = y.detach()
+                for r in (k.get('res1'), k.get('res2')):  # y = act(z) + res: the backward kernel decides on y - res1 - res2
+                    if r is not None:
+                        v = v - r.detach()
+                rec.sides[rec.names[id(m)]] = (v > 0).cpu()
+            return y
+
+        def dcn_w(m, x, om, act=F_.ACT_NONE):
+            y = dcn(m, x, om, act)
+            if act in (F_.ACT_RELU, F_.ACT_LRELU):
+                rec.sides[rec.names[id(m)]] = (y.detach() > 0).cpu()
+            return y
+
+        def pool_w(t):
+            rec.pool_inputs.append(t.detach().cpu())
+            return pool(t)
+
+        def omc_w(m, f):
+            om = omc(m, f)
+            rec.oms.append(om.detach().cpu())
+            return om
+
+        def rbf_w(ctx, x, w1, b1, w2, b2, res_scale=1.0):  # fused residual block: the hidden ReLU output is only in ctx
+            y = rbf(ctx, x, w1, b1, w2, b2, res_scale)
+            rec._resblock_h.append((w1.data_ptr(), ctx.to_save[1].detach()))
+            return y
+
+        self._resblock_h = []
+        F_.conv, F_.dcn_from_packed, F_.pool_maxavg, F_.offset_mask_conv = conv_w, dcn_w, pool_w, omc_w
+        ag.ResBlockFn.forward = staticmethod(rbf_w)
+        self._net_params = None
+        return self
+
+    def bind(self, net):
+        """call after the forward pass: resolves the fused residual blocks' names from their conv1 weights"""
+        by_ptr = {p.data_ptr(): n for n, p in net.named_parameters()}
+        for ptr, h in self._resblock_h:
+            self.sides[by_ptr[ptr][:-len('.weight')]] = (h > 0).cpu()
+        return self
+
+    def __exit__(self, *exc):
+        F_, ag = self._F, self._ag
+        F_.conv, F_.dcn_from_packed, F_.pool_maxavg, F_.offset_mask_conv = self._saved[:4]
+        ag.ResBlockFn.forward = staticmethod(self._saved[4])
+        return False
+
+    def oracle_kwargs(self):
+        offs = {k: om[:, :2 * om.shape[1] // 3] for k, om in zip(('l3', 'l2', 'l1', 'cas'), self.oms)}
+        return dict(pool_inputs=self.pool_inputs or None, dcn_offsets=offs or None, act_sides=self.sides)
