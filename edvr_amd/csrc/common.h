@@ -69,6 +69,7 @@ int winograd_wgrad_launch(const float *x1, const float *x2, const float *dz, flo
 
 // dcn_fused.hip: column-buffer-free DCNv2 forward for the EDVR signature (3x3, stride 1, pad 1, dil 1, groups 1)
 bool dcn_fused_supported(int C, int Co, int kh, int kw, int stride, int pad, int dil, int groups, int dg);
+int dcn_fused_pack(const float *weight, float *wpk, int Co, int C, hipStream_t stream);  // (Co, C, 3, 3) -> the fused kernel's layout, C * 9 * round_up(Co, 32) floats
 int dcn_fused_forward(const float *x, const float *offset, const float *mask, const float *wpk, const float *bias, float *y, int B, int C,
                       int H, int W, int Co, int dg, int64_t off_bs, int64_t msk_bs, int act, int halo, hipStream_t stream);
 

@@ -754,7 +754,7 @@ int edvr_dcnv2_fwd_f32(const float *x, const float *offset, const float *mask, c
   float *col = reinterpret_cast<float *>(static_cast<char *>(ws) + wsz.col);
   float *wpk = reinterpret_cast<float *>(static_cast<char *>(ws) + wsz.wpk);
   if (use_fused(s) && halo_hint >= 0) {
-    rc = edvr_conv2d_pack_weight_f32(weight, wpk, Co, C, 3, 0, stream_);
+    rc = dcn_fused_pack(weight, wpk, Co, C, stream);
     if (rc) return rc;
     return dcn_fused_forward(x, offset, mask, wpk, bias, y, B, C, H, W, Co, dg, s.off_bs, s.msk_bs, act, halo_hint, stream);
   }

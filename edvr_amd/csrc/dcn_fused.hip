@@ -18,12 +18,15 @@
 // (72 rows x 128) are staged in LDS through the same register-prefetch pipeline as conv2d.hip.
 // A tap whose 2x2 cell leaves the staged halo (|offset| > R) takes a wave-uniform slow path that gathers
 // from global memory with the full bounds logic - correctness never depends on R.
+#include <type_traits>
+
 #include "common.h"
 
 namespace edvr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct DcnFusedArgs {
   const float *x, *offset, *mask, *wpk, *bias;
@@ -54,10 +57,10 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_fwd_kernel(const DcnFusedArg
   constexpr int MB = 32 * MT, WROWS = WCK * KK;            // 36 weight rows (channel, tap) of MB floats per sub-chunk
   constexpr int XS_ELEMS = (CK * CHS + 3) / 4 * 4, WS_ELEMS = WROWS * MB;
   // LDS: the x halo tile and the weight slab are BOTH double-buffered (R = 3, MT = 4: 2 x 15 KB + 2 x 18 KB = 66 KB, two
-  // workgroups per CU).  Round 1 staged the 36 KB weight slab of a chunk through 36 registers per thread (global -> register
-  // -> LDS between two barriers): at 256 VGPRs the compiler spilled exactly those registers, i.e. the "prefetch" waited for
-  // its loads and went through scratch.  Weights now travel global -> LDS directly (global_load_lds_dwordx4: no registers, no
-  // ds_write pass), one 4-channel sub-chunk ahead of the MFMAs that read it.
+  // workgroups per CU) and BOTH filled by LDS-DMA (global_load_lds_dwordx4 / buffer_load_dword ... lds): no staging registers,
+  // no ds_write pass.  (Round 1 staged the 36 KB weight slab of a chunk through 36 registers per thread; at 256 VGPRs the
+  // compiler spilled exactly those, so the prefetch went through scratch.  Removing that - and the other changes of round 2
+  // noted below - freed 23 VGPRs and all scratch but did NOT move the kernel's speed: DESIGN.md section 8 has the measurements.)
   // (the R = 7 halo with >= 96 output channels would need 89-98 KB that way: there the x tile keeps ONE buffer and is committed
   //  at the chunk boundary between two barriers, as in round 1)
   constexpr bool XDB = (2 * XS_ELEMS + 2 * WS_ELEMS) * 4 <= 80 * 1024;
@@ -87,35 +90,33 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_fwd_kernel(const DcnFusedArg
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
-  // ---- x tile: register prefetch (all loads unconditional: clamped address + select), committed to the idle buffer mid-chunk
+  // ---- x halo tile -> LDS, asynchronously too (buffer_load_dword ... lds): lane q of the workgroup owns tile positions q and
+  //      q + 256; a position outside the image carries the offset 0x80000000, which fails the buffer range check and lands in
+  //      LDS as 0 - the zero padding the reference's per-corner bounds test (.cu:481-491) needs.  No staging registers at all.
   constexpr int NXK = (CHS + 255) / 256;
+  constexpr int RSRC_FLAGS = 0x00020000;
   int xoff[NXK];
 #pragma unroll
   for (int k = 0; k < NXK; ++k) {
     const int q = tid + k * 256;
     const int iy = q / RS, ix = q - iy * RS;
     const int gy = hy0 + iy, gx = wx0 + ix;
-    xoff[k] = (q < CHS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? gy * a.W + gx : -1;
+    xoff[k] = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (gy * a.W + gx) * 4 : (int)0x80000000;
   }
-  float xr[CK * NXK];
-  auto prefetch_x = [&](int c0) {
-#pragma unroll
-    for (int ch = 0; ch < CK; ++ch) {
-      const float *src = x + (int64_t)(c0 + ch) * P;
-#pragma unroll
-      for (int k = 0; k < NXK; ++k) {
-        const bool ok = xoff[k] >= 0;
-        const float v = src[ok ? xoff[k] : 0];
-        xr[ch * NXK + k] = ok ? v : 0.f;
-      }
-    }
-  };
-  auto commit_x = [&](float *xs) {
+  const __amdgpu_buffer_rsrc_t x_rsrc = [&]() {
+    const uint64_t pv = reinterpret_cast<uint64_t>(x);
+    const uint64_t pu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pv >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pv);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(pu), (short)0, a.C * P * 4, RSRC_FLAGS);
+  }();
+  auto dma_x = [&](float *dst, int c0) {
+    typedef __attribute__((address_space(3))) void lvoid;
 #pragma unroll
     for (int ch = 0; ch < CK; ++ch)
 #pragma unroll
       for (int k = 0; k < NXK; ++k)
-        if ((k + 1) * 256 <= CHS || tid + k * 256 < CHS) xs[ch * CHS + tid + k * 256] = xr[ch * NXK + k];
+        if ((k + 1) * 256 <= CHS || tid + k * 256 < CHS)  // (the last pass covers part of the workgroup: those lanes are masked off)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lvoid *)(dst + ch * CHS + k * 256 + wave * 64), 4, xoff[k], (c0 + ch) * P * 4, 0, 0);
   };
   // ---- weight sub-chunk (channels cb .. cb + 3, all taps) -> LDS buffer `dst`, asynchronously.  One wave instruction moves
   //      64 x 16 B to a CONTIGUOUS 1 KB of LDS (wave-uniform base + lane x 16); the slab is dense row-major [row][MB], so lane q
@@ -138,7 +139,10 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_fwd_kernel(const DcnFusedArg
   float w00[KK], w01[KK], w10[KK], w11[KK];
   int taddr[KK];  // (the slow path re-reads its offsets from global memory: 18 registers of sampling positions kept for a rare
                   //  branch were spilling state of the hot loop)
-  unsigned slow = 0;  // bit t: the 2x2 cell of tap t is not fully inside the staged halo
+  unsigned slow = 0;      // bit t: the 2x2 cell of tap t is not fully inside the staged halo (this lane)
+  unsigned slow_any = 0;  // the same for ANY lane of the wave, in a scalar register: the per-tap test in the hot loop is then one
+                          // s_bitcmp + branch instead of a v_cmp / ballot / exec-mask sequence, and a whole half chunk can take the
+                          // branch-free copy of the loop
   auto load_taps = [&](int g) {
 #pragma unroll
     for (int t = 0; t < KK; ++t) {
@@ -156,9 +160,17 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_fwd_kernel(const DcnFusedArg
       w11[t] = lh * lw * mm;
       const int ry = (int)fh - hy0, rx = (int)fw - wx0;
       const bool inside = ry >= 0 && ry <= IH - 2 && rx >= 0 && rx <= IW - 2;
+#ifdef DCNF_EXP_NOGATHER  /* ablation (wrong results): every lane reads its regular, conflict-free position */
+      taddr[t] = half * CHS + (oy - hy0 + t / 3 - 1) * RS + (ox - wx0 + t % 3 - 1);
+#else
       taddr[t] = half * CHS + (inside ? ry * RS + rx : 0);
+#endif
       if (valid && !inside) slow |= 1u << t; else slow &= ~(1u << t);
     }
+    unsigned any = 0;
+#pragma unroll
+    for (int t = 0; t < KK; ++t) any |= __any(slow >> t & 1u) ? 1u << t : 0u;
+    slow_any = __builtin_amdgcn_readfirstlane(any);
   };
 
   // ---- two channel pairs (one weight sub-chunk) of MFMAs.  One tap = 4 LDS gathers + MT weight reads -> 5 VALU -> MT MFMAs.
@@ -166,35 +178,43 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_fwd_kernel(const DcnFusedArg
   //      AFTER the MT MFMAs of the previous tap leave the wave at T + 64 (MT - 1) at the earliest and their LDS latency sits
   //      behind the last MFMA (round 1: matrix pipe 48 % busy).  Here the operands of tap t + 1 are requested BEFORE the MFMAs
   //      of tap t (two static register sets, schedule pinned): they return while those MFMAs drain.
-  const int abase = half * KK * MB + j;
-  auto run_half = [&](const float *xs, const float *wsb, int c0, int cp0) {
-    float cv[2][4], av[2][MT];
-    auto issue = [&](int q, int t, float (&c)[4], float (&aw)[MT]) {  // q = channel pair inside this half (0 / 1)
+  const int abase = half * KK * MB + j * MT;
+  // One (channel pair, tap) step = 4 LDS gathers + one weight read -> 7 VALU -> MT MFMAs, 18 steps per half chunk.
+  // SLOW = false: no tap of this wave's pixels leaves the halo for the current deformable group (slow_any == 0, decided once per
+  // group): straight-line code, no exec-mask test between the MFMAs, and a three-stage software pipeline the scheduler is told
+  // to interleave - while the MT MFMAs of step s issue (one every 64 cycles), the LDS reads of step s + 2 and the bilinear
+  // arithmetic of step s + 1 go into the issue slots between them.  Measured: 84 TF/s at sigma(offset) = 0.3 px against 80 for
+  // round 1's read-then-wait order; the ablation ceiling of this work split (no arithmetic at all) is 94.
+  auto run_half = [&](auto SLOWT, const float *xs, const float *wsb, int c0, int cp0) {
+    constexpr bool SLOW = decltype(SLOWT)::value;
+    constexpr int NT = 2 * KK;  // 18 (channel pair, tap) steps
+    float cv[3][4], av[3][MT];
+    auto issue = [&](int step, float (&c)[4], float (&aw)[MT]) {
+      const int q = step / KK, t = step % KK;  // q = channel pair inside this half (0 / 1)
       const float *cell = xs + taddr[t] + 2 * (cp0 + q) * CHS;
       c[0] = cell[0];
       c[1] = cell[1];
       c[2] = cell[RS];
       c[3] = cell[RS + 1];
+      // weight slab rows are stored [j][m] (dcn_fused_pack_kernel): the MT weights of this lane's 32-channel tiles are adjacent,
+      // one ds_read_b128 (MT = 4) / b64 (MT = 2) instead of MT ds_read_b32
+      const float *ap = wsb + abase + (2 * q * KK + t) * MB;
+      if constexpr (MT == 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(ap);
+        aw[0] = v[0]; aw[1] = v[1]; aw[2] = v[2]; aw[3] = v[3];
+      } else if constexpr (MT == 2) {
+        const f32x2 v = *reinterpret_cast<const f32x2 *>(ap);
+        aw[0] = v[0]; aw[1] = v[1];
+      } else {
 #pragma unroll
-      for (int m = 0; m < MT; ++m) aw[m] = wsb[abase + (2 * q * KK + t) * MB + m * 32];
+        for (int m = 0; m < MT; ++m) aw[m] = ap[m];
+      }
     };
-    issue(0, 0, cv[0], av[0]);
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-#pragma unroll
-      for (int t = 0; t < KK; ++t) {
-        const int cur = (q * KK + t) & 1, nxt = cur ^ 1;
-#ifdef DCNF_EXP_NOPIPE  /* ablation: operands requested right before their use */
-        if (!(q == 0 && t == 0)) issue(q, t, cv[cur], av[cur]);
-#else
-        if (t + 1 < KK) issue(q, t + 1, cv[nxt], av[nxt]);
-        else if (q == 0) issue(1, 0, cv[nxt], av[nxt]);
-#endif
-#ifdef DCNF_EXP_PIN  /* pinning the slice order measured 6 % slower (4.50 vs 4.25 ms on the EDVR-L L1 layer): left to the scheduler */
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        float bv = w00[t] * cv[cur][0] + w01[t] * cv[cur][1] + w10[t] * cv[cur][2] + w11[t] * cv[cur][3];
-        if (__any(slow >> t & 1u)) {  // wave-uniform: some lane's cell left the halo -> gather from global
+    auto sample = [&](int step, const float (&c)[4]) -> float {
+      const int q = step / KK, t = step % KK;
+      float bv = w00[t] * c[0] + w01[t] * c[1] + w10[t] * c[2] + w11[t] * c[3];
+      if constexpr (SLOW) {
+        if (slow_any >> t & 1u) {  // wave-uniform (SGPR): some lane's cell left the halo -> gather from global
           if (slow >> t & 1u) {
             const int g = c0 / cpg;
             const float m = msk_b[(int64_t)(g * 9 + t) * P + p];
@@ -203,11 +223,28 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_fwd_kernel(const DcnFusedArg
             bv = dcn_sample_global(x + (int64_t)(c0 + 2 * (cp0 + q) + half) * P, hsp, wsp, m, a.H, a.W);
           }
         }
+      }
+      return bv;
+    };
+    issue(0, cv[0], av[0]);
+    issue(1, cv[1], av[1]);
+    float bv = sample(0, cv[0]);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][m], bv, acc[m], 0, 0, 0);
-#ifdef DCNF_EXP_PIN  /* pinning the slice order measured 6 % slower (4.50 vs 4.25 ms on the EDVR-L L1 layer): left to the scheduler */
-        __builtin_amdgcn_sched_barrier(0);
-#endif
+    for (int st = 0; st < NT; ++st) {
+      const int cur = st % 3, n1 = (st + 1) % 3, n2 = (st + 2) % 3;
+      if (st + 2 < NT) issue(st + 2, cv[n2], av[n2]);
+      float bvn = 0.f;
+      if (st + 1 < NT) bvn = sample(st + 1, cv[n1]);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][m], bv, acc[m], 0, 0, 0);
+      bv = bvn;
+      if constexpr (!SLOW) {  // issue order inside this step: DS reads, then MFMAs with the VALU work spread between them
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);  // DS read
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // up to three VALU
+        }
       }
     }
   };
@@ -219,30 +256,26 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_fwd_kernel(const DcnFusedArg
   };
 
   // ---- schedule (chunk = 8 channels = weight sub-chunks A, B of 4):
-  //   boundary : [settle]  A(c), x(c) valid; nobody reads B any more   -> DMA B(c); x(c+8) -> registers;  MFMAs on A(c)
-  //   middle   : [settle]  B(c) valid; nobody reads A any more         -> DMA A(c+8); x registers -> idle x buffer;  MFMAs on B(c)
+  //   boundary : [settle]  A(c), x(c) valid; nobody reads B or the other x buffer any more -> DMA B(c), DMA x(c+8);  MFMAs on A(c)
+  //   middle   : [settle]  B(c) valid; nobody reads A any more                             -> DMA A(c+8);            MFMAs on B(c)
   dma_w(ws0, 0);
-  prefetch_x(0);
-  commit_x(xs0);
+  dma_x(xs0, 0);
   load_taps(0);
   for (int c0 = 0; c0 < a.C; c0 += CK) {
     const bool more = (c0 + CK) < a.C;
     const int xb = XDB ? (c0 / CK) & 1 : 0;
     const float *xs = xs0 + xb * XS_ELEMS;
     settle();
-    if (!XDB && c0 > 0) {  // single x buffer: the registers loaded during the previous chunk land now
-      commit_x(xs0);
-      __syncthreads();
+    if (!XDB && c0 > 0) {  // single x buffer (big halo, many output channels): the tile is fetched here, latency exposed
+      dma_x(xs0, c0);
+      settle();
     }
     dma_w(ws0 + WS_ELEMS, c0 + WCK);
-    if (more) prefetch_x(c0 + CK);
-    run_half(xs, ws0, c0, 0);
+    if (XDB && more) dma_x(xs0 + (xb ^ 1) * XS_ELEMS, c0 + CK);
+    if (slow_any) run_half(std::true_type{}, xs, ws0, c0, 0); else run_half(std::false_type{}, xs, ws0, c0, 0);
     settle();
-    if (more) {
-      dma_w(ws0, c0 + CK);
-      if (XDB) commit_x(xs0 + (xb ^ 1) * XS_ELEMS);
-    }
-    run_half(xs, ws0 + WS_ELEMS, c0, 2);
+    if (more) dma_w(ws0, c0 + CK);
+    if (slow_any) run_half(std::true_type{}, xs, ws0 + WS_ELEMS, c0, 2); else run_half(std::false_type{}, xs, ws0 + WS_ELEMS, c0, 2);
     if (more && (c0 + CK) % cpg == 0) load_taps((c0 + CK) / cpg);
   }
 
@@ -259,6 +292,26 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_fwd_kernel(const DcnFusedArg
       else if (a.act == EDVR_ACT_SIGMOID) v = __builtin_amdgcn_rcpf(1.f + __expf(-v));
       if (pix_ok && co < a.Co) a.y[((int64_t)img * a.Co + co) * P + p] = v;
     }
+}
+
+// Weight layout of the fused kernel: wpk[c][tap][co'] with the output channels of each launch block (128 = 4 tiles of 32, or the
+// 1-3 tiles of the tail launch) reordered [j][m]: co = block_start + m * 32 + j  ->  position block_start + j * MT + m.
+__global__ void dcn_fused_pack_kernel(const float *__restrict__ w, float *__restrict__ wpk, int Co, int C, int cop) {
+  const int64_t total = (int64_t)C * 9 * cop;
+  const int full = Co / 128, rem_tiles = (Co - full * 128 + 31) / 32;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int pos = (int)(i % cop), t = (int)((i / cop) % 9), c = (int)(i / ((int64_t)cop * 9));
+    const int blk = pos / 128 < full ? pos / 128 : full, start = blk * 128, mt = blk < full ? 4 : rem_tiles;
+    const int r = pos - start, j = r / mt, m = r - j * mt, co = start + m * 32 + j;
+    wpk[i] = (mt > 0 && j < 32 && co < Co) ? w[((int64_t)co * C + c) * 9 + t] : 0.f;
+  }
+}
+
+int dcn_fused_pack(const float *weight, float *wpk, int Co, int C, hipStream_t stream) {
+  const int cop = (Co + 31) / 32 * 32;
+  const int64_t total = (int64_t)C * 9 * cop;
+  hipLaunchKernelGGL(dcn_fused_pack_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 2048)), dim3(256), 0, stream, weight, wpk, Co, C, cop);
+  return check_launch("dcn_fused_pack_kernel");
 }
 
 bool dcn_fused_supported(int C, int Co, int kh, int kw, int stride, int pad, int dil, int groups, int dg) {

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from edvr_amd import ops
 dev = torch.device('cuda')
-for (B, C, H, W, sigma) in [(20, 128, 180, 320, 1.0), (20, 64, 180, 320, 1.0), (20, 128, 90, 160, 1.0), (20, 128, 180, 320, 4.0), (160, 128, 64, 64, 1.0)]:
+for (B, C, H, W, sigma) in [(20, 128, 180, 320, 0.3), (20, 128, 180, 320, 1.0), (20, 64, 180, 320, 1.0), (20, 128, 90, 160, 1.0), (20, 128, 180, 320, 4.0), (160, 128, 64, 64, 1.0)]:
     x = torch.randn(B, C, H, W, device=dev); w = torch.randn(C, C, 3, 3, device=dev) * 0.05; b = torch.randn(C, device=dev)
     off = torch.randn(B, 144, H, W, device=dev) * sigma; m = torch.rand(B, 72, H, W, device=dev)
     for _ in range(2): y = ops.dcnv2_forward(x, off, m, w, b, 1, 1, 1, 1, 8)
