@@ -71,9 +71,9 @@ WORKLOADS = {
     'edvr_m_x4_t5_64x64': dict(net=dict(num_feat=64, num_frame=5, num_reconstruct_block=10, center_frame_idx=2),
                                shape=(5, 3, 64, 64), batch=1, desc='EDVR-M x4, 5 frames, 64x64 LR crop, batch 1'),
 }
-MFMA_KERNELS = ('conv3x3_winograd_kernel', 'conv3x3_winograd_wgrad_kernel', 'conv2d_mfma_kernel', 'conv2d_wgrad_kernel',
+MFMA_KERNELS = ('conv3x3_winograd_kernel', 'conv3x3_winograd4_kernel', 'conv3x3_winograd_wgrad_kernel', 'conv2d_mfma_kernel', 'conv2d_wgrad_kernel',
                 'conv1x1_stream_kernel', 'dcnv2_fwd', 'dcnv2_bwd')
-WINOGRAD = ('conv3x3_winograd_kernel', 'conv3x3_winograd_wgrad_kernel')  # execute 16 instead of 36 multiplies per 2x2 tile
+WINOGRAD = ('conv3x3_winograd_kernel', 'conv3x3_winograd4_kernel', 'conv3x3_winograd_wgrad_kernel')  # execute 16 instead of 36 multiplies per 2x2 tile
 
 
 def parse():
@@ -352,7 +352,7 @@ def train_leg(args, device, rank, world, dist):
         per = instrumented_pass(step, 1)
         tab = kernel_table(per, 1, elapsed / args.train_steps)
         out['dominant_kernels'] = {k: v for k, v in list(tab.items())[:8]}
-        for key, label in (('conv3x3_winograd_kernel', 'fwd_dgrad'), ('conv3x3_winograd_wgrad_kernel', 'wgrad')):
+        for key, label in (('conv3x3_winograd_kernel', 'fwd_dgrad_8wave'), ('conv3x3_winograd4_kernel', 'fwd_dgrad'), ('conv3x3_winograd_wgrad_kernel', 'wgrad')):
             if key in tab:
                 out[f'{label}_mfma_frac'] = tab[key]['frac_of_mfma_peak']
     return out, step

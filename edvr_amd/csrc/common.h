@@ -41,6 +41,10 @@ int winograd_launch(const edvr_conv2d_desc &d, const float *U, int cop64, hipStr
 int winograd_pack(const float *w, float *U, int co, int ci, int cop64, int cip, int transpose_flip, float *wpk_direct, int cop32,
                   hipStream_t stream);  // wpk_direct != nullptr: also writes the direct layout [cip][9][cop32] in the same launch
 
+// winograd4.hip: the same convolution as 4-wave workgroups, two per CU (takes over where winograd4_supported)
+bool winograd4_supported(const edvr_conv2d_desc &d);
+int winograd4_launch(const edvr_conv2d_desc &d, const float *U, int cop64, hipStream_t stream);
+
 // conv_small.hip: 3x3 / stride-1 conv with <= 4 output channels on the vector ALUs (EDVR's conv_last)
 bool conv_small_eligible(const edvr_conv2d_desc &d);
 int conv_small_launch(const edvr_conv2d_desc &d, hipStream_t stream);

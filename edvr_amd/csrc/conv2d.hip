@@ -368,7 +368,10 @@ int conv2d_launch(const edvr_conv2d_desc &d, hipStream_t stream) {
     return EDVR_ERR_UNSUPPORTED;
   }
   if (!d.gate && !scaled && conv_small_eligible(d)) return conv_small_launch(d, stream);
-  if (winograd_eligible(d)) return winograd_launch(d, d.wpk + direct_packed_elems(d.co, a.ci, 3), round_up(d.co, 64), stream);
+  if (winograd_eligible(d)) {
+    const float *U = d.wpk + direct_packed_elems(d.co, a.ci, 3);
+    return winograd4_supported(d) ? winograd4_launch(d, U, round_up(d.co, 64), stream) : winograd_launch(d, U, round_up(d.co, 64), stream);
+  }
   if (d.ks == 3 && d.stride == 1) return launch_mt<3, 1>(a, stream);
   if (d.ks == 3 && d.stride == 2) return launch_mt<3, 2>(a, stream);
   if (conv1x1_eligible(d)) return conv1x1_launch(d, stream);
@@ -407,7 +410,7 @@ int edvr_conv2d_kernel_name(const edvr_conv2d_desc *d, char *buf, size_t buf_len
     return EDVR_OK;
   }
   if (edvr::winograd_eligible(*d)) {
-    snprintf(buf, buf_len, "conv3x3_winograd_kernel");
+    snprintf(buf, buf_len, edvr::winograd4_supported(*d) ? "conv3x3_winograd4_kernel" : "conv3x3_winograd_kernel");
     return EDVR_OK;
   }
   if (edvr::conv1x1_eligible(*d)) {
