@@ -45,12 +45,16 @@ struct ConvChunk {
 #define EDVR_CONV_MINWAVES 2
 #endif
 
-template <int KS, int STRIDE, int MT, int SW>
+// NS = 32-pixel sub-tiles per wave.  Two halve the weight reads per MFMA, one halves the tile (twice the workgroups, half the
+// accumulators: more waves in flight).  Measured (direct kernel alone, TF/s, NS = 2 -> 1): 3x3 stride 2 61 -> 111, 1x1 41-50 ->
+// 71-82, 3x3 on 45x80 / 90x160 images 62 / 101 -> 92 / 124, 128 -> 512 channels 112 -> 126, 128 -> 128 at 180x320 109 -> 115;
+// only the 64-channel layers (two 32-channel tiles per workgroup) lose 3 %.  So: one sub-tile from three channel tiles up.
+template <int KS, int STRIDE, int MT, int SW, int NS>
 __global__ __launch_bounds__(256, EDVR_CONV_MINWAVES) void conv2d_mfma_kernel(const ConvArgs a) {
   // (measured: giving the 1x1/MT=4 instantiation the 512-register budget instead of spilling is SLOWER, 27 vs 41 TF/s:
   //  that shape is latency-bound and wants the occupancy)
   constexpr int SH = 32 / SW;        // rows of one 32-pixel subtile
-  constexpr int NSUB = 2;            // subtiles per wave
+  constexpr int NSUB = NS;           // subtiles per wave
   constexpr int TW = SW;             // output tile width
   constexpr int TH = 4 * NSUB * SH;  // output tile height (4 waves)
   constexpr int IW = (TW - 1) * STRIDE + KS;
@@ -300,27 +304,28 @@ static inline size_t direct_packed_elems(int co, int ci, int ks) {
 
 template <int KS, int STRIDE, int MT, int SW>
 static int launch_one(const ConvArgs &a, int co_start, int co_blocks, hipStream_t stream) {
-  constexpr int SH = 32 / SW, TH = 8 * SH, TW = SW;
+  constexpr int NS = MT >= 3 ? 1 : 2;
+  constexpr int SH = 32 / SW, TH = 4 * NS * SH, TW = SW;
   ConvArgs b = a;
   b.tiles_x = cdiv(a.wo, TW);
   b.tiles_y = cdiv(a.ho, TH);
   b.co_start = co_start;
   dim3 grid(b.tiles_x * b.tiles_y, co_blocks, a.d.n);
-  hipLaunchKernelGGL((conv2d_mfma_kernel<KS, STRIDE, MT, SW>), grid, dim3(256), 0, stream, b);
+  hipLaunchKernelGGL((conv2d_mfma_kernel<KS, STRIDE, MT, SW, NS>), grid, dim3(256), 0, stream, b);
   return check_launch("conv2d_mfma_kernel");
 }
 
-static inline bool use_sw16(int ho, int wo) {
-  // pick the tile geometry (8x32 or 16x16) that wastes fewer lanes on this output size
-  const int64_t w32 = (int64_t)cdiv(ho, 8) * 8 * cdiv(wo, 32) * 32;
-  const int64_t w16 = (int64_t)cdiv(ho, 16) * 16 * cdiv(wo, 16) * 16;
+static inline bool use_sw16(int ho, int wo, int ns = 2) {
+  // pick the tile geometry (4ns x 32 or 8ns x 16) that wastes fewer lanes on this output size
+  const int64_t w32 = (int64_t)cdiv(ho, 4 * ns) * 4 * ns * cdiv(wo, 32) * 32;
+  const int64_t w16 = (int64_t)cdiv(ho, 8 * ns) * 8 * ns * cdiv(wo, 16) * 16;
   return w16 < w32;
 }
 
 template <int KS, int STRIDE, int MT>
 static int launch_sw(const ConvArgs &a, int co_start, int co_blocks, hipStream_t stream) {
-  return use_sw16(a.ho, a.wo) ? launch_one<KS, STRIDE, MT, 16>(a, co_start, co_blocks, stream)
-                              : launch_one<KS, STRIDE, MT, 32>(a, co_start, co_blocks, stream);
+  return use_sw16(a.ho, a.wo, MT >= 3 ? 1 : 2) ? launch_one<KS, STRIDE, MT, 16>(a, co_start, co_blocks, stream)
+                                               : launch_one<KS, STRIDE, MT, 32>(a, co_start, co_blocks, stream);
 }
 
 template <int KS, int STRIDE>
@@ -418,7 +423,8 @@ int edvr_conv2d_kernel_name(const edvr_conv2d_desc *d, char *buf, size_t buf_len
     return EDVR_OK;
   }
   const int mt = d->co >= 128 ? 4 : edvr::cdiv(d->co, 32);  // the launch carrying most of the work
-  snprintf(buf, buf_len, "conv2d_mfma_kernel<%d, %d, %d, %d>", d->ks, d->stride, mt, edvr::use_sw16(ho, wo) ? 16 : 32);
+  const int ns = mt >= 3 ? 1 : 2;
+  snprintf(buf, buf_len, "conv2d_mfma_kernel<%d, %d, %d, %d, %d>", d->ks, d->stride, mt, edvr::use_sw16(ho, wo, ns) ? 16 : 32, ns);
   return EDVR_OK;
 }
 

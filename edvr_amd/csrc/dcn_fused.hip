@@ -63,9 +63,10 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_fwd_kernel(const DcnFusedArg
   // noted below - freed 23 VGPRs and all scratch but did NOT move the kernel's speed: DESIGN.md section 8 has the measurements.)
   // (the R = 7 halo with >= 96 output channels would need 89-98 KB that way: there the x tile keeps ONE buffer and is committed
   //  at the chunk boundary between two barriers, as in round 1)
-  constexpr bool XDB = (2 * XS_ELEMS + 2 * WS_ELEMS) * 4 <= 80 * 1024;
-  __shared__ __attribute__((aligned(16))) float smem[(XDB ? 2 : 1) * XS_ELEMS + 2 * WS_ELEMS];
-  float *xs0 = smem, *ws0 = smem + (XDB ? 2 : 1) * XS_ELEMS;
+  constexpr bool XDB = (2 * XS_ELEMS + 2 * WS_ELEMS + 3 * 9 * 128) * 4 <= 80 * 1024;
+  constexpr int TP_ELEMS = 3 * KK * TH * TW;  // 27 offset / mask values of the NEXT deformable group for the 128 pixels: 13.5 KB
+  __shared__ __attribute__((aligned(16))) float smem[(XDB ? 2 : 1) * XS_ELEMS + 2 * WS_ELEMS + TP_ELEMS];
+  float *xs0 = smem, *ws0 = smem + (XDB ? 2 : 1) * XS_ELEMS, *tp = ws0 + 2 * WS_ELEMS;
 
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, j = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -143,12 +144,32 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_fwd_kernel(const DcnFusedArg
   unsigned slow_any = 0;  // the same for ANY lane of the wave, in a scalar register: the per-tap test in the hot loop is then one
                           // s_bitcmp + branch instead of a v_cmp / ballot / exec-mask sequence, and a whole half chunk can take the
                           // branch-free copy of the loop
-  auto load_taps = [&](int g) {
+  // The 27 offset / mask values of a group come from global memory; consumed right away, their latency (1-2 us) sat exposed
+  // between two chunks every 16 channels (measured on the 64-channel layer, where registers allowed a register prefetch: +17 %).
+  // They are fetched by LDS-DMA one whole group ahead - requested right after a group's first barrier, read from LDS when the
+  // group ends - into `tp` [value 27][wave 4][pixel 32]; both half-waves of a pixel read the same word (broadcast).
+  const int tp_voff = pix_ok ? p * 4 : (int)0x80000000;
+  auto request_taps = [&](int g) {
+    typedef __attribute__((address_space(3))) void lvoid;
+    auto rsrc_of = [&](const float *ptr, int bytes) {  // (built here: eight scalar registers live for 27 instructions, not for the kernel)
+      const uint64_t pv = reinterpret_cast<uint64_t>(ptr);
+      const uint64_t pu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pv >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pv);
+      return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(pu), (short)0, bytes, RSRC_FLAGS);
+    };
+    const __amdgpu_buffer_rsrc_t off_rsrc = rsrc_of(off_b, a.dg * 18 * P * 4), msk_rsrc = rsrc_of(msk_b, a.dg * 9 * P * 4);
+    if (half == 0) {  // lanes 0-31: one word per pixel
+#pragma unroll
+      for (int t = 0; t < KK; ++t) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(off_rsrc, (lvoid *)(tp + ((3 * t + 0) * 4 + wave) * 32), 4, tp_voff, (g * 18 + 2 * t) * P * 4, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(off_rsrc, (lvoid *)(tp + ((3 * t + 1) * 4 + wave) * 32), 4, tp_voff, (g * 18 + 2 * t + 1) * P * 4, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(msk_rsrc, (lvoid *)(tp + ((3 * t + 2) * 4 + wave) * 32), 4, tp_voff, (g * 9 + t) * P * 4, 0, 0);
+      }
+    }
+  };
+  auto finish_taps = [&]() {
 #pragma unroll
     for (int t = 0; t < KK; ++t) {
-      const float dy = off_b[(int64_t)(g * 18 + 2 * t) * P + p];
-      const float dx = off_b[(int64_t)(g * 18 + 2 * t + 1) * P + p];
-      const float m = msk_b[(int64_t)(g * 9 + t) * P + p];
+      const float dy = tp[((3 * t + 0) * 4 + wave) * 32 + j], dx = tp[((3 * t + 1) * 4 + wave) * 32 + j], m = tp[((3 * t + 2) * 4 + wave) * 32 + j];
       const float h = (float)(oy - 1 + t / 3) + dy, w = (float)(ox - 1 + t % 3) + dx;
       const bool valid = pix_ok && h > -1.f && w > -1.f && h < (float)a.H && w < (float)a.W;  // .cu:618
       const float fh = floorf(h), fw = floorf(w);
@@ -173,11 +194,6 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_fwd_kernel(const DcnFusedArg
     slow_any = __builtin_amdgcn_readfirstlane(any);
   };
 
-  // ---- two channel pairs (one weight sub-chunk) of MFMAs.  One tap = 4 LDS gathers + MT weight reads -> 5 VALU -> MT MFMAs.
-  //      A wave issues in order and an MFMA only issues once the matrix pipe accepts it (every 64 cycles), so reads placed
-  //      AFTER the MT MFMAs of the previous tap leave the wave at T + 64 (MT - 1) at the earliest and their LDS latency sits
-  //      behind the last MFMA (round 1: matrix pipe 48 % busy).  Here the operands of tap t + 1 are requested BEFORE the MFMAs
-  //      of tap t (two static register sets, schedule pinned): they return while those MFMAs drain.
   const int abase = half * KK * MB + j * MT;
   // One (channel pair, tap) step = 4 LDS gathers + one weight read -> 7 VALU -> MT MFMAs, 18 steps per half chunk.
   // SLOW = false: no tap of this wave's pixels leaves the halo for the current deformable group (slow_any == 0, decided once per
@@ -260,7 +276,9 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_fwd_kernel(const DcnFusedArg
   //   middle   : [settle]  B(c) valid; nobody reads A any more                             -> DMA A(c+8);            MFMAs on B(c)
   dma_w(ws0, 0);
   dma_x(xs0, 0);
-  load_taps(0);
+  request_taps(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (each wave reads back only what it requested itself)
+  finish_taps();
   for (int c0 = 0; c0 < a.C; c0 += CK) {
     const bool more = (c0 + CK) < a.C;
     const int xb = XDB ? (c0 / CK) & 1 : 0;
@@ -272,11 +290,12 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_fwd_kernel(const DcnFusedArg
     }
     dma_w(ws0 + WS_ELEMS, c0 + WCK);
     if (XDB && more) dma_x(xs0 + (xb ^ 1) * XS_ELEMS, c0 + CK);
+    if (c0 % cpg == 0 && c0 + cpg < a.C) request_taps(c0 / cpg + 1);  // first chunk of a group: the next group's 27 values
     if (slow_any) run_half(std::true_type{}, xs, ws0, c0, 0); else run_half(std::false_type{}, xs, ws0, c0, 0);
     settle();
     if (more) dma_w(ws0, c0 + CK);
     if (slow_any) run_half(std::true_type{}, xs, ws0 + WS_ELEMS, c0, 2); else run_half(std::false_type{}, xs, ws0 + WS_ELEMS, c0, 2);
-    if (more && (c0 + CK) % cpg == 0) load_taps((c0 + CK) / cpg);
+    if (more && (c0 + CK) % cpg == 0) finish_taps();  // (requested a group ago; landed before the middle barrier of its first chunk)
   }
 
   // ---- epilogue: bias, activation, store
