@@ -72,7 +72,7 @@ WORKLOADS = {
                                shape=(5, 3, 64, 64), batch=1, desc='EDVR-M x4, 5 frames, 64x64 LR crop, batch 1'),
 }
 MFMA_KERNELS = ('conv3x3_winograd_kernel', 'conv3x3_winograd4_kernel', 'conv3x3_winograd_wgrad_kernel', 'conv2d_mfma_kernel', 'conv2d_wgrad_kernel',
-                'conv1x1_stream_kernel', 'dcnv2_fwd', 'dcnv2_bwd')
+                'conv1x1_stream_kernel', 'gemm_nt_kernel', 'dcnv2_fwd', 'dcnv2_bwd')
 WINOGRAD = ('conv3x3_winograd_kernel', 'conv3x3_winograd4_kernel', 'conv3x3_winograd_wgrad_kernel')  # execute 16 instead of 36 multiplies per 2x2 tile
 
 

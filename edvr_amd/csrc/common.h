@@ -33,6 +33,10 @@ int conv2d_launch(const edvr_conv2d_desc &d, hipStream_t stream);
 size_t gemm_nt_ws_elems(int M, int N, int64_t K);
 int gemm_nt_launch(const float *A, const float *B, float *C, int M, int N, int64_t K, int64_t lda, int64_t ldb,
                    bool accumulate, float *ws, hipStream_t stream);
+// the same summed over `nb` (A, B) pairs a_bs / b_bs elements apart (images): dW of the DCNv2 backward and of the 1x1 convs
+size_t gemm_nt_ws_elems_b(int M, int N, int64_t K, int nb);
+int gemm_nt_batched(const float *A, const float *B, float *C, int M, int N, int64_t K, int64_t lda, int64_t ldb, int nb, int64_t a_bs,
+                    int64_t b_bs, bool accumulate, float *ws, hipStream_t stream);
 
 // winograd.hip: F(2x2,3x3) path of the 3x3 / stride-1 convolution.  U (transformed weights, [ci_pad][16][round_up(co,64)])
 // follows the direct packed layout inside the buffer edvr_conv2d_pack_weight_f32 fills.
@@ -42,6 +46,7 @@ int winograd_pack(const float *w, float *U, int co, int ci, int cop64, int cip, 
                   hipStream_t stream);  // wpk_direct != nullptr: also writes the direct layout [cip][9][cop32] in the same launch
 
 // winograd4.hip: the same convolution as 4-wave workgroups, two per CU (takes over where winograd4_supported)
+bool winograd4_enabled();  // EDVR_WINOGRAD_4WAVE=1: the weights are then packed in that kernel's operand order
 bool winograd4_supported(const edvr_conv2d_desc &d);
 int winograd4_launch(const edvr_conv2d_desc &d, const float *U, int cop64, hipStream_t stream);
 

@@ -139,7 +139,9 @@ bool conv1x1_eligible(const edvr_conv2d_desc &d) {
   if (!enabled || d.ks != 1 || d.stride != 1 || d.out_mode != EDVR_OUT_NCHW || d.algo == EDVR_CONV_DIRECT) return false;
   if ((d.c1 & 1) || (d.c2 & 1)) return false;                                      // channel pairs must not straddle x1 / x2
   const int64_t per_img = (int64_t)std::max(d.c1, d.c2) * d.h * d.w * 4;
-  return per_img < ((int64_t)1 << 31) && d.co >= 32 && d.c1 + d.c2 >= 64;         // 32-bit buffer offsets; worth a 64-channel slab
+  // 32-bit buffer offsets; a deep K: at 128 input channels the one-sub-tile direct kernel (3 waves per SIMD) is faster - 82.6 vs
+  // 71.7 TF/s on the 128 -> 1152 `dcol` product of the DCN backward - while this kernel wins from 640 channels up (84 vs 71, 104 vs 82)
+  return per_img < ((int64_t)1 << 31) && d.co >= 32 && d.c1 + d.c2 >= 320;
 }
 
 int conv1x1_launch(const edvr_conv2d_desc &d, hipStream_t stream) {

@@ -630,7 +630,7 @@ static int gemm_splits(int M, int N, int64_t total_chunks) {
   return s;
 }
 
-static int gemm_nt_batched(const float *A, const float *B, float *C, int M, int N, int64_t K, int64_t lda, int64_t ldb, int nb,
+int gemm_nt_batched(const float *A, const float *B, float *C, int M, int N, int64_t K, int64_t lda, int64_t ldb, int nb,
                            int64_t a_bs, int64_t b_bs, bool accumulate, float *ws, hipStream_t stream) {
   GemmNT g;
   g.A = A; g.B = B; g.ws = ws; g.M = M; g.N = N; g.nb = nb; g.K = K; g.lda = lda; g.ldb = ldb; g.a_bs = a_bs; g.b_bs = b_bs;
@@ -646,7 +646,7 @@ static int gemm_nt_batched(const float *A, const float *B, float *C, int M, int 
   return reduce_partials_launch(ws, C, (int64_t)M * N, g.splits, accumulate ? 1 : 0, stream);
 }
 
-static size_t gemm_nt_ws_elems_b(int M, int N, int64_t K, int nb) {
+size_t gemm_nt_ws_elems_b(int M, int N, int64_t K, int nb) {
   const int64_t chunks = cdiv64(K, GK) * nb;
   return (size_t)gemm_splits(M, N, chunks) * M * N;
 }

@@ -305,7 +305,8 @@ size_t edvr_conv2d_wgrad_ws_bytes(int n, int ci, int h, int w, int co, int ks, i
   const int units = n * edvr::cdiv(ho, 2) * edvr::cdiv(wo, 32);
   const int mw = edvr::wgrad_mw(co, stride);
   const int tiles = edvr::cdiv(ci, 32 * (4 / mw)) * edvr::cdiv(co, 32 * mw);
-  return std::max(std::max(wino, small), (size_t)edvr::wgrad_splits(tiles, units) * co * ci * ks * ks * sizeof(float));  // any algorithm
+  const size_t gemm = ks == 1 ? edvr::gemm_nt_ws_elems_b(co, ci, (int64_t)ho * wo, n) * sizeof(float) : 0;  // 1x1: the split-K GEMM of dcn.hip
+  return std::max(std::max(std::max(wino, small), gemm), (size_t)edvr::wgrad_splits(tiles, units) * co * ci * ks * ks * sizeof(float));  // any algorithm
 }
 
 int edvr_conv2d_wgrad_f32(const float *x1, const float *x2, const float *dz, float *dw, int c1, int c2, int n, int h, int w, int co,
@@ -349,6 +350,15 @@ int edvr_conv2d_wgrad_f32(const float *x1, const float *x2, const float *dz, flo
     if (rc || !dbias) return rc;
     return edvr_channel_sum_f32(dz, dbias, n, co, (int64_t)a.ho * a.wo, dz_img_stride, ws, ws_bytes, stream_);
   }
+  if (ks == 1 && !x2 && winograd_wgrad_get_algo() == EDVR_CONV_AUTO && ws_bytes >= gemm_nt_ws_elems_b(co, ci, (int64_t)h * w, n) * sizeof(float)) {
+    // 1x1: dW[co, ci] = sum over images and pixels of dz[co, p] x[ci, p] is the K-contiguous "NT" product the DCN backward uses
+    // for its dW (128 x 128 tiles, 4 accumulator tiles per wave, 98 TF/s); the strip kernel below has ONE tile per wave and two
+    // barriers per 32 MFMAs for a 1x1 kernel (40 TF/s)
+    int rc = gemm_nt_batched(dz, x1, dw, co, ci, (int64_t)h * w, (int64_t)h * w, (int64_t)h * w, n, dz_img_stride, x1_img_stride, accumulate != 0,
+                             a.ws, stream);
+    if (rc || !dbias) return rc;
+    return edvr_channel_sum_f32(dz, dbias, n, co, (int64_t)a.ho * a.wo, dz_img_stride, ws, ws_bytes, stream_);
+  }
   int wsplits = 0;
   if (winograd_wgrad_plan(n, c1, c2, h, w, co, ks, stride, &wsplits) && ws_bytes >= winograd_wgrad_ws_bytes(co, ci, wsplits)) {
     int rc = winograd_wgrad_launch(x1, x2, dz, a.ws, c1, c2, n, h, w, co, x1_img_stride, x2_img_stride, x2_div, x2_mul, x2_add,
@@ -383,6 +393,8 @@ int edvr_conv2d_wgrad_kernel_name(int n, int c1, int c2, int h, int w, int co, i
   int splits = 0;
   if (winograd_wgrad_get_algo() == EDVR_CONV_AUTO && wgrad_small_plan(n, c1, c2, h, w, co, ks, stride, &splits))
     snprintf(buf, buf_len, "wgrad3x3_smallco_kernel");
+  else if (ks == 1 && c2 == 0 && winograd_wgrad_get_algo() == EDVR_CONV_AUTO)
+    snprintf(buf, buf_len, "gemm_nt_kernel");
   else if (winograd_wgrad_plan(n, c1, c2, h, w, co, ks, stride, &splits))
     snprintf(buf, buf_len, "conv3x3_winograd_wgrad_kernel");
   else

@@ -1,35 +1,29 @@
 // winograd4.hip - the Winograd F(2x2, 3x3) convolution of winograd.hip as FOUR-wave workgroups, two per CU (gfx950).
-// EXPERIMENT, opt-in (EDVR_WINOGRAD_4WAVE=1): correct (same tests as winograd.hip), measured at parity with the 8-wave kernel.
+// EXPERIMENT, opt-in (EDVR_WINOGRAD_4WAVE=1): correct (same tests as winograd.hip).
 //
 // winograd.hip runs one 8-wave workgroup per CU: both waves of a SIMD belong to it and meet at the same barrier, so while an
 // item's epilogue (output transform, sibling exchange, 64 KB of stores) and the pipeline refill run - 5.6 of 39 us per item at
 // 128 input channels - the matrix pipe of the whole CU idles, and every barrier stall idles it too.  Here a workgroup has 4
 // waves (wave = (ph, 32-channel half of the 64-channel block), 8 accumulator tiles = the same 256-register budget) and owns
 // 64 output channels x 32 tiles (4 x 32 output pixels); TWO of them share a CU, one wave of each per SIMD, and nothing ties
-// them together: one workgroup's epilogue, barrier waits and refill are the other's MFMA time.  64 KB of LDS each:
-//   * U (transformed weights) is staged in 4-channel sub-chunks (4 x 16 x 64 floats = 16 KB) through four rotating 16-byte
-//     registers per thread into a double-buffered slab, one sub-chunk ahead of the MFMAs that read it;
+// them together: one workgroup's epilogue, barrier waits and refill are the other's MFMA time.
+//   * U (transformed weights): with this split every element of U is an MFMA A operand of exactly ONE wave of the workgroup
+//     (its channel half, its two transform rows), so staging U through LDS is pure overhead.  The weights are packed in
+//     operand order instead ([co block][channel pair][row][co half][lane][4 positions], winograd_weight_kernel) and each lane
+//     fetches its next four A operands with one coalesced 16-byte buffer load (1 KB per wave) straight into a rotating set of
+//     four register quads, half a chunk ahead of the MFMAs that consume them.  No LDS traffic, no barrier for U.
 //   * V (transformed input) keeps the rotating-register pipeline of winograd.hip - thread = (channel of the 8-channel chunk,
 //     tile of 32): loads of chunk k + 2, transform + commit of chunk k + 1 in the shadow of the MFMAs of chunk k - in a
-//     double-buffered 2 x 16 KB slab.
-// Per 8-channel chunk: barrier -> 16 MFMAs on U_A(k) (+ column transforms, patch loads; U_B(k) registers -> stage 1, reloaded
-// with U_A(k+1)) -> barrier -> 16 MFMAs on U_B(k) (+ V commits; U_A(k+1) registers -> stage 0, reloaded with U_B(k+1)).
-// Barriers wait for LDS traffic only (the loads in flight target registers).  The second dispatch wave of workgroups starts
-// a good epilogue later (one-off s_sleep): with equal work per item a phase difference between the two workgroups of a CU
-// persists, so their epilogues do not coincide.
+//     double-buffered 2 x 16 KB slab, one barrier per chunk (LDS traffic only; the loads in flight target registers).
+//   * The sibling exchange of the output transform has its own 32 KB, so the epilogue needs one barrier.
+// The second dispatch wave of workgroups starts a good epilogue later (one-off s_sleep): with equal work per item a phase
+// difference between the two workgroups of a CU persists, so their epilogues do not coincide.
 //
-// What was measured (n = 20, 128 -> 128, 180x320, bias + LeakyReLU; 8-wave kernel 1.72-1.75 ms):
-//   U by LDS-DMA (global_load_lds_dwordx4, no staging registers)        1.95 ms   two workgroups need 32 KB of U per half chunk
-//                                                                                 and CU = ~32 GB/s; one CU's LDS-DMA path delivers
-//                                                                                 ~25 GB/s (the same DMA in the 8-wave kernel, at
-//                                                                                 15 GB/s per CU: 1.80 ms - no gain there either)
+// Earlier forms of this file, measured (n = 20, 128 -> 128, 180x320, bias + LeakyReLU; 8-wave kernel 1.72-1.75 ms):
+//   U by LDS-DMA (global_load_lds_dwordx4, no staging registers)        1.95 ms   one CU's LDS-DMA path delivers ~25 GB/s
 //   ... with the U fetch removed (wrong results; bound of the structure) 1.45 ms   the overlap works: 235 alg. TF/s = 0.66 executed
-//   U through rotating registers (this file)                            1.81 ms   each workgroup stages the full 64-channel U slab
-//                                                                                 for half the tiles: twice the U traffic and
-//                                                                                 staging instructions per MFMA eat what the
-//                                                                                 overlapped epilogue gives back
-//   without the start-up stagger / with looser barrier waits            no change
-// Same arithmetic, same epilogue variants and the same packed weights as winograd.hip (results are bit-identical).
+//   U through rotating registers into a double-buffered LDS slab        1.81 ms   twice the U staging per MFMA of the 8-wave kernel
+// Same arithmetic and the same epilogue variants as winograd.hip (results are bit-identical).
 #include <cstdlib>
 #include <type_traits>
 
@@ -43,7 +37,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct Wino4Args {
   edvr_conv2d_desc d;
-  const float *U;  // [ci_pad][16][cop]
+  const float *U;  // operand order: [co block 64][channel pair][row 4][co half 2][lane 64][4]
   int ci, ci_real, cop, tiles_x, tiles_y, items;  // ci: rounded up to 16 (U has all-zero rows there), ci_real = c1 + c2
   float ys, ys_gs;  // y_scale (0 -> 1) and y_scale * gate_slope, resolved on the host
 };
@@ -54,10 +48,10 @@ __device__ __forceinline__ void mfma_acc4(f32x16 &acc, float a, float b) {
 
 template <bool PAIR, bool GATE = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_winograd4_kernel(const Wino4Args a) {
-  constexpr int CK = 8, UK = 4, TY = 2, TX = 16;  // V chunk / U sub-chunk channels; 32 tiles = 4 x 32 output pixels
-  constexpr int USLAB = UK * 16 * 64, VSLAB = CK * 16 * 32;  // floats per stage (16 KB each)
-  __shared__ __attribute__((aligned(16))) float smem[2 * USLAB + 2 * VSLAB];  // 64 KB
-  float *const Us0 = smem, *const Us1 = smem + USLAB, *const Vs0 = smem + 2 * USLAB, *const Vs1 = Vs0 + VSLAB;
+  constexpr int CK = 8, TY = 2, TX = 16;  // V chunk channels; 32 tiles = 4 x 32 output pixels
+  constexpr int VSLAB = CK * 16 * 32;      // floats per V stage (16 KB)
+  __shared__ __attribute__((aligned(16))) float smem[2 * VSLAB + 4 * 2048];  // two V stages + the exchange area = 64 KB
+  float *const Vs0 = smem, *const Vs1 = smem + VSLAB, *const Xs = smem + 2 * VSLAB;
 
   const edvr_conv2d_desc &d = a.d;
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, j = lane & 31;
@@ -105,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd4_kernel(const Wino4Ar
   f32x16 acc[8];  // tiles 0-3 = transform row row_lo, 4-7 = row_hi (below)
   float pr[16];   // raw patch of (channel 2 wave + half, tile j) of the chunk being staged
   float tt[16];   // B^T d
-  f32x4 ur[4];    // this thread's 4 x 16 B of the U sub-chunk being staged
+  f32x4 aq[4];    // A operands (U) of four MFMA groups: group g of a chunk uses aq[g & 3], reloaded for group g + 4 right after
 
   __amdgpu_buffer_rsrc_t ld_rsrc = uniform_rsrc(a.U, 0);
   auto load_begin = [&](int c0) {
@@ -142,65 +136,54 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd4_kernel(const Wino4Ar
     dst[2 * 32] = t[2] - t[1];
     dst[3 * 32] = t[1] - t[3];
   };
-  // U sub-chunk (channels cb .. cb + 3, 16 positions, 64 output channels from coblk): 1024 float4, thread t holds numbers
-  // t + 256 g (row (t >> 4) + 16 g of the 64 (channel, xi) rows, 4 floats at column 4 (t & 15)); slab dense [(channel, xi)][64]
-  const int u_bytes = a.ci * 16 * a.cop * 4;
-  const int u_voff = ((tid >> 4) * a.cop + (tid & 15) * 4) * 4;
-  const __amdgpu_buffer_rsrc_t u_rsrc = uniform_rsrc(a.U, u_bytes);
-  auto load_u = [&](int g, int cb, int coblk) {
-    ur[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_voff, ((cb * 16 + 16 * g) * a.cop + coblk) * 4, 0));
-  };
-  auto commit_u = [&](float *Us, int g) { *reinterpret_cast<f32x4 *>(Us + (tid + g * 256) * 4) = ur[g]; };
-
   const int row_lo = ph ? 2 : 1, row_hi = ph ? 3 : 0;
-  const int abase[2] = {half * 16 * 64 + row_lo * 4 * 64 + wm * 32 + j, half * 16 * 64 + row_hi * 4 * 64 + wm * 32 + j};  // A (U): co tile
+  // A operands of group g = (channel pair g >> 1, row set g & 1) of the chunk at channel c0, output-channel block coblk:
+  // one 1 KB block of the packed weights per wave, lane l reads 16 bytes at 16 l (positions 4 row .. 4 row + 3)
+  const int u_bytes = a.ci * 16 * a.cop * 4, np = a.ci >> 1;
+  const int u_voff = lane * 16;
+  const __amdgpu_buffer_rsrc_t u_rsrc = uniform_rsrc(a.U, u_bytes);
+  auto load_a = [&](int q, int c0, int g, int coblk) {
+    const int row = (g & 1) ? row_hi : row_lo;
+    const int soff = (((((coblk >> 6) * np + (c0 >> 1) + (g >> 1)) * 4 + row) * 2 + wm) * 1024);
+    aq[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_voff, soff, 0));
+  };
+
   const int bbase[2] = {half * 16 * 32 + row_lo * 4 * 32 + j, half * 16 * 32 + row_hi * 4 * 32 + j};                      // B (V): the 32 tiles
-  // One 8-channel chunk (V stage P).  On entry the U registers hold sub-chunk B of THIS chunk; (ua_c, ua_co) / (ub_c, ub_co):
-  // channel base and output-channel block of sub-chunks A and B of the NEXT chunk, fetched into the registers as they free up.
-  auto iteration = [&](auto PAR, int c_load, auto LOAD, int ua_c, int ua_co, int ub_c, int ub_co) {
+  // One 8-channel chunk (V stage P): 8 groups (channel pair g >> 1, accumulator tiles 4 (g & 1) .. +3) of 4 MFMAs.  (cur_c,
+  // cur_co): channel base / output-channel block of THIS chunk - its groups 4..7 are fetched while groups 0..3 run; (nxt_c,
+  // nxt_co): the next chunk, whose groups 0..3 are fetched while groups 4..7 run.
+  auto iteration = [&](auto PAR, int c_load, auto LOAD, int cur_c, int cur_co, int nxt_c, int nxt_co) {
     constexpr int P = decltype(PAR)::value;
-    constexpr bool LD = decltype(LOAD)::value;  // false: patch and U_B reloads are issued by the caller (end of an item)
+    constexpr bool LD = decltype(LOAD)::value;  // false: the patch reloads are issued by the caller (end of an item)
     const float *Vs = P ? Vs1 : Vs0;
     float *Vd = P ? Vs0 : Vs1;
-    // boundary: U stage 0 and this chunk's V stage are complete; nobody reads U stage 1 or the other V stage any more
+    // this chunk's V stage is complete; nobody reads the other stage any more
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     load_begin(c_load);
-    float av[2][4], bv[2][4];
+    float bv[2][4];
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-      const float *Us = sub ? Us1 : Us0;
-      float *Ud = sub ? Us0 : Us1;
-      if (sub == 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // middle: stage 1 complete, stage 0 free
+    for (int i = 0; i < 4; ++i) bv[0][i] = Vs[bbase[0] + i * 32];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        av[0][i] = Us[abase[0] + i * 64];
-        bv[0][i] = Vs[bbase[0] + (2 * (2 * sub) * 16 + i) * 32];
+    for (int g = 0; g < 8; ++g) {
+      const int cur = g & 1, nxt = cur ^ 1;
+      if (g + 1 < 8) {
+        const int cpn = (g + 1) >> 1, hn = (g + 1) & 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bv[nxt][i] = Vs[bbase[hn] + (2 * cpn * 16 + i) * 32];
       }
+      const int x0 = (g & 1) * 4;
 #pragma unroll
-      for (int gg = 0; gg < 4; ++gg) {  // group = (channel pair cpl of the sub-chunk, row set hn)
-        const int g = sub * 4 + gg, cur = gg & 1, nxt = cur ^ 1;
-        if (gg + 1 < 4) {
-          const int cpl = (gg + 1) >> 1, hn = (gg + 1) & 1;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            av[nxt][i] = Us[abase[hn] + (2 * cpl * 16 + i) * 64];
-            bv[nxt][i] = Vs[bbase[hn] + (2 * (2 * sub + cpl) * 16 + i) * 32];
-          }
-        }
-        const int x0 = (gg & 1) * 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) mfma_acc4(acc[x0 + i], av[cur][i], bv[cur][i]);
-        if (g < 4) {
-          transform_col(g);
-          if (LD) load_col(g);
-        } else {
-          commit_v_row(Vd, g - 4);
-        }
-        commit_u(Ud, gg);  // registers -> the stage the NEXT half reads
-        if (sub == 0) load_u(gg, ua_c, ua_co);
-        else if (LD) load_u(gg, ub_c, ub_co);
-        __builtin_amdgcn_sched_barrier(0);  // pin the slice schedule (winograd.hip)
+      for (int i = 0; i < 4; ++i) mfma_acc4(acc[x0 + i], aq[g & 3][i], bv[cur][i]);
+      // half a chunk ahead (a full chunk ahead - 8 quads - measured no faster: 1.66 vs 1.64 ms, and spills in the epilogue)
+      if (g < 4) {
+        load_a(g, cur_c, g + 4, cur_co);
+        transform_col(g);
+        if (LD) load_col(g);
+      } else {
+        load_a(g - 4, nxt_c, g - 4, nxt_co);
+        commit_v_row(Vd, g - 4);
       }
+      __builtin_amdgcn_sched_barrier(0);  // pin the slice schedule (winograd.hip)
     }
   };
   using S0 = std::integral_constant<int, 0>;
@@ -223,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd4_kernel(const Wino4Ar
   // ---- prologue of the first item: U_A(0) on its way, V chunk 0 -> registers -> stage 0, chunk 1 -> registers
   setup(item_first);
 #pragma unroll
-  for (int g = 0; g < 4; ++g) load_u(g, 0, co_blk);
+  for (int g = 0; g < 4; ++g) load_a(g, 0, g, co_blk);
   load_begin(0);
 #pragma unroll
   for (int c = 0; c < 4; ++c) load_col(c);
@@ -231,10 +214,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd4_kernel(const Wino4Ar
   for (int c = 0; c < 4; ++c) transform_col(c);
 #pragma unroll
   for (int r = 0; r < 4; ++r) commit_v_row(Vs0, r);
-#pragma unroll
-  for (int g = 0; g < 4; ++g) commit_u(Us0, g);
-#pragma unroll
-  for (int g = 0; g < 4; ++g) load_u(g, UK, co_blk);
   load_begin(CK);
 #pragma unroll
   for (int c = 0; c < 4; ++c) load_col(c);
@@ -248,20 +227,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd4_kernel(const Wino4Ar
     const int e_img = img, e_ty0 = ty0, e_tx0 = tx0, e_co_blk = co_blk;
 #pragma unroll 1
     for (int c0 = 2 * CK; c0 < a.ci; c0 += 2 * CK) {
-      iteration(S0{}, c0, std::true_type{}, c0 - CK, e_co_blk, c0 - CK + UK, e_co_blk);
-      iteration(S1{}, c0 + CK, std::true_type{}, c0, e_co_blk, c0 + UK, e_co_blk);
+      iteration(S0{}, c0, std::true_type{}, c0 - 2 * CK, e_co_blk, c0 - CK, e_co_blk);
+      iteration(S1{}, c0 + CK, std::true_type{}, c0 - CK, e_co_blk, c0, e_co_blk);
     }
     // last two chunks of this item: their patch loads already belong to the NEXT item (or re-stage this one after the last)
     {
       const int next = item + xcd_wgs;
       setup(next < item_end ? next : item);
     }
-    iteration(S0{}, 0, std::true_type{}, a.ci - CK, e_co_blk, a.ci - CK + UK, e_co_blk);
-    // The last chunk commits chunk 0 of the next item (V and U sub-chunk A) but leaves the staging registers EMPTY (the output
-    // transform needs them); chunk 1's patches and U sub-chunk B(0) are loaded after the exchange, under the stores.
-    iteration(S1{}, CK, std::false_type{}, 0, co_blk, UK, co_blk);
-    // every wave is done with U stage 1 / V stage 1 before they become the exchange area
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    iteration(S0{}, 0, std::true_type{}, a.ci - 2 * CK, e_co_blk, a.ci - CK, e_co_blk);
+    // The last chunk commits V chunk 0 of the next item and fetches its first A operands, but leaves the patch registers EMPTY
+    // (the output transform needs them); chunk 1's patches are loaded after the exchange, under the stores.
+    iteration(S1{}, CK, std::false_type{}, a.ci - CK, e_co_blk, 0, co_blk);
 
     // ---- output transform Y = A^T M A.  Lane (half, j) holds tile j and 16 output channels
     //      co_blk + wm*32 + (r&3) + 8*(r>>2) + 4*half, for rows 2ph, 2ph+1 of M: acc[rr*4 + c][r].
@@ -284,10 +261,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd4_kernel(const Wino4Ar
     // ~1400 scalar branches per workgroup and made this epilogue cost as much as six chunks of the main loop.
     const float slope = d.act == EDVR_ACT_LRELU ? 0.1f : (d.act == EDVR_ACT_RELU ? 0.f : 1.f);  // none/relu/lrelu = max(v, slope*v)
     const bool interior = e_ty0 + 2 * TY <= d.h && e_tx0 + 2 * TX <= d.w && e_co_blk + 64 <= d.co && (d.w & 1) == 0;
-    // exchange through the two buffers that are idle now: U stage 1 (written by the ph = 0 waves) and V stage 1 (ph = 1 waves),
-    // [wm][r][lane][2] = 8 KB per wave; stage 0 of both already holds the next item's first chunk
-    float *xsend = (ph ? Vs1 : Us1) + wm * 2048;
-    const float *xrecv = (ph ? Us1 : Vs1) + wm * 2048;
+    // sibling exchange [wave][r][lane][2] = 8 KB per wave in its own area: the previous item's values were read many barriers ago
+    float *xsend = Xs + wave * 2048;
+    const float *xrecv = Xs + (wave ^ 2) * 2048;
     // ---- common to all epilogue variants (kept OUT of the specialised lambdas: hoisted above their dispatch by the
     //      compiler, the sums were spilled to scratch across the multi-way branch, ~70 scratch accesses per item)
     // Row pass (M A)[row][.] = (m0 + m1 + m2, m1 - m2 - m3) of the row to send (tiles 0-3), one accumulator tile at a
@@ -299,8 +275,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd4_kernel(const Wino4Ar
     load_begin(CK);
 #pragma unroll
     for (int c = 0; c < 4; ++c) load_col(c);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) load_u(g, UK, co_blk);
 #else
     // bias now, residuals right after the row pass (when the accumulators are dead): their latency hides behind the
     // transform and the exchange instead of being exposed once per batch of stores
@@ -385,15 +359,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd4_kernel(const Wino4Ar
 #endif
     }
     __builtin_amdgcn_sched_barrier(0);
-    // second barrier: pair 1 is overwritten by the first iteration of the next item
-#ifndef WINO_EXP_NOXCHG
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
     load_begin(CK);  // chunk 1 of the next item (geometry already switched)
 #pragma unroll
     for (int c = 0; c < 4; ++c) load_col(c);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) load_u(g, UK, co_blk);
     auto emit = [&](auto HAS_RES, auto SHUFFLE, auto SIGMOID, auto INTERIOR) {
       constexpr int RES = decltype(HAS_RES)::value;  // 0: none, 1: add residual(s), 2: gate
       constexpr bool SHF = decltype(SHUFFLE)::value, SIG = decltype(SIGMOID)::value, INT = decltype(INTERIOR)::value;
