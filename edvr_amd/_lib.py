@@ -22,6 +22,7 @@ class ConvDesc(ctypes.Structure):
         ('bias', vp), ('co', i32), ('ks', i32), ('stride', i32), ('act', i32), ('act_from', i32), ('res1', vp),
         ('res2', vp), ('res1_img_stride', i64), ('res2_img_stride', i64), ('y', vp), ('y_img_stride', i64),
         ('out_mode', i32), ('algo', i32), ('gate', vp), ('gate_img_stride', i64), ('gate_slope', f32), ('y_scale', f32),
+        ('wpk_f4', vp),
     ]
 
 
@@ -32,6 +33,8 @@ PROTOTYPES = {
     'edvr_check_device': (i32, []),
     'edvr_conv2d_packed_weight_elems': (sz, [i32, i32, i32]),
     'edvr_conv2d_pack_weight_f32': (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    'edvr_conv2d_packed_weight_f4_elems': (sz, [i32, i32]),
+    'edvr_conv2d_pack_weight_f4_f32': (i32, [vp, vp, i32, i32, i32, vp]),
     'edvr_conv2d_f32': (i32, [ctypes.POINTER(ConvDesc), vp]),
     'edvr_conv2d_gate_supported': (i32, [ctypes.POINTER(ConvDesc)]),
     'edvr_conv2d_kernel_name': (i32, [ctypes.POINTER(ConvDesc), ctypes.c_char_p, sz]),
@@ -74,7 +77,7 @@ PROTOTYPES = {
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
 OUT_NCHW, OUT_PIXEL_SHUFFLE2 = 0, 1
-CONV_AUTO, CONV_DIRECT, CONV_WINOGRAD = 0, 1, 2
+CONV_AUTO, CONV_DIRECT, CONV_WINOGRAD, CONV_WINOGRAD_F4 = 0, 1, 2, 3
 
 _lib = None
 

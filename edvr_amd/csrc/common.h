@@ -50,6 +50,10 @@ bool winograd4_enabled();  // EDVR_WINOGRAD_4WAVE=1: the weights are then packed
 bool winograd4_supported(const edvr_conv2d_desc &d);
 int winograd4_launch(const edvr_conv2d_desc &d, const float *U, int cop64, hipStream_t stream);
 
+// winograd_f4.hip: F(4x4,3x3), wave-specialised workgroups; needs edvr_conv2d_desc.wpk_f4 (inference path)
+bool winograd_f4_eligible(const edvr_conv2d_desc &d);
+int winograd_f4_launch(const edvr_conv2d_desc &d, hipStream_t stream);
+
 // conv_small.hip: 3x3 / stride-1 conv with <= 4 output channels on the vector ALUs (EDVR's conv_last)
 bool conv_small_eligible(const edvr_conv2d_desc &d);
 int conv_small_launch(const edvr_conv2d_desc &d, hipStream_t stream);

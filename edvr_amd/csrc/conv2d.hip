@@ -373,6 +373,7 @@ int conv2d_launch(const edvr_conv2d_desc &d, hipStream_t stream) {
     return EDVR_ERR_UNSUPPORTED;
   }
   if (!d.gate && !scaled && conv_small_eligible(d)) return conv_small_launch(d, stream);
+  if (winograd_f4_eligible(d)) return winograd_f4_launch(d, stream);
   if (winograd_eligible(d)) {
     const float *U = d.wpk + direct_packed_elems(d.co, a.ci, 3);
     return winograd4_supported(d) ? winograd4_launch(d, U, round_up(d.co, 64), stream) : winograd_launch(d, U, round_up(d.co, 64), stream);
@@ -412,6 +413,10 @@ int edvr_conv2d_kernel_name(const edvr_conv2d_desc *d, char *buf, size_t buf_len
   const int ho = (d->h + 2 * pad - d->ks) / d->stride + 1, wo = (d->w + 2 * pad - d->ks) / d->stride + 1;
   if (edvr::conv_small_eligible(*d)) {
     snprintf(buf, buf_len, "conv3x3_smallco_kernel");
+    return EDVR_OK;
+  }
+  if (edvr::winograd_f4_eligible(*d)) {
+    snprintf(buf, buf_len, "conv3x3_winograd_f4_kernel");
     return EDVR_OK;
   }
   if (edvr::winograd_eligible(*d)) {

@@ -1,0 +1,559 @@
+// winograd_f4.hip - 3x3 / stride-1 convolution as Winograd F(4x4, 3x3) on the fp32 matrix cores (gfx950), inference path.
+//
+// F(2x2,3x3) (winograd.hip) issues 16 multiplies per 2x2 outputs and channel pair = 4 per output; F(4x4,3x3) issues 36 per 4x4
+// = 2.25 per output: 1.78x fewer MFMAs again.  The price is arithmetic error - the transform matrices hold 4, 5, 8 where
+// F(2x2) has 1 - measured 1.4e-6 of the output scale at 128 input channels in fp32 (F(2x2): 2e-7), far inside the 1e-3 dB
+// PSNR bound the path is specified with.  Training keeps F(2x2): its gradient tests are pinned at 1e-5.
+//
+//   V = B^T d B      6x6 input patches (stride 4), transformed in registers by the PRODUCER waves, -> LDS
+//   M[xi] = sum_ci U[xi][co, ci] * V[xi][ci, tile]      36 GEMMs on v_mfma_f32_32x32x2_f32, CONSUMER waves
+//   Y = A^T M A      row pass (6 -> 4) in the consumers' registers, column pass by the producers after an LDS exchange
+//   U = G g G^T      packed once per weight version in MFMA operand order (winograd_f4_pack)
+//
+// Work split: wave-specialised 1024-thread workgroups, one per CU, persistent over items of 64 output channels x 32 tiles
+// (2 x 16 tiles = 8 x 64 output pixels):
+//   * 12 consumer waves = (32-channel half wm, transform row r): 6 accumulator tiles (32 co x 32 tiles, positions (r, 0..5)) =
+//     96 registers, three per SIMD.  Their loop is ds_read (B operand, shared by the two wm waves) + MFMA only; the A operands
+//     (U) belong to exactly one wave each, so they come straight from global memory - one 16-byte and one 8-byte buffer load per
+//     six MFMAs, packed so that a wave reads 1.5 KB contiguous - two k-steps ahead.  No staging stall ever sits on a wave that
+//     issues MFMAs.
+//   * 4 producer waves (one per SIMD): thread = (channel of the 8-channel chunk, tile) loads its 6x6 patch through a rotating
+//     register set (chunk k + 2 is requested as soon as the registers of chunk k + 1 are transformed), applies B^T . B and
+//     writes the 36 positions to the double-buffered V slab (2 x 36 KB).  They also own everything that touches the output:
+//     after the consumers' row pass (T = M A, written to a double-buffered 2 x 24 KB exchange area in eight 8-channel phases)
+//     they finish Y = A^T T, apply bias / activation / residuals / gate / PixelShuffle and store 16-byte rows.
+//   One barrier per chunk (LDS only) + 8 per item.
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+
+namespace edvr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct WinoF4Args {
+  edvr_conv2d_desc d;
+  const float *U;  // [co block 64][channel pair][row 6][co half 2][lane 64 x 4 | lane 64 x 2]
+  int ci, ci_real, cop, tiles_x, tiles_y, items;  // ci: rounded up to 8 (U has all-zero rows there), ci_real = c1 + c2
+  float ys, ys_gs;                                // y_scale (0 -> 1) and y_scale * gate_slope
+};
+
+#ifdef F4_EXP_NOEPI /* ablation: no output transform / stores */
+#define F4_EPI_PHASES 0
+#else
+#define F4_EPI_PHASES 8
+#endif
+#define F4_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+template <bool PAIR>
+__global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const WinoF4Args a) {
+  constexpr int CK = 8;
+  constexpr int VSLAB = CK * 36 * 32;   // floats per V stage (36 KB): [channel 8][position 36][tile 32]
+  constexpr int XSZ = 2 * 6 * 8 * 32 * 4;  // exchange area (2 x 24 KB): [phase parity][row 6][channel 8][tile 32][4]
+  __shared__ __attribute__((aligned(16))) float smem[2 * VSLAB + XSZ];
+  float *const Xs = smem + 2 * VSLAB;
+
+  const edvr_conv2d_desc &d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, j = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hw = d.h * d.w, plane_bytes = hw * 4;
+  const int co_blocks = (d.co + 63) / 64;
+  const int n_chunks = a.ci / CK;
+  constexpr int RSRC_FLAGS = 0x00020000;  // raw buffer, 32-bit data format (gfx9 family)
+  auto uniform_rsrc = [&](const float *p, int bytes) {
+    const uint64_t pv = reinterpret_cast<uint64_t>(p);
+    const uint64_t pu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pv >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pv);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(pu), (short)0, bytes, RSRC_FLAGS);
+  };
+
+  // Persistent workgroups, XCD-aware walk (winograd.hip): every XCD gets one contiguous range of items.
+  const int n_xcd = gridDim.x < 8 ? 1 : 8;
+  const int xcd = n_xcd == 1 ? 0 : (int)blockIdx.x % 8, xcd_rank = n_xcd == 1 ? (int)blockIdx.x : (int)blockIdx.x / 8;
+  const int xcd_wgs = n_xcd == 1 ? (int)gridDim.x : ((int)gridDim.x - xcd + 7) / 8;
+  const int span = (a.items + n_xcd - 1) / n_xcd;
+  const int item_end = min(a.items, (xcd + 1) * span);
+  const int item_first = xcd * span + xcd_rank;
+  if (item_first >= item_end) return;
+  auto decode = [&](int item, int &co_blk, int &img, int &ty0, int &tx0) {
+    co_blk = __builtin_amdgcn_readfirstlane((item % co_blocks) * 64);
+    const int tile_blk = __builtin_amdgcn_readfirstlane((item / co_blocks) % (a.tiles_x * a.tiles_y));
+    img = __builtin_amdgcn_readfirstlane(item / (co_blocks * a.tiles_x * a.tiles_y));
+    ty0 = __builtin_amdgcn_readfirstlane((tile_blk / a.tiles_x) * 8);  // output-pixel origin of the 8 x 64 block
+    tx0 = __builtin_amdgcn_readfirstlane((tile_blk % a.tiles_x) * 64);
+  };
+
+  if (wave < 4) {
+    // =========================================================================================== producers
+#ifdef F4_EXP_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    const int p_ty = j >> 4, p_tx = j & 15;  // tile j of the 2 x 16; channel 2 wave + half of the chunk
+    constexpr int NCG = PAIR ? 4 : 6;        // column groups: {0, (1, 2), (3, 4), 5} or six single columns
+    constexpr int OOB = 0x40000000;          // >= num_records (two planes < 2^29 bytes, winograd_f4_supported) alone or summed
+    int rowoff[6], coloff[NCG];
+    const float *x1 = d.x1, *x2 = d.x1;
+    int l_item = item_first, l_k = 0;  // load cursor: (item, chunk) the NEXT patch loads belong to
+    auto setup = [&](int item) {
+      int cb, img, ty0, tx0;
+      decode(item, cb, img, ty0, tx0);
+#ifdef F4_EXP_L2HOT /* ablation: every item reads the first block of image 0 (cache-resident) */
+      img = 0, ty0 = 0, tx0 = 0;
+#endif
+      x1 = d.x1 + (int64_t)img * d.x1_img_stride;
+      x2 = x1;
+      if (d.x2) {
+        const int i2 = d.x2_div > 0 ? (img / d.x2_div) * d.x2_mul + d.x2_add : img;
+        x2 = d.x2 + (int64_t)i2 * d.x2_img_stride;
+      }
+      const int gy0 = ty0 + 4 * p_ty - 1, gx0 = tx0 + 4 * p_tx - 1;  // top-left of the 6x6 patch (pad 1)
+#pragma unroll
+      for (int r = 0; r < 6; ++r) rowoff[r] = (gy0 + r >= 0 && gy0 + r < d.h) ? ((gy0 + r) * d.w + gx0) * 4 + half * plane_bytes : OOB;
+#pragma unroll
+      for (int g = 0; g < NCG; ++g) {
+        const int c = PAIR ? (g == 0 ? 0 : 2 * g - 1) : g;  // first column of the group; an aligned pair is valid or padded together
+        coloff[g] = (gx0 + c >= 0 && gx0 + c < d.w) ? c * 4 : OOB;
+      }
+    };
+    __amdgpu_buffer_rsrc_t ld_rsrc = uniform_rsrc(d.x1, 0);
+    auto load_begin = [&](int c0) {
+      const int c = c0 + 2 * wave;  // even; c1 is even when there is an x2 (host check): the pair never straddles x1 / x2
+      const float *pl = (c < d.c1) ? (x1 + (int64_t)c * hw) : (x2 + (int64_t)(c - d.c1) * hw);
+      const int nvalid = a.ci_real - c;  // channels of the padding: empty (or one-plane) buffer, their loads return 0
+      ld_rsrc = uniform_rsrc(pl, nvalid >= 2 ? 2 * plane_bytes : (nvalid == 1 ? plane_bytes : 0));
+    };
+    float pr[36];  // raw patch [r][c]
+    float tt[36];  // B^T d
+    auto load_col = [&](int c) {  // reload column c of the patch registers (all six rows)
+      if (PAIR && (c == 1 || c == 3)) return;  // second halves are loaded with columns 2 / 4, once both are consumed
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        if (PAIR && (c == 2 || c == 4)) {
+          const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(ld_rsrc, rowoff[r] + coloff[c / 2], 0, 0));
+          pr[r * 6 + c - 1] = v[0];
+          pr[r * 6 + c] = v[1];
+        } else {
+          const int g = PAIR ? (c == 0 ? 0 : 3) : c;
+          pr[r * 6 + c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ld_rsrc, rowoff[r] + coloff[g], 0, 0));
+        }
+      }
+    };
+    // 1-D input transform B^T (Lavin & Gray): 12 operations
+#define F4_BT(d0, d1, d2, d3, d4, d5, t0, t1, t2, t3, t4, t5)   \
+  {                                                             \
+    const float p_ = __builtin_fmaf(-4.f, d2, d4), q_ = __builtin_fmaf(-4.f, d1, d3); \
+    const float r_ = d4 - d2, s_ = d3 - d1;                     \
+    t0 = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4)); \
+    t1 = p_ + q_;                                               \
+    t2 = p_ - q_;                                               \
+    t3 = __builtin_fmaf(2.f, s_, r_);                           \
+    t4 = __builtin_fmaf(-2.f, s_, r_);                          \
+    t5 = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5)); \
+  }
+    auto transform_col = [&](int c) {
+      F4_BT(pr[0 * 6 + c], pr[1 * 6 + c], pr[2 * 6 + c], pr[3 * 6 + c], pr[4 * 6 + c], pr[5 * 6 + c], tt[0 * 6 + c], tt[1 * 6 + c],
+            tt[2 * 6 + c], tt[3 * 6 + c], tt[4 * 6 + c], tt[5 * 6 + c]);
+    };
+    auto commit_row = [&](float *Vd, int r) {  // positions (r, 0..5) of (B^T d) B
+      float o0, o1, o2, o3, o4, o5;
+      F4_BT(tt[r * 6 + 0], tt[r * 6 + 1], tt[r * 6 + 2], tt[r * 6 + 3], tt[r * 6 + 4], tt[r * 6 + 5], o0, o1, o2, o3, o4, o5);
+      float *dst = Vd + ((2 * wave + half) * 36 + r * 6) * 32 + j;
+      dst[0 * 32] = o0;
+      dst[1 * 32] = o1;
+      dst[2 * 32] = o2;
+      dst[3 * 32] = o3;
+      dst[4 * 32] = o4;
+      dst[5 * 32] = o5;
+    };
+#undef F4_BT
+    auto advance = [&]() {  // the load cursor moves one chunk; at an item boundary the geometry switches
+      if (++l_k == n_chunks) {
+        l_k = 0;
+        const int nx = l_item + xcd_wgs;
+        l_item = nx < item_end ? nx : l_item;  // past the last item: re-stage it (never consumed)
+        setup(l_item);
+      }
+    };
+
+    // ---- prologue: chunk 0 -> registers -> stage 0, chunk 1 -> registers
+    setup(item_first);
+    load_begin(0);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) load_col(c);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) transform_col(c);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) commit_row(smem, r);
+    advance();
+    load_begin(l_k * CK);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) load_col(c);
+    F4_LDS_BARRIER();
+
+    int par = 0;  // stage the consumers read during the current step
+    for (int item = item_first; item < item_end; item += xcd_wgs) {
+      int e_co_blk, e_img, e_ty0, e_tx0;
+      decode(item, e_co_blk, e_img, e_ty0, e_tx0);
+#pragma unroll 1
+      for (int k = 0; k < n_chunks; ++k) {
+        // the registers hold chunk k + 1 (chunk 0 of the next item at the end): transform into the idle stage, reload with k + 2
+        advance();
+        load_begin(l_k * CK);
+        float *Vd = smem + (par ^ 1) * VSLAB;
+#ifndef F4_EXP_NOPROD  /* ablation: the producers only keep the barrier count */
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {  // (pinned: a column's reload goes out as soon as the column is consumed)
+          transform_col(c);
+#ifndef F4_EXP_NOLOAD
+          load_col(c);
+#endif
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) commit_row(Vd, r);
+#endif
+        F4_LDS_BARRIER();
+        par ^= 1;
+      }
+
+      // ---- column pass Y = A^T T + epilogue + stores: 8 phases of 8 output channels, one (channel, tile) per thread and phase.
+      //      The exchange area is double-buffered: the consumers write phase p + 1 while phase p is read here (one barrier per
+      //      phase).  Bias and residual / gate rows of phase p + 1 are requested as soon as those of phase p are consumed.
+      const int plane = hw;
+      float *y = d.y + (int64_t)e_img * d.y_img_stride;
+      const float *r1 = d.res1 ? d.res1 + (int64_t)e_img * d.res1_img_stride : nullptr;
+      const float *r2 = d.res2 ? d.res2 + (int64_t)e_img * d.res2_img_stride : nullptr;
+      const float *gt = d.gate ? d.gate + (int64_t)e_img * d.gate_img_stride : nullptr;
+      const float *rq = gt ? gt : r1;  // the tensor read per output element (gate and residuals exclude each other)
+      const float slope = d.act == EDVR_ACT_LRELU ? 0.1f : (d.act == EDVR_ACT_RELU ? 0.f : 1.f);  // none/relu/lrelu = max(v, slope*v)
+      const bool sig = d.act == EDVR_ACT_SIGMOID, shuffle = d.out_mode == EDVR_OUT_PIXEL_SHUFFLE2;
+      const bool vec = !shuffle && (d.w & 3) == 0 && e_ty0 + 8 <= d.h && e_tx0 + 64 <= d.w;  // whole 16-byte rows inside the image
+      const int cl8 = tid >> 5, tile = tid & 31;
+      const int oy = e_ty0 + 4 * (tile >> 4), ox = e_tx0 + 4 * (tile & 15);
+      const int co_t = e_co_blk + (cl8 >> 2) * 32 + 4 * ((cl8 >> 1) & 1) + (cl8 & 1);  // + 8 (p >> 1) + 2 (p & 1) in phase p
+      const int pix = oy * d.w + ox;
+      auto column_pass = [&](auto VEC) {
+        constexpr bool V = decltype(VEC)::value;  // whole 16-byte rows inside the image, NCHW: no per-element tests
+        f32x4 rr[4];
+        float b_next = 0.f;
+        auto co_of = [&](int p) { return co_t + 8 * (p >> 1) + 2 * (p & 1); };
+        auto prefetch = [&](int p) {  // bias and (V) rows oy .. oy + 3 of the residual(s) / gate of channel co_of(p)
+          const int co = min(co_of(p), d.co - 1);
+          b_next = d.bias ? d.bias[co] : 0.f;
+          if (V && rq) {
+            const float *q1 = rq + (int64_t)co * plane + pix;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rr[i] = *reinterpret_cast<const f32x4 *>(q1 + i * d.w);
+            if (r2) {
+              const float *q2 = r2 + (int64_t)co * plane + pix;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) rr[i] += *reinterpret_cast<const f32x4 *>(q2 + i * d.w);
+            }
+          }
+        };
+        prefetch(0);
+#pragma unroll 1
+        for (int p = 0; p < (F4_EPI_PHASES); ++p) {
+          F4_LDS_BARRIER();  // T of this phase is in its half of the exchange area
+          const float *Xb = Xs + (p & 1) * (XSZ / 2) + (cl8 * 32 + tile) * 4;
+          f32x4 T[6];
+#pragma unroll
+          for (int r = 0; r < 6; ++r) T[r] = *reinterpret_cast<const f32x4 *>(Xb + r * (8 * 32 * 4));
+          const int co = co_of(p);
+          const float b = b_next;
+          const float sl = co >= d.act_from ? slope : 1.f;
+          f32x4 Y[4];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {  // A^T along the rows (6 -> 4), + bias
+            const float s1 = T[1][jj] + T[2][jj], d1 = T[1][jj] - T[2][jj], s2 = T[3][jj] + T[4][jj], d2 = T[3][jj] - T[4][jj];
+            Y[0][jj] = T[0][jj] + s1 + s2 + b;
+            Y[1][jj] = __builtin_fmaf(2.f, d2, d1) + b;
+            Y[2][jj] = __builtin_fmaf(4.f, s2, s1) + b;
+            Y[3][jj] = __builtin_fmaf(8.f, d2, d1) + T[5][jj] + b;
+          }
+          if (sig) {
+            if (co >= d.act_from) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) Y[i][jj] = __builtin_amdgcn_rcpf(1.f + __expf(-Y[i][jj]));
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) Y[i][jj] = fmaxf(Y[i][jj], sl * Y[i][jj]);
+          }
+          if (V) {
+            if (gt) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) Y[i][jj] *= rr[i][jj] > 0.f ? a.ys : a.ys_gs;
+            } else if (r1) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) Y[i][jj] = __builtin_fmaf(Y[i][jj], a.ys, rr[i][jj]);
+            }
+            if (co < d.co) {
+              float *q = y + (int64_t)co * plane + pix;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(q + i * d.w) = Y[i];
+            }
+          } else if (co < d.co) {
+#pragma unroll 1
+            for (int i = 0; i < 4; ++i) {
+              if (oy + i >= d.h) break;
+              const int64_t off = (int64_t)co * plane + pix + i * d.w;
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) {
+                if (ox + jj < d.w) {
+                  float o = Y[i][jj];
+                  if (gt) o *= gt[off + jj] > 0.f ? a.ys : a.ys_gs;
+                  else if (r1) o = __builtin_fmaf(o, a.ys, r1[off + jj] + (r2 ? r2[off + jj] : 0.f));
+                  if (shuffle)
+                    y[(int64_t)(co >> 2) * plane * 4 + (2 * (oy + i) + ((co >> 1) & 1)) * (2 * d.w) + 2 * (ox + jj) + (co & 1)] = o;
+                  else
+                    y[off + jj] = o;
+                }
+              }
+            }
+          }
+          prefetch(min(p + 1, 7));  // consumed one phase later
+        }
+      };
+      if (vec) column_pass(std::true_type{});
+      else column_pass(std::false_type{});
+    }
+  } else {
+    // =========================================================================================== consumers
+    const int q = wave - 4, wm = q & 1, row = q >> 1;
+    const int np = a.ci >> 1;
+    const __amdgpu_buffer_rsrc_t u_rsrc = uniform_rsrc(a.U, a.cop * a.ci * 36 * 4);
+    const int voff4 = lane * 16, voff2 = 1024 + lane * 8;
+    f32x16 acc[6];
+    f32x4 a4[2];
+    f32x2 a2[2];
+    const int n_steps = 4 * n_chunks;  // k-steps (channel pairs) of an item
+    int u_base = 0;  // byte offset of (co block, channel pair 0, row, wm); a k-step further on is 12 blocks of 1536 bytes
+    auto set_item = [&](int co_blk) { u_base = (((co_blk >> 6) * np * 6 + row) * 2 + wm) * 1536; };
+    auto load_a = [&](int set, int t) {  // A operands of k-step t (channel pair t): positions (row, 0..3) and (row, 4..5)
+      const int soff = u_base + t * (12 * 1536);
+      a4[set] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, voff4, soff, 0));
+      a2[set] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(u_rsrc, voff2, soff, 0));
+    };
+    int co_blk, img_, ty_, tx_;
+    decode(item_first, co_blk, img_, ty_, tx_);
+    set_item(co_blk);
+    load_a(0, 0);
+    load_a(1, 1);
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    F4_LDS_BARRIER();
+
+    int par = 0;
+    const int b_lane = half * 36 * 32 + row * 6 * 32 + j;  // B operand: channel 2 cp + half, position (row, c), tile j
+    for (int item = item_first; item < item_end; item += xcd_wgs) {
+#pragma unroll 1
+      for (int k = 0; k < n_chunks; ++k) {
+        const float *Vs = smem + par * VSLAB + b_lane;
+        // 8 groups of 3 MFMAs (k-step cp = channel pair, positions (row, 0..2) / (row, 3..5)); the B operands of group g + 1 are
+        // fetched before the MFMAs of group g, the A registers of a k-step are re-requested (two k-steps ahead) right after
+        // its last MFMA.  The schedule is pinned: left free, hipcc sinks every load to just before its first use.
+        float bv[2][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) bv[0][c] = Vs[c * 32];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+          const int cp = g >> 1, hi = g & 1, set = cp & 1, cur = g & 1, nxt = cur ^ 1;
+          if (g + 1 < 8) {
+            const int cpn = (g + 1) >> 1, hn = (g + 1) & 1;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) bv[nxt][c] = Vs[(2 * cpn * 36 + 3 * hn + c) * 32];
+          }
+#ifdef F4_EXP_NOMFMA  /* ablation: operands fetched, no MFMA */
+          asm volatile("" ::"v"(bv[cur][0]), "v"(bv[cur][1]), "v"(bv[cur][2]), "v"(a4[set]), "v"(a2[set]));
+          if (hi) load_a(set, min(4 * k + cp + 2, n_steps - 1));
+          __builtin_amdgcn_sched_barrier(0);
+          continue;
+#endif
+          if (!hi) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[set][c], bv[cur][c], acc[c], 0, 0, 0);
+          } else {
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[set][3], bv[cur][0], acc[3], 0, 0, 0);
+            acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[set][0], bv[cur][1], acc[4], 0, 0, 0);
+            acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[set][1], bv[cur][2], acc[5], 0, 0, 0);
+            load_a(set, min(4 * k + cp + 2, n_steps - 1));  // past the end of the item: a redundant reload of its last k-step
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        F4_LDS_BARRIER();
+        par ^= 1;
+      }
+      {  // A operands of the next item's first two k-steps: in flight during the row pass
+        const int nx = item + xcd_wgs;
+        decode(nx < item_end ? nx : item, co_blk, img_, ty_, tx_);
+        set_item(co_blk);
+        load_a(0, 0);
+        load_a(1, 1);
+      }
+#ifdef F4_EXP_NOEPI
+#pragma unroll
+      for (int c = 0; c < 6; ++c) asm volatile("" ::"v"(acc[c]));  // keep the MFMAs alive
+#endif
+      // ---- row pass T = M A (6 -> 4) and hand-over to the producers: 8 phases of two accumulator registers (8 output channels
+      //      over the two channel halves), alternating halves of the exchange area
+#pragma unroll
+      for (int p = 0; p < (F4_EPI_PHASES); ++p) {
+        float *Xb = Xs + (p & 1) * (XSZ / 2);
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          const int r = 2 * p + rr;
+          const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r], m5 = acc[5][r];
+          const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+          f32x4 T;
+          T[0] = m0 + s1 + s2;
+          T[1] = __builtin_fmaf(2.f, d2, d1);
+          T[2] = __builtin_fmaf(4.f, s2, s1);
+          T[3] = __builtin_fmaf(8.f, d2, d1) + m5;
+          const int cl8 = wm * 4 + half * 2 + rr;
+          *reinterpret_cast<f32x4 *>(Xb + ((row * 8 + cl8) * 32 + j) * 4) = T;
+        }
+        F4_LDS_BARRIER();  // phase p written (and phase p - 1 read: its half may be overwritten next)
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    }
+  }
+}
+
+// U[xi] = (G g G^T)[xi] of the 3x3 kernel g = w[co][ci] (data-gradient kernel when transpose_flip) in the operand order above.
+__global__ void winograd_f4_weight_kernel(const float *__restrict__ w, float *__restrict__ U, int co, int ci, int cop, int cip,
+                                          int transpose_flip) {
+  const int64_t total = (int64_t)cip * cop;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int o = (int)(i % cop), c = (int)(i / cop);
+    float g[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float v = 0.f;
+      if (o < co && c < ci) v = transpose_flip ? w[((int64_t)c * co + o) * 9 + (8 - t)] : w[((int64_t)o * ci + c) * 9 + t];
+      g[t] = v;
+    }
+    // rows of G: (1/4, 0, 0), (-1/6, -1/6, -1/6), (-1/6, 1/6, -1/6), (1/24, 1/12, 1/6), (1/24, -1/12, 1/6), (0, 0, 1)
+    auto G6 = [](float g0, float g1, float g2, float *o6) {
+      const float e = (g0 + g2) * (-1.f / 6.f), f = g1 * (-1.f / 6.f);
+      const float p = g0 * (1.f / 24.f) + g2 * (1.f / 6.f), q2 = g1 * (1.f / 12.f);
+      o6[0] = g0 * 0.25f;
+      o6[1] = e + f;
+      o6[2] = e - f;
+      o6[3] = p + q2;
+      o6[4] = p - q2;
+      o6[5] = g2;
+    };
+    float tmp[6][3];  // G g
+#pragma unroll
+    for (int jx = 0; jx < 3; ++jx) {
+      float col[6];
+      G6(g[0 * 3 + jx], g[1 * 3 + jx], g[2 * 3 + jx], col);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) tmp[r][jx] = col[r];
+    }
+    const int64_t blk0 = ((int64_t)(o >> 6) * (cip >> 1) + (c >> 1)) * 12 + ((o >> 5) & 1);
+    const int ln = (c & 1) * 32 + (o & 31);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {  // (G g) G^T
+      float u[6];
+      G6(tmp[r][0], tmp[r][1], tmp[r][2], u);
+      float *blk = U + (blk0 + 2 * r) * 384;
+      *reinterpret_cast<f32x4 *>(blk + ln * 4) = f32x4{u[0], u[1], u[2], u[3]};
+      *reinterpret_cast<f32x2 *>(blk + 256 + ln * 2) = f32x2{u[4], u[5]};
+    }
+  }
+}
+
+bool winograd_f4_enabled() {
+  static const bool on = []() {
+    const char *e = getenv("EDVR_WINOGRAD_F4");  // "0": never (F(2x2) / direct everywhere)
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
+// The kernel itself: any 3x3 / stride-1 conv whose epilogue the F(2x2) kernel also takes, with a packed-F4 weight buffer.
+bool winograd_f4_supported(const edvr_conv2d_desc &d) {
+  if (!d.wpk_f4 || d.ks != 3 || d.stride != 1) return false;
+  const bool has_res = d.res1 || d.res2;
+  if (d.gate && (has_res || d.act == EDVR_ACT_SIGMOID || d.out_mode != EDVR_OUT_NCHW)) return false;
+  if ((d.res2 && !d.res1) || (d.out_mode != EDVR_OUT_NCHW && has_res)) return false;
+  if (d.y_scale != 0.f && d.y_scale != 1.f && !d.res1 && !d.gate) return false;  // the scale lives in the residual / gate epilogues
+  if (d.c2 > 0 && (d.c1 & 1)) return false;                                      // a staging wave covers two consecutive channels
+  if ((int64_t)d.h * d.w * 8 >= ((int64_t)1 << 29)) return false;                // two planes + the out-of-range sentinel in 32 bits
+  if ((d.w & 1) || ((int64_t)d.h * d.w & 1)) return false;                       // aligned column pairs (PAIR) only, for now
+  auto aligned = [](const float *p, int64_t img_stride, int a) { return !p || ((reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0 && (img_stride * 4 & (a - 1)) == 0); };
+  if (!aligned(d.x1, d.x1_img_stride, 8) || !aligned(d.x2, d.x2_img_stride, 8)) return false;
+  if (!aligned(d.y, d.y_img_stride, 16) || !aligned(d.res1, d.res1_img_stride, 16) || !aligned(d.res2, d.res2_img_stride, 16) ||
+      !aligned(d.gate, d.gate_img_stride, 16))
+    return false;
+  return true;
+}
+
+bool winograd_f4_eligible(const edvr_conv2d_desc &d) {
+  if (!winograd_f4_supported(d)) return false;
+  if (d.algo == EDVR_CONV_WINOGRAD_F4) return true;  // explicit request: any size the kernel can do
+  if (d.algo != EDVR_CONV_AUTO || !winograd_f4_enabled()) return false;
+  return d.co >= 48 && d.c1 + d.c2 >= 32 && d.w >= 48 && d.h >= 8;  // auto: only where it beats F(2x2)
+}
+
+int winograd_f4_launch(const edvr_conv2d_desc &d, hipStream_t stream) {
+  WinoF4Args a;
+  a.d = d;
+  a.U = d.wpk_f4;
+  a.ci_real = d.c1 + d.c2;
+  a.ci = (a.ci_real + 7) / 8 * 8;
+  a.cop = (d.co + 63) / 64 * 64;
+  a.ys = d.y_scale == 0.f ? 1.f : d.y_scale;
+  a.ys_gs = a.ys * d.gate_slope;
+  a.tiles_x = cdiv(d.w, 64);
+  a.tiles_y = cdiv(d.h, 8);
+  a.items = a.tiles_x * a.tiles_y * cdiv(d.co, 64) * d.n;
+  static const int n_cu = []() {
+    int dev = 0, n = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    return n;
+  }();
+  const dim3 grid(std::min(a.items, n_cu));
+  hipLaunchKernelGGL((conv3x3_winograd_f4_kernel<true>), grid, dim3(1024), 0, stream, a);
+  return check_launch("conv3x3_winograd_f4_kernel");
+}
+
+int winograd_f4_pack(const float *w, float *U, int co, int ci, int transpose_flip, hipStream_t stream) {
+  const int cop = (co + 63) / 64 * 64, cip = (ci + 7) / 8 * 8;
+  const int64_t total = (int64_t)cip * cop;
+  hipLaunchKernelGGL(winograd_f4_weight_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 4096)), dim3(256), 0, stream, w, U, co, ci,
+                     cop, cip, transpose_flip);
+  return check_launch("winograd_f4_weight_kernel");
+}
+
+}  // namespace edvr
+
+extern "C" {
+
+size_t edvr_conv2d_packed_weight_f4_elems(int co, int ci) { return (size_t)((co + 63) / 64 * 64) * ((ci + 7) / 8 * 8) * 36; }
+
+int edvr_conv2d_pack_weight_f4_f32(const float *w, float *wpk_f4, int co, int ci, int transpose_flip, edvr_stream_t stream) {
+  EDVR_REQUIRE(w && wpk_f4 && co > 0 && ci > 0, "pack_weight_f4: bad arguments");
+  return edvr::winograd_f4_pack(w, wpk_f4, co, ci, transpose_flip, edvr::as_stream(stream));
+}
+
+}  // extern "C"

@@ -10,7 +10,7 @@ import weakref
 import torch
 
 from . import _lib
-from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, CONV_AUTO, CONV_DIRECT, CONV_WINOGRAD, OUT_NCHW,  # noqa: F401
+from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, CONV_AUTO, CONV_DIRECT, CONV_WINOGRAD, CONV_WINOGRAD_F4, OUT_NCHW,  # noqa: F401
                    OUT_PIXEL_SHUFFLE2)
 
 
@@ -80,10 +80,11 @@ def workspace(nbytes, device):
 _PACKED = {}  # id(parameter) -> (weakref, {transpose_flip: (version, packed, data_ptr)})
 
 
-def pack_conv_weight(weight, transpose_flip=False):
-    """(co, ci, k, k) parameter -> MFMA-friendly [ci_pad][k*k][co_pad] array, cached per parameter version."""
+def pack_conv_weight(weight, transpose_flip=False, f4=False):
+    """(co, ci, k, k) parameter -> MFMA-friendly [ci_pad][k*k][co_pad] array, cached per parameter version.
+    f4: the F(4x4,3x3) Winograd weights of a 3x3 kernel instead (conv2d's `wpk_f4`), a separate buffer with its own cache slot."""
     require_gpu(weight)
-    key, wid, ver = bool(transpose_flip), id(weight), weight._version
+    key, wid, ver = (bool(transpose_flip), bool(f4)), id(weight), weight._version
     ent = _PACKED.get(wid)
     if ent is not None and ent[0]() is weight:
         hit = ent[1].get(key)
@@ -99,10 +100,15 @@ def pack_conv_weight(weight, transpose_flip=False):
     o, i, k, k2 = w.shape
     assert k == k2, 'square kernels only'
     co, ci = (i, o) if transpose_flip else (o, i)
-    n = L.edvr_conv2d_packed_weight_elems(co, ci, k)
-    out = torch.empty(n, dtype=torch.float32, device=w.device)
-    _lib.check(L.edvr_conv2d_pack_weight_f32(_ptr(w), _ptr(out), co, ci, k, 1 if transpose_flip else 0, _stream()),
-               'edvr_conv2d_pack_weight_f32')
+    if f4:
+        assert k == 3, 'F(4x4,3x3) weights are for 3x3 kernels'
+        out = torch.empty(L.edvr_conv2d_packed_weight_f4_elems(co, ci), dtype=torch.float32, device=w.device)
+        _lib.check(L.edvr_conv2d_pack_weight_f4_f32(_ptr(w), _ptr(out), co, ci, 1 if transpose_flip else 0, _stream()),
+                   'edvr_conv2d_pack_weight_f4_f32')
+    else:
+        out = torch.empty(L.edvr_conv2d_packed_weight_elems(co, ci, k), dtype=torch.float32, device=w.device)
+        _lib.check(L.edvr_conv2d_pack_weight_f32(_ptr(w), _ptr(out), co, ci, k, 1 if transpose_flip else 0, _stream()),
+                   'edvr_conv2d_pack_weight_f32')
     ent[1][key] = (ver, out, weight.data_ptr())
     return out
 
@@ -121,9 +127,10 @@ CONV_ALGO = CONV_AUTO  # default algorithm request of conv2d(); tests flip it to
 
 
 def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NONE, act_from=0, res1=None, res2=None,
-           out_mode=OUT_NCHW, out=None, algo=None, gate=None, gate_slope=0.0, y_scale=1.0):
+           out_mode=OUT_NCHW, out=None, algo=None, gate=None, gate_slope=0.0, y_scale=1.0, wpk_f4=None):
     """y = y_scale * act(conv(cat(x1, x2)) + bias) + res1 + res2 on the fp32 MFMA kernel.
-    algo: CONV_AUTO (default; module-level CONV_ALGO overrides it, used by tests), CONV_DIRECT or CONV_WINOGRAD.
+    algo: CONV_AUTO (default; module-level CONV_ALGO overrides it, used by tests), CONV_DIRECT, CONV_WINOGRAD or CONV_WINOGRAD_F4.
+    wpk_f4: pack_conv_weight(w, f4=True) - allows the F(4x4,3x3) Winograd kernel (inference; ~1e-6 relative rounding error).
 
     x2_map = (div, mul, add): image i of x2 is (i // div) * mul + add (broadcast of a reference frame).
     gate (n, co, ho, wo): y *= gate > 0 ? 1 : gate_slope - the backward of a ReLU / LeakyReLU fused into the data-gradient conv
@@ -171,6 +178,9 @@ def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NON
         d.gate, d.gate_img_stride, d.gate_slope = _ptr(gate), _img_stride(gate), float(gate_slope)
     d.y, d.y_img_stride, d.out_mode = _ptr(out), _img_stride(out), out_mode
     d.y_scale = float(y_scale)
+    if wpk_f4 is not None:
+        require_gpu(wpk_f4)
+        d.wpk_f4 = _ptr(wpk_f4)
     d.algo = CONV_ALGO if algo is None else algo
     name, flops, nbytes = 'conv2d', 0.0, 0.0
     if LAUNCH_HOOK is not None:  # measurement only (bench.py): brackets the launch with events on this stream

@@ -67,6 +67,7 @@ int edvr_check_device(void);
 #define EDVR_CONV_AUTO 0
 #define EDVR_CONV_DIRECT 1
 #define EDVR_CONV_WINOGRAD 2
+#define EDVR_CONV_WINOGRAD_F4 3 /* F(4x4,3x3): needs edvr_conv2d_desc.wpk_f4; falls back like EDVR_CONV_WINOGRAD where it does not apply */
 
 #define EDVR_OUT_NCHW 0
 #define EDVR_OUT_PIXEL_SHUFFLE2 1 /* y[n, co/4, 2h+(co%4)/2, 2w+co%2]  (nn.PixelShuffle(2)) */
@@ -106,6 +107,10 @@ typedef struct edvr_conv2d_desc {
   float gate_slope;
   float y_scale;          /* y = y_scale * act(conv + bias) [gated] + res1 + res2; 0 means 1.  ResidualBlockNoBN's res_scale
                            * (arch_util.py:95).  3x3 convs only (EDVR_ERR_UNSUPPORTED for 1x1 / <= 4 output channels / PixelShuffle). */
+  const float *wpk_f4;    /* optional: the same weights packed by edvr_conv2d_pack_weight_f4_f32.  Its presence ALLOWS the
+                           * F(4x4,3x3) Winograd kernel (csrc/winograd_f4.hip: 2.25 instead of 4 multiplies per output; fp32
+                           * rounding error ~1e-6 of the output scale instead of ~2e-7) under EDVR_CONV_AUTO where that kernel is the
+                           * fastest; NULL keeps the F(2x2) / direct choice.  Inference path: training leaves it NULL. */
 } edvr_conv2d_desc;
 
 size_t edvr_conv2d_packed_weight_elems(int co, int ci, int ks);
@@ -113,6 +118,9 @@ size_t edvr_conv2d_packed_weight_elems(int co, int ci, int ks);
  * w'(ci, co, ks, ks) with w'[c][o][i][j] = w[o][c][ks-1-i][ks-1-j] (then `co`/`ci` refer to w'). */
 int edvr_conv2d_pack_weight_f32(const float *w, float *wpk, int co, int ci, int ks, int transpose_flip,
                                 edvr_stream_t stream);
+/* F(4x4,3x3) weights of a 3x3 conv: U = G g G^T in MFMA operand order, edvr_conv2d_packed_weight_f4_elems(co, ci) floats. */
+size_t edvr_conv2d_packed_weight_f4_elems(int co, int ci);
+int edvr_conv2d_pack_weight_f4_f32(const float *w, float *wpk_f4, int co, int ci, int transpose_flip, edvr_stream_t stream);
 int edvr_conv2d_f32(const edvr_conv2d_desc *d, edvr_stream_t stream);
 /* 1 if edvr_conv2d_f32 would accept `d` with a `gate` (the Winograd kernel applies under d->algo, the sizes and the
  * EDVR_CONV_WINOGRAD environment switch), else 0.  Callers that fuse an activation backward into a data-gradient conv ask

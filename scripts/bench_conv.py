@@ -20,20 +20,22 @@ SHAPES = [  # n, ci, h, w, co, ks, stride
 ]
 if len(sys.argv) > 1:
     SHAPES = [SHAPES[int(i)] for i in sys.argv[1].split(',')]
+F4 = len(sys.argv) > 2 and sys.argv[2] == 'f4'  # 3x3 / stride-1 shapes on the F(4x4,3x3) kernel
 dev = torch.device('cuda')
 for (n, ci, h, w, co, ks, st) in SHAPES:
     x = torch.randn(n, ci, h, w, device=dev)
     wt = torch.randn(co, ci, ks, ks, device=dev) * 0.05
     b = torch.randn(co, device=dev)
     wpk = ops.pack_conv_weight(wt)
+    kw = dict(wpk_f4=ops.pack_conv_weight(wt, f4=True), algo=ops.CONV_WINOGRAD_F4) if (F4 and ks == 3 and st == 1) else {}
     for _ in range(2):
-        y = ops.conv2d(x, wpk, b, co, ks, stride=st, act=ops.ACT_LRELU)
+        y = ops.conv2d(x, wpk, b, co, ks, stride=st, act=ops.ACT_LRELU, **kw)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 5
     e0.record()
     for _ in range(reps):
-        y = ops.conv2d(x, wpk, b, co, ks, stride=st, act=ops.ACT_LRELU)
+        y = ops.conv2d(x, wpk, b, co, ks, stride=st, act=ops.ACT_LRELU, **kw)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps

@@ -1,0 +1,121 @@
+"""-m gpu: the F(4x4,3x3) Winograd conv kernel (csrc/winograd_f4.hip, inference path) through the C ABI against torch's CPU conv
+in fp64.  Tolerance: F(4x4) transforms hold coefficients up to 8 (F(2x2): 1), so fp32 rounding is ~1e-6 of the output scale at
+128 channels instead of ~2e-7; the bound below is 3e-5 of the output scale (the path's specification is 1e-3 dB PSNR)."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+RTOL_F4 = 3e-5
+
+
+def _rel(a, ref):
+    return ((a.double().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+CASES = [
+    # n, c1, c2, h, w, co, act, res, out_mode, x2map, gate
+    (2, 64, 0, 16, 64, 64, 'lrelu', 0, 0, None, None),        # exactly one 8 x 64 block per image and channel block
+    (1, 128, 0, 45, 80, 128, 'relu', 1, 0, None, None),        # ragged: 45 rows, 80 columns
+    (3, 64, 0, 64, 64, 64, 'lrelu', 0, 0, None, None),        # training-crop size
+    (2, 32, 0, 19, 38, 70, 'lrelu', 2, 0, None, None),        # partial channel block (70), two residuals, w % 4 != 0
+    (1, 16, 16, 10, 50, 64, 'relu', 0, 0, None, None),        # concat input
+    (4, 64, 64, 18, 34, 64, 'none', 0, 0, (2, 2, 1), None),   # concat input through the frame map
+    (1, 48, 0, 8, 36, 128, 'lrelu', 0, 1, None, None),        # pixel-shuffle epilogue
+    (1, 32, 0, 12, 36, 216, 'sigmoid_from', 0, 0, None, None),  # offset / mask conv epilogue, 216 channels
+    (2, 216, 0, 12, 40, 128, 'none', 0, 0, None, None),       # 216 input channels (27 chunks: odd)
+    (1, 100, 20, 8, 34, 64, 'lrelu', 1, 0, None, None),       # concat boundary inside a chunk
+    (1, 20, 0, 9, 66, 48, 'none', 0, 0, None, None),          # 20 -> 24 padded input channels, 66 columns (2 blocks, second nearly empty)
+    (2, 64, 0, 14, 38, 64, 'none', 0, 0, None, 0.1),          # gate (LeakyReLU backward) epilogue
+    (2, 64, 0, 16, 40, 64, 'relu', 1, 0, None, None),         # residual + y_scale (set below)
+    (1, 8, 0, 8, 64, 64, 'none', 0, 0, None, None),           # a single chunk per item
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_f4_conv_matches_fp64(gpu, case):
+    from edvr_amd import _lib, ops
+    n, c1, c2, h, w, co, actn, nres, out_mode, x2map, gate = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x1 = torch.randn(n, c1, h, w, generator=g)
+    n2 = n if x2map is None else (n // x2map[0]) * x2map[1]
+    x2 = torch.randn(n2, c2, h, w, generator=g) if c2 else None
+    wt = torch.randn(co, c1 + c2, 3, 3, generator=g) * 0.1
+    b = torch.randn(co, generator=g)
+    if x2 is None:
+        xin = x1
+    elif x2map is None:
+        xin = torch.cat([x1, x2], 1)
+    else:
+        idx = [(i // x2map[0]) * x2map[1] + x2map[2] for i in range(n)]
+        xin = torch.cat([x1, x2[idx]], 1)
+    ref = F.conv2d(xin.double(), wt.double(), b.double(), 1, 1)
+    act, act_from = {'none': (0, 0), 'relu': (1, 0), 'lrelu': (2, 0), 'sigmoid_from': (3, 2 * co // 3)}[actn]
+    if actn == 'relu':
+        ref = F.relu(ref)
+    elif actn == 'lrelu':
+        ref = F.leaky_relu(ref, 0.1)
+    elif actn == 'sigmoid_from':
+        ref = torch.cat([ref[:, :act_from], torch.sigmoid(ref[:, act_from:])], 1)
+    y_scale = 0.25 if (nres == 1 and actn == 'relu' and h == 16) else 1.0
+    ref = ref * y_scale
+    gt = None
+    if gate is not None:
+        gt = torch.randn(ref.shape, generator=g).relu()
+        ref = ref * torch.where(gt > 0, 1.0, gate).double()
+    res = [torch.randn(ref.shape, generator=g) for _ in range(nres)]
+    for r in res:
+        ref = ref + r.double()
+    if out_mode == 1:
+        ref = F.pixel_shuffle(ref, 2)
+    wg = wt.to(gpu)
+    wpk, wf4 = ops.pack_conv_weight(wg), ops.pack_conv_weight(wg, f4=True)
+    kw = dict(x2=None if x2 is None else x2.to(gpu), x2_map=x2map, act=act, act_from=act_from, res1=res[0].to(gpu) if nres > 0 else None,
+              res2=res[1].to(gpu) if nres > 1 else None, out_mode=out_mode, gate=None if gt is None else gt.to(gpu),
+              gate_slope=gate or 0.0, y_scale=y_scale, wpk_f4=wf4, algo=ops.CONV_WINOGRAD_F4)
+    # the request must reach the F(4x4) kernel (not fall back)
+    d = _lib.ConvDesc()
+    d.c1, d.c2, d.n, d.h, d.w, d.co, d.ks, d.stride, d.algo = c1, c2, n, h, w, co, 3, 1, ops.CONV_WINOGRAD_F4
+    x1g = x1.to(gpu)
+    d.x1, d.wpk_f4, d.out_mode, d.act = x1g.data_ptr(), wf4.data_ptr(), out_mode, act
+    if c2:
+        d.x2 = kw['x2'].data_ptr()
+    buf = ctypes.create_string_buffer(96)
+    _lib.lib().edvr_conv2d_kernel_name(ctypes.byref(d), buf, 96)
+    assert buf.value == b'conv3x3_winograd_f4_kernel', buf.value
+    y = ops.conv2d(x1g, wpk, b.to(gpu), co, 3, **kw)
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape
+    assert _rel(y, ref) < RTOL_F4, _rel(y, ref)
+
+
+def test_f4_is_deterministic_and_repeated_launches_agree(gpu):
+    from edvr_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(6, 128, 36, 128, generator=g).to(gpu)
+    wt = (torch.randn(128, 128, 3, 3, generator=g) * 0.05).to(gpu)
+    b = torch.randn(128, generator=g).to(gpu)
+    wpk, wf4 = ops.pack_conv_weight(wt), ops.pack_conv_weight(wt, f4=True)
+    first = ops.conv2d(x, wpk, b, 128, 3, act=ops.ACT_LRELU, wpk_f4=wf4, algo=ops.CONV_WINOGRAD_F4)
+    ref = ops.conv2d(x, wpk, b, 128, 3, act=ops.ACT_LRELU, algo=ops.CONV_DIRECT)
+    assert _rel(first, ref.double().cpu()) < RTOL_F4
+    for _ in range(20):
+        again = ops.conv2d(x, wpk, b, 128, 3, act=ops.ACT_LRELU, wpk_f4=wf4, algo=ops.CONV_WINOGRAD_F4)
+        assert torch.equal(again, first)
+
+
+def test_f4_data_gradient_packing(gpu):
+    """transpose_flip packing: the F(4x4) kernel as the data gradient of the stride-1 conv."""
+    from edvr_amd import ops
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(1, 24, 10, 14, generator=g, dtype=torch.float64, requires_grad=True)
+    wt = torch.randn(40, 24, 3, 3, generator=g, dtype=torch.float64) * 0.1
+    dy = torch.randn(1, 40, 10, 14, generator=g, dtype=torch.float64)
+    F.conv2d(x, wt, None, 1, 1).backward(dy)
+    wg = wt.float().to(gpu)
+    dx = ops.conv2d(dy.float().to(gpu), ops.pack_conv_weight(wg, transpose_flip=True), None, 24, 3,
+                    wpk_f4=ops.pack_conv_weight(wg, transpose_flip=True, f4=True), algo=ops.CONV_WINOGRAD_F4)
+    assert _rel(dx, x.grad) < RTOL_F4
