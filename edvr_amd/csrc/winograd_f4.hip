@@ -17,9 +17,10 @@
 //     (U) belong to exactly one wave each, so they come straight from global memory - one 16-byte and one 8-byte buffer load per
 //     six MFMAs, packed so that a wave reads 1.5 KB contiguous - two k-steps ahead.  No staging stall ever sits on a wave that
 //     issues MFMAs.
-//   * 4 producer waves (one per SIMD): thread = (channel of the 8-channel chunk, tile) loads its 6x6 patch through a rotating
-//     register set (chunk k + 2 is requested as soon as the registers of chunk k + 1 are transformed), applies B^T . B and
-//     writes the 36 positions to the double-buffered V slab (2 x 36 KB).  They also own everything that touches the output:
+//   * 4 producer waves (one per SIMD): the raw input rows of a wave's two channels arrive by LDS-DMA in a 6 KB region private
+//     to the wave (requested one chunk ahead); thread = (channel of the 8-channel chunk, tile) reads its 6x6 patch from there,
+//     applies B^T . B and writes the 36 positions to the double-buffered V slab (2 x 36 KB).  They also own everything that
+//     touches the output:
 //     after the consumers' row pass (T = M A, written to a double-buffered 2 x 24 KB exchange area in eight 8-channel phases)
 //     they finish Y = A^T T, apply bias / activation / residuals / gate / PixelShuffle and store 16-byte rows.
 //   One barrier per chunk (LDS only) + 8 per item.
@@ -48,12 +49,40 @@ struct WinoF4Args {
 #endif
 #define F4_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-template <bool PAIR>
+#ifdef F4_EXP_TRACE /* measurement build: cycle stamps of workgroup 0 (arrival at / release from every barrier, per wave) */
+__device__ long long f4_trace[16 * 2 * 512];
+__device__ long long f4_trace_p[4 * 4 * 512];  // producers: after the DMA wait, after the patch reads, after the DMA issue, after the transforms
+#define F4_PSTAMP(i)                                                                                         \
+  do {                                                                                                      \
+    if (blockIdx.x == 0 && f4_slot < 512 && (threadIdx.x & 63) == 0)                                        \
+      f4_trace_p[(f4_slot * 4 + (threadIdx.x >> 6)) * 4 + (i)] = __builtin_readcyclecounter();              \
+  } while (0)
+#define F4_STAMP(slot)                                                                                          \
+  do {                                                                                                          \
+    if (blockIdx.x == 0 && (slot) < 512 && (threadIdx.x & 63) == 0)                                            \
+      f4_trace[((slot) * 16 + (threadIdx.x >> 6)) * 2 + f4_tr_ph] = __builtin_readcyclecounter();              \
+  } while (0)
+#define F4_BARRIER_T()   \
+  do {                   \
+    int f4_tr_ph = 0;    \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    F4_STAMP(f4_slot);   \
+    asm volatile("s_barrier" ::: "memory"); \
+    f4_tr_ph = 1;        \
+    F4_STAMP(f4_slot);   \
+    ++f4_slot;           \
+  } while (0)
+#else
+#define F4_BARRIER_T() F4_LDS_BARRIER()
+#define F4_PSTAMP(i)
+#endif
+
 __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const WinoF4Args a) {
   constexpr int CK = 8;
   constexpr int VSLAB = CK * 36 * 32;   // floats per V stage (36 KB): [channel 8][position 36][tile 32]
   constexpr int XSZ = 2 * 6 * 8 * 32 * 4;  // exchange area (2 x 24 KB): [phase parity][row 6][channel 8][tile 32][4]
-  __shared__ __attribute__((aligned(16))) float smem[2 * VSLAB + XSZ];
+  constexpr int RWAVE = 6 * 64 * 4 + 4;     // raw-input region of one producer wave: 6 DMA instructions x 64 lanes x 16 B, + one-dword shift (below)
+  __shared__ __attribute__((aligned(16))) float smem[2 * VSLAB + XSZ + 4 * RWAVE];  // 144 KB
   float *const Xs = smem + 2 * VSLAB;
 
   const edvr_conv2d_desc &d = a.d;
@@ -78,6 +107,9 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
   const int item_end = min(a.items, (xcd + 1) * span);
   const int item_first = xcd * span + xcd_rank;
   if (item_first >= item_end) return;
+#ifdef F4_EXP_TRACE
+  int f4_slot = 0;
+#endif
   auto decode = [&](int item, int &co_blk, int &img, int &ty0, int &tx0) {
     co_blk = __builtin_amdgcn_readfirstlane((item % co_blocks) * 64);
     const int tile_blk = __builtin_amdgcn_readfirstlane((item / co_blocks) % (a.tiles_x * a.tiles_y));
@@ -88,34 +120,38 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
 
   if (wave < 4) {
     // =========================================================================================== producers
-#ifdef F4_EXP_PRIO
+    // Vector instructions are not issued while an MFMA of the same SIMD executes (measured: the staging wave got one instruction
+    // per MFMA slot and was the last at every barrier).  With the higher priority its ~85 instructions per chunk go first and
+    // the three MFMA waves fill the rest; its instruction count is what it costs.
     __builtin_amdgcn_s_setprio(3);
-#endif
     const int p_ty = j >> 4, p_tx = j & 15;  // tile j of the 2 x 16; channel 2 wave + half of the chunk
-    constexpr int NCG = PAIR ? 4 : 6;        // column groups: {0, (1, 2), (3, 4), 5} or six single columns
-    constexpr int OOB = 0x40000000;          // >= num_records (two planes < 2^29 bytes, winograd_f4_supported) alone or summed
-    int rowoff[6], coloff[NCG];
+    // Raw input of this wave's two channels for one chunk: [channel 2][row 10][18 x 16 B] = image rows ty0 - 1 .. ty0 + 8,
+    // columns tx0 - 4 .. tx0 + 67, fetched by LDS-DMA (buffer_load_dwordx4 ... lds: lane l of instruction i delivers 16-byte piece
+    // 64 i + l; pieces outside the image get an out-of-range offset and arrive as zeros = the padding).  The region is PRIVATE
+    // to the wave - it alone reads the patches of these two channels - so no cross-wave ordering is needed: read the patches of
+    // chunk k + 1, then request chunk k + 2 into the same place; it has the rest of the step to arrive.
+    // (First version: every thread gathered its 6x6 patch with 24 buffer loads - 16 quad accesses per instruction in the
+    // texture addresser, 4160 L1 accesses per chunk and CU, address path 50 % busy: 1.24 ms where the MFMAs need 0.55.)
+    typedef __attribute__((address_space(3))) void lvoid;
+    constexpr int OOB = (int)0x80000000;
+    float *const Rw = smem + 2 * VSLAB + XSZ + wave * RWAVE;
+    int dma_off[6];
     const float *x1 = d.x1, *x2 = d.x1;
-    int l_item = item_first, l_k = 0;  // load cursor: (item, chunk) the NEXT patch loads belong to
+    int l_item = item_first, l_k = 0;  // load cursor: (item, chunk) the NEXT request belongs to
     auto setup = [&](int item) {
       int cb, img, ty0, tx0;
       decode(item, cb, img, ty0, tx0);
-#ifdef F4_EXP_L2HOT /* ablation: every item reads the first block of image 0 (cache-resident) */
-      img = 0, ty0 = 0, tx0 = 0;
-#endif
       x1 = d.x1 + (int64_t)img * d.x1_img_stride;
       x2 = x1;
       if (d.x2) {
         const int i2 = d.x2_div > 0 ? (img / d.x2_div) * d.x2_mul + d.x2_add : img;
         x2 = d.x2 + (int64_t)i2 * d.x2_img_stride;
       }
-      const int gy0 = ty0 + 4 * p_ty - 1, gx0 = tx0 + 4 * p_tx - 1;  // top-left of the 6x6 patch (pad 1)
 #pragma unroll
-      for (int r = 0; r < 6; ++r) rowoff[r] = (gy0 + r >= 0 && gy0 + r < d.h) ? ((gy0 + r) * d.w + gx0) * 4 + half * plane_bytes : OOB;
-#pragma unroll
-      for (int g = 0; g < NCG; ++g) {
-        const int c = PAIR ? (g == 0 ? 0 : 2 * g - 1) : g;  // first column of the group; an aligned pair is valid or padded together
-        coloff[g] = (gx0 + c >= 0 && gx0 + c < d.w) ? c * 4 : OOB;
+      for (int i = 0; i < 6; ++i) {
+        const int q = i * 64 + lane, ch = q / 180, rem = q - ch * 180, row = rem / 18, cx = rem - row * 18;
+        const int gy = ty0 - 1 + row, gx = tx0 - 4 + 4 * cx;  // w % 4 == 0: a piece is inside or outside the row as a whole
+        dma_off[i] = (q < 360 && gy >= 0 && gy < d.h && gx >= 0 && gx < d.w) ? (ch * hw + gy * d.w + gx) * 4 : OOB;
       }
     };
     __amdgpu_buffer_rsrc_t ld_rsrc = uniform_rsrc(d.x1, 0);
@@ -125,50 +161,69 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
       const int nvalid = a.ci_real - c;  // channels of the padding: empty (or one-plane) buffer, their loads return 0
       ld_rsrc = uniform_rsrc(pl, nvalid >= 2 ? 2 * plane_bytes : (nvalid == 1 ? plane_bytes : 0));
     };
-    float pr[36];  // raw patch [r][c]
-    float tt[36];  // B^T d
-    auto load_col = [&](int c) {  // reload column c of the patch registers (all six rows)
-      if (PAIR && (c == 1 || c == 3)) return;  // second halves are loaded with columns 2 / 4, once both are consumed
+    auto dma_issue = [&]() {
+#ifdef F4_EXP_NODMA /* ablation (wrong results): no input fetch at all */
+      return;
+#endif
+#pragma unroll
+      for (int i = 0; i < 6; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(ld_rsrc, (lvoid *)(Rw + 1 + i * 256), 16, dma_off[i], 0, 0, 0);
+    };
+    // The input transform runs on PACKED fp32 math (v_pk_fma_f32 / v_pk_add_f32: two lanes of work per instruction): vector
+    // instructions of the staging waves take issue slots from the MFMAs of the same SIMD, so their count is what matters
+    // (72 packed operations per patch and chunk; the scalar form had 144 + 57 moves).
+    //   B^T d    along the rows, on pairs of adjacent columns (2 cp, 2 cp + 1): the 12-operation scheme on both at once;
+    //   (.) B    along the columns of one row held as the same pairs P0 = (d0, d1), P1 = (d2, d3), P2 = (d4, d5): the outputs
+    //            pair up so that every operand is one register pair with a lo/hi selection (op_sel) - no repacking:
+    //            (t0, t5) = 4 P0 - 5 P1 + P2;  (p, r) = d4 + (-4, -1) d2;  (q, s) = d3 + (-4, -1) d1;
+    //            (t1, t3) = (p, r) + (1, 2) (q, s);  (t2, t4) = (p, r) - (1, 2) (q, s).
+    f32x2 pp[6][3];  // raw patch: row r, columns (2 cp, 2 cp + 1)
+    f32x2 tp[6][3];  // B^T d, same pairing
+    // The DMA writes the pieces ONE DWORD into the region: column tx0 - 4 + k of a row lands at dword k + 1, so the patch of tile
+    // p_tx (columns 4 p_tx + 3 .. + 8) starts at the 16-byte aligned dword 4 p_tx + 4: one b128 + one b64 read per row, already
+    // paired the way the packed transform wants them (no moves).
+    const float *patch = Rw + ((half * 10 + 4 * p_ty) * 18 + p_tx) * 4 + 4;  // patch row r, column c: patch[r * 72 + c]
+    auto read_patch = [&]() {
+#ifndef F4_EXP_NOWAIT /* ablation (wrong results): do not wait for the DMA */
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the requested chunk is in the region
+#endif
+      F4_PSTAMP(0);
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
-        if (PAIR && (c == 2 || c == 4)) {
-          const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(ld_rsrc, rowoff[r] + coloff[c / 2], 0, 0));
-          pr[r * 6 + c - 1] = v[0];
-          pr[r * 6 + c] = v[1];
-        } else {
-          const int g = PAIR ? (c == 0 ? 0 : 3) : c;
-          pr[r * 6 + c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ld_rsrc, rowoff[r] + coloff[g], 0, 0));
-        }
+        const f32x4 m = *reinterpret_cast<const f32x4 *>(patch + r * 72);
+        pp[r][0] = f32x2{m[0], m[1]};
+        pp[r][1] = f32x2{m[2], m[3]};
+        pp[r][2] = *reinterpret_cast<const f32x2 *>(patch + r * 72 + 4);
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and in registers: the region may be overwritten
+      F4_PSTAMP(1);
     };
-    // 1-D input transform B^T (Lavin & Gray): 12 operations
-#define F4_BT(d0, d1, d2, d3, d4, d5, t0, t1, t2, t3, t4, t5)   \
-  {                                                             \
-    const float p_ = __builtin_fmaf(-4.f, d2, d4), q_ = __builtin_fmaf(-4.f, d1, d3); \
-    const float r_ = d4 - d2, s_ = d3 - d1;                     \
-    t0 = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4)); \
-    t1 = p_ + q_;                                               \
-    t2 = p_ - q_;                                               \
-    t3 = __builtin_fmaf(2.f, s_, r_);                           \
-    t4 = __builtin_fmaf(-2.f, s_, r_);                          \
-    t5 = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5)); \
-  }
-    auto transform_col = [&](int c) {
-      F4_BT(pr[0 * 6 + c], pr[1 * 6 + c], pr[2 * 6 + c], pr[3 * 6 + c], pr[4 * 6 + c], pr[5 * 6 + c], tt[0 * 6 + c], tt[1 * 6 + c],
-            tt[2 * 6 + c], tt[3 * 6 + c], tt[4 * 6 + c], tt[5 * 6 + c]);
+    auto transform_cols = [&](int cp) {  // 1-D input transform B^T (Lavin & Gray), 12 operations (a * b + c contracts to an fma)
+      const f32x2 d0 = pp[0][cp], d1 = pp[1][cp], d2 = pp[2][cp], d3 = pp[3][cp], d4 = pp[4][cp], d5 = pp[5][cp];
+      const f32x2 p_ = d4 - 4.f * d2, q_ = d3 - 4.f * d1, r_ = d4 - d2, s_ = d3 - d1;
+      tp[0][cp] = 4.f * d0 + (d4 - 5.f * d2);
+      tp[1][cp] = p_ + q_;
+      tp[2][cp] = p_ - q_;
+      tp[3][cp] = r_ + 2.f * s_;
+      tp[4][cp] = r_ - 2.f * s_;
+      tp[5][cp] = 4.f * d1 + (d5 - 5.f * d3);
     };
     auto commit_row = [&](float *Vd, int r) {  // positions (r, 0..5) of (B^T d) B
-      float o0, o1, o2, o3, o4, o5;
-      F4_BT(tt[r * 6 + 0], tt[r * 6 + 1], tt[r * 6 + 2], tt[r * 6 + 3], tt[r * 6 + 4], tt[r * 6 + 5], o0, o1, o2, o3, o4, o5);
+      const f32x2 P0 = tp[r][0], P1 = tp[r][1], P2 = tp[r][2];
+      const f32x2 lo1 = __builtin_shufflevector(P1, P1, 0, 0), hi1 = __builtin_shufflevector(P1, P1, 1, 1);  // d2, d3
+      const f32x2 lo2 = __builtin_shufflevector(P2, P2, 0, 0), hi0 = __builtin_shufflevector(P0, P0, 1, 1);  // d4, d1
+      const f32x2 t05 = 4.f * P0 + (P2 - 5.f * P1);
+      const f32x2 pr_ = lo2 + f32x2{-4.f, -1.f} * lo1;
+      const f32x2 qs_ = hi1 + f32x2{-4.f, -1.f} * hi0;
+      const f32x2 t13 = pr_ + f32x2{1.f, 2.f} * qs_;
+      const f32x2 t24 = pr_ - f32x2{1.f, 2.f} * qs_;
       float *dst = Vd + ((2 * wave + half) * 36 + r * 6) * 32 + j;
-      dst[0 * 32] = o0;
-      dst[1 * 32] = o1;
-      dst[2 * 32] = o2;
-      dst[3 * 32] = o3;
-      dst[4 * 32] = o4;
-      dst[5 * 32] = o5;
+      dst[0 * 32] = t05[0];
+      dst[1 * 32] = t13[0];
+      dst[2 * 32] = t24[0];
+      dst[3 * 32] = t13[1];
+      dst[4 * 32] = t24[1];
+      dst[5 * 32] = t05[1];
     };
-#undef F4_BT
     auto advance = [&]() {  // the load cursor moves one chunk; at an item boundary the geometry switches
       if (++l_k == n_chunks) {
         l_k = 0;
@@ -178,20 +233,19 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
       }
     };
 
-    // ---- prologue: chunk 0 -> registers -> stage 0, chunk 1 -> registers
+    // ---- prologue: chunk 0 -> region -> registers -> stage 0; chunk 1 requested
     setup(item_first);
     load_begin(0);
-#pragma unroll
-    for (int c = 0; c < 6; ++c) load_col(c);
-#pragma unroll
-    for (int c = 0; c < 6; ++c) transform_col(c);
-#pragma unroll
-    for (int r = 0; r < 6; ++r) commit_row(smem, r);
+    dma_issue();
+    read_patch();
     advance();
     load_begin(l_k * CK);
+    dma_issue();
 #pragma unroll
-    for (int c = 0; c < 6; ++c) load_col(c);
-    F4_LDS_BARRIER();
+    for (int cp = 0; cp < 3; ++cp) transform_cols(cp);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) commit_row(smem, r);
+    F4_BARRIER_T();
 
     int par = 0;  // stage the consumers read during the current step
     for (int item = item_first; item < item_end; item += xcd_wgs) {
@@ -199,23 +253,22 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
       decode(item, e_co_blk, e_img, e_ty0, e_tx0);
 #pragma unroll 1
       for (int k = 0; k < n_chunks; ++k) {
-        // the registers hold chunk k + 1 (chunk 0 of the next item at the end): transform into the idle stage, reload with k + 2
-        advance();
-        load_begin(l_k * CK);
+        // the region holds chunk k + 1 (chunk 0 of the next item at the end): patches -> registers, request chunk k + 2,
+        // transform into the idle stage
         float *Vd = smem + (par ^ 1) * VSLAB;
 #ifndef F4_EXP_NOPROD  /* ablation: the producers only keep the barrier count */
+        read_patch();
+        advance();
+        load_begin(l_k * CK);
+        dma_issue();
+        F4_PSTAMP(2);
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {  // (pinned: a column's reload goes out as soon as the column is consumed)
-          transform_col(c);
-#ifndef F4_EXP_NOLOAD
-          load_col(c);
-#endif
-          __builtin_amdgcn_sched_barrier(0);
-        }
+        for (int cp = 0; cp < 3; ++cp) transform_cols(cp);
 #pragma unroll
         for (int r = 0; r < 6; ++r) commit_row(Vd, r);
+        F4_PSTAMP(3);
 #endif
-        F4_LDS_BARRIER();
+        F4_BARRIER_T();
         par ^= 1;
       }
 
@@ -257,7 +310,7 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
         prefetch(0);
 #pragma unroll 1
         for (int p = 0; p < (F4_EPI_PHASES); ++p) {
-          F4_LDS_BARRIER();  // T of this phase is in its half of the exchange area
+          F4_BARRIER_T();  // T of this phase is in its half of the exchange area
           const float *Xb = Xs + (p & 1) * (XSZ / 2) + (cl8 * 32 + tile) * 4;
           f32x4 T[6];
 #pragma unroll
@@ -355,7 +408,7 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
     for (int c = 0; c < 6; ++c)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-    F4_LDS_BARRIER();
+    F4_BARRIER_T();
 
     int par = 0;
     const int b_lane = half * 36 * 32 + row * 6 * 32 + j;  // B operand: channel 2 cp + half, position (row, c), tile j
@@ -394,7 +447,7 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        F4_LDS_BARRIER();
+        F4_BARRIER_T();
         par ^= 1;
       }
       {  // A operands of the next item's first two k-steps: in flight during the row pass
@@ -426,7 +479,7 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
           const int cl8 = wm * 4 + half * 2 + rr;
           *reinterpret_cast<f32x4 *>(Xb + ((row * 8 + cl8) * 32 + j) * 4) = T;
         }
-        F4_LDS_BARRIER();  // phase p written (and phase p - 1 read: its half may be overwritten next)
+        F4_BARRIER_T();  // phase p written (and phase p - 1 read: its half may be overwritten next)
       }
 #pragma unroll
       for (int c = 0; c < 6; ++c)
@@ -497,10 +550,10 @@ bool winograd_f4_supported(const edvr_conv2d_desc &d) {
   if ((d.res2 && !d.res1) || (d.out_mode != EDVR_OUT_NCHW && has_res)) return false;
   if (d.y_scale != 0.f && d.y_scale != 1.f && !d.res1 && !d.gate) return false;  // the scale lives in the residual / gate epilogues
   if (d.c2 > 0 && (d.c1 & 1)) return false;                                      // a staging wave covers two consecutive channels
-  if ((int64_t)d.h * d.w * 8 >= ((int64_t)1 << 29)) return false;                // two planes + the out-of-range sentinel in 32 bits
-  if ((d.w & 1) || ((int64_t)d.h * d.w & 1)) return false;                       // aligned column pairs (PAIR) only, for now
+  if ((int64_t)d.h * d.w * 8 >= ((int64_t)1 << 31)) return false;                // two planes in 32-bit buffer offsets
+  if (d.w & 3) return false;                                                     // input rows are fetched as aligned 16-byte pieces
   auto aligned = [](const float *p, int64_t img_stride, int a) { return !p || ((reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0 && (img_stride * 4 & (a - 1)) == 0); };
-  if (!aligned(d.x1, d.x1_img_stride, 8) || !aligned(d.x2, d.x2_img_stride, 8)) return false;
+  if (!aligned(d.x1, d.x1_img_stride, 16) || !aligned(d.x2, d.x2_img_stride, 16)) return false;
   if (!aligned(d.y, d.y_img_stride, 16) || !aligned(d.res1, d.res1_img_stride, 16) || !aligned(d.res2, d.res2_img_stride, 16) ||
       !aligned(d.gate, d.gate_img_stride, 16))
     return false;
@@ -533,7 +586,7 @@ int winograd_f4_launch(const edvr_conv2d_desc &d, hipStream_t stream) {
     return n;
   }();
   const dim3 grid(std::min(a.items, n_cu));
-  hipLaunchKernelGGL((conv3x3_winograd_f4_kernel<true>), grid, dim3(1024), 0, stream, a);
+  hipLaunchKernelGGL(conv3x3_winograd_f4_kernel, grid, dim3(1024), 0, stream, a);
   return check_launch("conv3x3_winograd_f4_kernel");
 }
 
@@ -548,6 +601,11 @@ int winograd_f4_pack(const float *w, float *U, int co, int ci, int transpose_fli
 }  // namespace edvr
 
 extern "C" {
+
+#ifdef F4_EXP_TRACE
+int edvr_f4_trace_read(long long *host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(edvr::f4_trace), sizeof(long long) * n); }
+int edvr_f4_trace_read_p(long long *host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(edvr::f4_trace_p), sizeof(long long) * n); }
+#endif
 
 size_t edvr_conv2d_packed_weight_f4_elems(int co, int ci) { return (size_t)((co + 63) / 64 * 64) * ((ci + 7) / 8 * 8) * 36; }
 

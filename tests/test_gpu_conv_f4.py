@@ -21,15 +21,15 @@ CASES = [
     (2, 64, 0, 16, 64, 64, 'lrelu', 0, 0, None, None),        # exactly one 8 x 64 block per image and channel block
     (1, 128, 0, 45, 80, 128, 'relu', 1, 0, None, None),        # ragged: 45 rows, 80 columns
     (3, 64, 0, 64, 64, 64, 'lrelu', 0, 0, None, None),        # training-crop size
-    (2, 32, 0, 19, 38, 70, 'lrelu', 2, 0, None, None),        # partial channel block (70), two residuals, w % 4 != 0
-    (1, 16, 16, 10, 50, 64, 'relu', 0, 0, None, None),        # concat input
-    (4, 64, 64, 18, 34, 64, 'none', 0, 0, (2, 2, 1), None),   # concat input through the frame map
+    (2, 32, 0, 19, 36, 70, 'lrelu', 2, 0, None, None),        # partial channel block (70), two residuals, ragged block
+    (1, 16, 16, 10, 52, 64, 'relu', 0, 0, None, None),        # concat input
+    (4, 64, 64, 18, 36, 64, 'none', 0, 0, (2, 2, 1), None),   # concat input through the frame map
     (1, 48, 0, 8, 36, 128, 'lrelu', 0, 1, None, None),        # pixel-shuffle epilogue
     (1, 32, 0, 12, 36, 216, 'sigmoid_from', 0, 0, None, None),  # offset / mask conv epilogue, 216 channels
     (2, 216, 0, 12, 40, 128, 'none', 0, 0, None, None),       # 216 input channels (27 chunks: odd)
-    (1, 100, 20, 8, 34, 64, 'lrelu', 1, 0, None, None),       # concat boundary inside a chunk
-    (1, 20, 0, 9, 66, 48, 'none', 0, 0, None, None),          # 20 -> 24 padded input channels, 66 columns (2 blocks, second nearly empty)
-    (2, 64, 0, 14, 38, 64, 'none', 0, 0, None, 0.1),          # gate (LeakyReLU backward) epilogue
+    (1, 100, 20, 8, 36, 64, 'lrelu', 1, 0, None, None),       # concat boundary inside a chunk
+    (1, 20, 0, 9, 68, 48, 'none', 0, 0, None, None),          # 20 -> 24 padded input channels, 68 columns (2 blocks, second nearly empty)
+    (2, 64, 0, 14, 40, 64, 'none', 0, 0, None, 0.1),          # gate (LeakyReLU backward) epilogue
     (2, 64, 0, 16, 40, 64, 'relu', 1, 0, None, None),         # residual + y_scale (set below)
     (1, 8, 0, 8, 64, 64, 'none', 0, 0, None, None),           # a single chunk per item
 ]
@@ -107,13 +107,33 @@ def test_f4_is_deterministic_and_repeated_launches_agree(gpu):
         assert torch.equal(again, first)
 
 
+def test_f4_falls_back_where_it_does_not_apply(gpu):
+    """A width that is not a multiple of 4 (rows are fetched as aligned 16-byte pieces): the request runs on F(2x2) instead."""
+    from edvr_amd import _lib, ops
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(1, 32, 12, 38, generator=g)
+    wt = torch.randn(64, 32, 3, 3, generator=g) * 0.1
+    ref = F.conv2d(x.double(), wt.double(), None, 1, 1)
+    wg = wt.to(gpu)
+    d = _lib.ConvDesc()
+    d.c1, d.n, d.h, d.w, d.co, d.ks, d.stride, d.algo = 32, 1, 12, 38, 64, 3, 1, ops.CONV_WINOGRAD_F4
+    wf4 = ops.pack_conv_weight(wg, f4=True)
+    xg = x.to(gpu)
+    d.x1, d.wpk_f4 = xg.data_ptr(), wf4.data_ptr()
+    buf = ctypes.create_string_buffer(96)
+    _lib.lib().edvr_conv2d_kernel_name(ctypes.byref(d), buf, 96)
+    assert buf.value == b'conv3x3_winograd_kernel', buf.value
+    y = ops.conv2d(xg, ops.pack_conv_weight(wg), None, 64, 3, wpk_f4=wf4, algo=ops.CONV_WINOGRAD_F4)
+    assert _rel(y, ref) < RTOL_F4
+
+
 def test_f4_data_gradient_packing(gpu):
     """transpose_flip packing: the F(4x4) kernel as the data gradient of the stride-1 conv."""
     from edvr_amd import ops
     g = torch.Generator().manual_seed(6)
-    x = torch.randn(1, 24, 10, 14, generator=g, dtype=torch.float64, requires_grad=True)
+    x = torch.randn(1, 24, 10, 16, generator=g, dtype=torch.float64, requires_grad=True)
     wt = torch.randn(40, 24, 3, 3, generator=g, dtype=torch.float64) * 0.1
-    dy = torch.randn(1, 40, 10, 14, generator=g, dtype=torch.float64)
+    dy = torch.randn(1, 40, 10, 16, generator=g, dtype=torch.float64)
     F.conv2d(x, wt, None, 1, 1).backward(dy)
     wg = wt.float().to(gpu)
     dx = ops.conv2d(dy.float().to(gpu), ops.pack_conv_weight(wg, transpose_flip=True), None, 24, 3,
