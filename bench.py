@@ -71,9 +71,10 @@ WORKLOADS = {
     'edvr_m_x4_t5_64x64': dict(net=dict(num_feat=64, num_frame=5, num_reconstruct_block=10, center_frame_idx=2),
                                shape=(5, 3, 64, 64), batch=1, desc='EDVR-M x4, 5 frames, 64x64 LR crop, batch 1'),
 }
-MFMA_KERNELS = ('conv3x3_winograd_kernel', 'conv3x3_winograd4_kernel', 'conv3x3_winograd_wgrad_kernel', 'conv2d_mfma_kernel', 'conv2d_wgrad_kernel',
+MFMA_KERNELS = ('conv3x3_winograd_f4_kernel', 'conv3x3_winograd_kernel', 'conv3x3_winograd4_kernel', 'conv3x3_winograd_wgrad_kernel', 'conv2d_mfma_kernel', 'conv2d_wgrad_kernel',
                 'conv1x1_stream_kernel', 'gemm_nt_kernel', 'dcnv2_fwd', 'dcnv2_bwd')
 WINOGRAD = ('conv3x3_winograd_kernel', 'conv3x3_winograd4_kernel', 'conv3x3_winograd_wgrad_kernel')  # execute 16 instead of 36 multiplies per 2x2 tile
+WINOGRAD_F4 = ('conv3x3_winograd_f4_kernel',)  # F(4x4,3x3): 36 instead of 144 multiplies per 4x4 tile
 
 
 def parse():
@@ -139,6 +140,8 @@ def _is_mfma(name):
 
 
 def _executed(name, flops):
+    if name.startswith(WINOGRAD_F4):
+        return flops / 4.0
     return flops / 2.25 if name.startswith(WINOGRAD) else flops
 
 
@@ -152,7 +155,7 @@ def kernel_table(per, steps, step_seconds):
         if _is_mfma(name) and flops > 0:
             ex = _executed(name, flops) / secs / 1e12
             row.update(bound='mfma', tflops_executed=round(ex, 2), frac_of_mfma_peak=round(ex / PEAK_F32_MFMA_TFLOPS, 4))
-            if name.startswith(WINOGRAD):
+            if name.startswith(WINOGRAD + WINOGRAD_F4):
                 row['tflops_algorithmic'] = round(flops / secs / 1e12, 2)
         else:
             gbps = nbytes / secs / 1e9
@@ -183,13 +186,15 @@ def roofline_object(per, steps, step_seconds, workload, default_batch):
     ex = _executed(name, flops) / secs / 1e12
     tr, tr_src = measured_traffic(workload, name) if default_batch else (None, None)
     wino = name.startswith(WINOGRAD)
+    f4 = name.startswith(WINOGRAD_F4)
     return {
         'bound': 'mfma', 'kernel': name, 'achieved': round(ex, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
         'frac': round(ex / PEAK_F32_MFMA_TFLOPS, 4),
         'definition': 'achieved = flops the fp32 matrix cores execute (v_mfma_f32_32x32x2_f32 issues x 4096) / HIP-event time of '
                       'the kernel; frac = achieved / peak',
-        'algorithm': 'winograd F(2x2,3x3), fp32: 16 instead of 36 multiplies per 2x2 tile and channel pair' if wino
-                     else 'direct implicit GEMM, fp32',
+        'algorithm': 'winograd F(4x4,3x3), fp32: 36 instead of 144 multiplies per 4x4 tile and channel pair' if f4
+                     else ('winograd F(2x2,3x3), fp32: 16 instead of 36 multiplies per 2x2 tile and channel pair' if wino
+                           else 'direct implicit GEMM, fp32'),
         # SURVEY 8(d) counts ALGORITHMIC flops (2*9*Ci*Co per output pixel); Winograd executes 1/2.25 of them, so this figure can
         # exceed the MFMA peak - it is the direct-algorithm-equivalent rate, not a roofline fraction:
         'algorithmic_tflops': round(flops / secs / 1e12, 2),

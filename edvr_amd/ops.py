@@ -5,6 +5,7 @@ function launches hand-written HIP kernels from libedvr_amd.so on
 ``torch.cuda.current_stream()`` and never synchronises.
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -124,6 +125,7 @@ def invalidate_packed_weights():
 DCN_SCATTER_AUTO, DCN_SCATTER_DEVICE, DCN_SCATTER_LDS, DCN_SCATTER_STRIP = 0, 1, 2, 3  # include/edvr_amd.h EDVR_DCN_SCATTER_*
 LAUNCH_HOOK = None  # callable(kernel_name, algorithmic_flops, launch_fn, algorithmic_bytes) or None
 CONV_ALGO = CONV_AUTO  # default algorithm request of conv2d(); tests flip it to cover both kernels on every shape
+F4_INFERENCE = os.environ.get('EDVR_WINOGRAD_F4', '1') != '0'  # functional.conv hands the F(4x4,3x3) weights to no-grad convs
 
 
 def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NONE, act_from=0, res1=None, res2=None,
