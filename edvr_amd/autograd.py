@@ -20,7 +20,8 @@ class ConvFn(Function):
         x2_map, act, act_from, out_mode, ks, stride, y_scale = cfg
         wpk = ops.pack_conv_weight(weight)
         y = ops.conv2d(x, wpk, bias.detach() if bias is not None else None, weight.shape[0], ks, x2=x2, x2_map=x2_map, stride=stride,
-                       act=act, act_from=act_from, res1=res1, res2=res2, out_mode=out_mode, y_scale=y_scale)
+                       act=act, act_from=act_from, res1=res1, res2=res2, out_mode=out_mode, y_scale=y_scale,
+                       wpk_f4=ops.f4_weight(weight, ks) if stride == 1 else None)
         if y_scale != 1.0 and act != ACT_NONE:
             raise NotImplementedError('y_scale together with a fused activation has no backward (not used by EDVR)')
         keep_y = act != ACT_NONE
@@ -57,7 +58,8 @@ class ConvFn(Function):
             c1 = x.shape[1]
             z = ops.zero_stuff2(dz, x.shape[2], x.shape[3]) if stride == 2 else dz
             wt = ops.pack_conv_weight(weight, transpose_flip=True)
-            dcat = ops.conv2d(z, wt, None, weight.shape[1], ks, y_scale=y_scale)  # data gradient = stride-1 conv with flipped W^T
+            dcat = ops.conv2d(z, wt, None, weight.shape[1], ks, y_scale=y_scale,  # data gradient = stride-1 conv with flipped W^T
+                              wpk_f4=ops.f4_weight(weight, ks, transpose_flip=True))
             if need[0]:
                 dx = dcat[:, :c1] if x2 is not None else dcat
             if x2 is not None and need[1]:
@@ -81,8 +83,9 @@ class ResBlockFn(Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, res_scale=1.0):
         c = w1.shape[0]
-        h = ops.conv2d(x, ops.pack_conv_weight(w1), b1.detach() if b1 is not None else None, c, 3, act=ACT_RELU)
-        y = ops.conv2d(h, ops.pack_conv_weight(w2), b2.detach() if b2 is not None else None, c, 3, res1=x, y_scale=res_scale)
+        h = ops.conv2d(x, ops.pack_conv_weight(w1), b1.detach() if b1 is not None else None, c, 3, act=ACT_RELU, wpk_f4=ops.f4_weight(w1, 3))
+        y = ops.conv2d(h, ops.pack_conv_weight(w2), b2.detach() if b2 is not None else None, c, 3, res1=x, y_scale=res_scale,
+                       wpk_f4=ops.f4_weight(w2, 3))
         ctx.save_for_backward(x, h, w1, w2)
         ctx.has_bias = (b1 is not None, b2 is not None)
         ctx.res_scale = float(res_scale)
@@ -103,11 +106,13 @@ class ResBlockFn(Function):
                 dw2.mul_(s)
                 db2.mul_(s)
         # d(pre-activation of conv1) = s * (W2^T * dy) gated by relu'(z1) = [h > 0]
-        dz1 = ops.conv2d(dy, ops.pack_conv_weight(w2, transpose_flip=True), None, c, 3, gate=h, gate_slope=0.0, y_scale=s)
+        dz1 = ops.conv2d(dy, ops.pack_conv_weight(w2, transpose_flip=True), None, c, 3, gate=h, gate_slope=0.0, y_scale=s,
+                         wpk_f4=ops.f4_weight(w2, 3, transpose_flip=True))
         if need[1] or (need[2] and ctx.has_bias[0]):
             dw1, db1 = ops.conv2d_wgrad(x, None, None, dz1, c, 3, 1, want_db=True)
         if need[0]:
-            dx = ops.conv2d(dz1, ops.pack_conv_weight(w1, transpose_flip=True), None, c, 3, res1=dy)  # + identity branch
+            dx = ops.conv2d(dz1, ops.pack_conv_weight(w1, transpose_flip=True), None, c, 3, res1=dy,  # + identity branch
+                            wpk_f4=ops.f4_weight(w1, 3, transpose_flip=True))
         return (dx, dw1 if need[1] else None, db1 if (need[2] and ctx.has_bias[0]) else None, dw2 if need[3] else None,
                 db2 if (need[4] and ctx.has_bias[1]) else None, None)
 

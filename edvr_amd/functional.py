@@ -37,9 +37,9 @@ def conv(m, x, *, x2=None, x2_map=None, act=ACT_NONE, act_from=0, res1=None, res
         from . import autograd as ag
         return ag.conv(m, x, x2, x2_map, act, act_from, res1, res2, out_mode, ks, stride, y_scale)
     wpk = ops.pack_conv_weight(m.weight)
-    # inference only: the F(4x4,3x3) Winograd weights let the C side pick that kernel where it is the fastest (2.25 instead of 4
-    # multiplies per output, rounding ~1e-6 of the output scale instead of ~2e-7; EDVR_WINOGRAD_F4=0 switches it off).  The
-    # training path above stays on F(2x2): its gradient parity tests are pinned at 1e-5.
+    # the F(4x4,3x3) Winograd weights let the C side pick that kernel where it is the fastest (2.25 instead of 4 multiplies per
+    # output, rounding ~1e-6 of the output scale instead of ~2e-7; EDVR_WINOGRAD_F4=0 switches it off here,
+    # EDVR_WINOGRAD_F4_TRAIN=0 in the training path above)
     wf4 = ops.pack_conv_weight(m.weight, f4=True) if (ops.F4_INFERENCE and ks == 3 and stride == 1 and m.in_channels >= 32
                                                       and m.out_channels >= 48) else None
     bias = m.bias.detach() if m.bias is not None else None

@@ -114,6 +114,14 @@ def pack_conv_weight(weight, transpose_flip=False, f4=False):
     return out
 
 
+def f4_weight(weight, ks, transpose_flip=False):
+    """The F(4x4,3x3) packing of a 3x3 weight for the training path, or None when that path is off / the layer too small."""
+    if not F4_TRAINING or ks != 3:
+        return None
+    co, ci = (weight.shape[1], weight.shape[0]) if transpose_flip else (weight.shape[0], weight.shape[1])
+    return pack_conv_weight(weight, transpose_flip=transpose_flip, f4=True) if (ci >= 32 and co >= 48) else None
+
+
 def invalidate_packed_weights():
     """Drop every cached packed weight.  The cache follows a parameter's autograd version and storage pointer, which in-place
     torch ops, optimizers and load_state_dict maintain; a write through `.data` (or through a raw pointer that does not call
@@ -126,6 +134,8 @@ DCN_SCATTER_AUTO, DCN_SCATTER_DEVICE, DCN_SCATTER_LDS, DCN_SCATTER_STRIP = 0, 1,
 LAUNCH_HOOK = None  # callable(kernel_name, algorithmic_flops, launch_fn, algorithmic_bytes) or None
 CONV_ALGO = CONV_AUTO  # default algorithm request of conv2d(); tests flip it to cover both kernels on every shape
 F4_INFERENCE = os.environ.get('EDVR_WINOGRAD_F4', '1') != '0'  # functional.conv hands the F(4x4,3x3) weights to no-grad convs
+F4_TRAINING = os.environ.get('EDVR_WINOGRAD_F4_TRAIN', '1') != '0'  # autograd.py: forward and data-gradient convs too (-11 % per iteration;
+#                                                                   the gradient parity tests hold at their 1e-5 bounds)
 
 
 def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NONE, act_from=0, res1=None, res2=None,

@@ -27,5 +27,5 @@ for slot in range(nslots):
           ' | cons ' + ' '.join(f'{a - min(rel):6d}' for a in arr[4:]))
     if slot >= 1:
         prev_rel = min(buf[((slot - 1) * 16 + wv) * 2 + 1] - t0 for wv in range(16))
-        print('      producer stamps after previous release (dma-wait, patch-read, dma-issue, transforms, arrival): ' +
+        print('      producer stamps after previous release (patches-in-regs, dma-issued, transformed+written, dma-landed, arrival): ' +
               ' | '.join(' '.join(f'{bufp[(slot * 4 + wv) * 4 + i] - t0 - prev_rel:5d}' for i in range(4)) + f' {arr[wv] - prev_rel:5d}' for wv in range(4)))
