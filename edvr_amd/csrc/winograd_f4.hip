@@ -18,13 +18,13 @@
 //     (U) belong to exactly one wave each, so they come straight from global memory - one 16-byte and one 8-byte buffer load per
 //     six MFMAs, packed so that a wave reads 1.5 KB contiguous - two k-steps ahead.  No staging stall ever sits on a wave that
 //     issues MFMAs.
-//   * 4 producer waves (one per SIMD): the raw input rows of a wave's two channels arrive by LDS-DMA in two 6 KB regions
-//     private to the wave (requested two chunks ahead); thread = (channel of the 8-channel chunk, tile) reads its 6x6 patch from there,
+//   * 4 producer waves (one per SIMD): the raw input rows of a wave's two channels arrive by LDS-DMA in a 6 KB region private
+//     to the wave (requested one chunk ahead); thread = (channel of the 8-channel chunk, tile) reads its 6x6 patch from there,
 //     applies B^T . B and writes the 36 positions to the double-buffered V slab (2 x 36 KB).  They also own everything that
 //     touches the output:
-//     after the consumers' row pass (T = M A, written to a double-buffered 2 x 12 KB exchange area in sixteen 4-channel phases)
+//     after the consumers' row pass (T = M A, written to a double-buffered 2 x 24 KB exchange area in eight 8-channel phases)
 //     they finish Y = A^T T, apply bias / activation / residuals / gate / PixelShuffle and store 16-byte rows.
-//   One barrier per chunk (LDS only) + 16 per item.
+//   One barrier per chunk (LDS only) + 8 per item.
 #include <cstdlib>
 #include <type_traits>
 
@@ -46,7 +46,7 @@ struct WinoF4Args {
 #ifdef F4_EXP_NOEPI /* ablation: no output transform / stores */
 #define F4_EPI_PHASES 0
 #else
-#define F4_EPI_PHASES 16
+#define F4_EPI_PHASES 8
 #endif
 #define F4_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
@@ -63,11 +63,10 @@ __device__ long long f4_trace_p[4 * 4 * 512];  // producers: after the DMA wait,
     if (blockIdx.x == 0 && (slot) < 512 && (threadIdx.x & 63) == 0)                                            \
       f4_trace[((slot) * 16 + (threadIdx.x >> 6)) * 2 + f4_tr_ph] = __builtin_readcyclecounter();              \
   } while (0)
-#define F4_BARRIER_T() F4_BARRIER_TN("0")
-#define F4_BARRIER_TN(N) \
+#define F4_BARRIER_T()   \
   do {                   \
     int f4_tr_ph = 0;    \
-    asm volatile("s_waitcnt lgkmcnt(" N ")" ::: "memory"); \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
     F4_STAMP(f4_slot);   \
     asm volatile("s_barrier" ::: "memory"); \
     f4_tr_ph = 1;        \
@@ -76,16 +75,15 @@ __device__ long long f4_trace_p[4 * 4 * 512];  // producers: after the DMA wait,
   } while (0)
 #else
 #define F4_BARRIER_T() F4_LDS_BARRIER()
-#define F4_BARRIER_TN(N) asm volatile("s_waitcnt lgkmcnt(" N ")\n\ts_barrier" ::: "memory")
 #define F4_PSTAMP(i)
 #endif
 
 __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const WinoF4Args a) {
   constexpr int CK = 8;
   constexpr int VSLAB = CK * 36 * 32;   // floats per V stage (36 KB): [channel 8][position 36][tile 32]
-  constexpr int XSZ = 2 * 6 * 4 * 32 * 4;  // exchange area (2 x 12 KB): [phase parity][row 6][channel 4][tile 32][4]
+  constexpr int XSZ = 2 * 6 * 8 * 32 * 4;  // exchange area (2 x 24 KB): [phase parity][row 6][channel 8][tile 32][4]
   constexpr int RWAVE = 6 * 64 * 4 + 4;     // raw-input region of one producer wave: 6 DMA instructions x 64 lanes x 16 B, + one-dword shift (below)
-  __shared__ __attribute__((aligned(16))) float smem[2 * VSLAB + XSZ + 8 * RWAVE];  // 72 + 24 + 48 KB
+  __shared__ __attribute__((aligned(16))) float smem[2 * VSLAB + XSZ + 4 * RWAVE];  // 144 KB
   float *const Xs = smem + 2 * VSLAB;
 
   const edvr_conv2d_desc &d = a.d;
@@ -137,7 +135,7 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
     // texture addresser, 4160 L1 accesses per chunk and CU, address path 50 % busy: 1.24 ms where the MFMAs need 0.55.)
     typedef __attribute__((address_space(3))) void lvoid;
     constexpr int OOB = (int)0x80000000;
-    float *const Rw = smem + 2 * VSLAB + XSZ + wave * 2 * RWAVE;  // two regions: chunk parity
+    float *const Rw = smem + 2 * VSLAB + XSZ + wave * RWAVE;
     int dma_off[6];
     const float *x1 = d.x1, *x2 = d.x1;
     int l_item = item_first, l_k = 0;  // load cursor: (item, chunk) the NEXT request belongs to
@@ -157,31 +155,19 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
         dma_off[i] = (q < 360 && gy >= 0 && gy < d.h && gx >= 0 && gx < d.w) ? (ch * hw + gy * d.w + gx) * 4 : OOB;
       }
     };
-    // The requests are issued from inline assembly: the compiler orders every LDS read after ALL outstanding LDS-DMA it knows of
-    // (s_waitcnt vmcnt(0) at the top of the step - the whole DMA latency back on the critical path).  Untracked requests can only
-    // make its own vmcnt waits stricter (memory operations retire in order), never too weak; the waits for the requests
-    // themselves are written by hand below.
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    i32x4 ld_rsrc = {0, 0, 0, RSRC_FLAGS};
+    __amdgpu_buffer_rsrc_t ld_rsrc = uniform_rsrc(d.x1, 0);
     auto load_begin = [&](int c0) {
       const int c = c0 + 2 * wave;  // even; c1 is even when there is an x2 (host check): the pair never straddles x1 / x2
       const float *pl = (c < d.c1) ? (x1 + (int64_t)c * hw) : (x2 + (int64_t)(c - d.c1) * hw);
       const int nvalid = a.ci_real - c;  // channels of the padding: empty (or one-plane) buffer, their loads return 0
-      const uint64_t pv = reinterpret_cast<uint64_t>(pl);
-      ld_rsrc[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)pv);
-      ld_rsrc[1] = __builtin_amdgcn_readfirstlane((int)(pv >> 32)) & 0xffff;
-      ld_rsrc[2] = nvalid >= 2 ? 2 * plane_bytes : (nvalid == 1 ? plane_bytes : 0);
+      ld_rsrc = uniform_rsrc(pl, nvalid >= 2 ? 2 * plane_bytes : (nvalid == 1 ? plane_bytes : 0));
     };
-    const unsigned rw_lds = (unsigned)(size_t)(lvoid *)(Rw + 1);  // LDS byte address of region 0 (+ the one-dword shift)
-    auto dma_issue = [&](int reg) {
+    auto dma_issue = [&]() {
 #ifdef F4_EXP_NODMA /* ablation (wrong results): no input fetch at all */
       return;
 #endif
-      const unsigned base = rw_lds + reg * (RWAVE * 4);
 #pragma unroll
-      for (int i = 0; i < 6; ++i)
-        asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(base + i * 1024), "v"(dma_off[i]), "s"(ld_rsrc)
-                     : "memory", "m0");
+      for (int i = 0; i < 6; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(ld_rsrc, (lvoid *)(Rw + 1 + i * 256), 16, dma_off[i], 0, 0, 0);
     };
     // The input transform runs on PACKED fp32 math (v_pk_fma_f32 / v_pk_add_f32: two lanes of work per instruction): vector
     // instructions of the staging waves take issue slots from the MFMAs of the same SIMD, so their count is what matters
@@ -197,15 +183,20 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
     // p_tx (columns 4 p_tx + 3 .. + 8) starts at the 16-byte aligned dword 4 p_tx + 4: one b128 + one b64 read per row, already
     // paired the way the packed transform wants them (no moves).
     const float *patch = Rw + ((half * 10 + 4 * p_ty) * 18 + p_tx) * 4 + 4;  // patch row r, column c: patch[r * 72 + c]
-    auto read_patch = [&](int reg) {  // issues the reads only: the caller waits (lgkmcnt) before it uses pp
-      const float *q = patch + reg * RWAVE;
+    auto read_patch = [&]() {
+#ifndef F4_EXP_NOWAIT /* ablation (wrong results): do not wait for the DMA */
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the requested chunk is in the region
+#endif
+      F4_PSTAMP(0);
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
-        const f32x4 m = *reinterpret_cast<const f32x4 *>(q + r * 72);
+        const f32x4 m = *reinterpret_cast<const f32x4 *>(patch + r * 72);
         pp[r][0] = f32x2{m[0], m[1]};
         pp[r][1] = f32x2{m[2], m[3]};
-        pp[r][2] = *reinterpret_cast<const f32x2 *>(q + r * 72 + 4);
+        pp[r][2] = *reinterpret_cast<const f32x2 *>(patch + r * 72 + 4);
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and in registers: the region may be overwritten
+      F4_PSTAMP(1);
     };
     auto transform_cols = [&](int cp) {  // 1-D input transform B^T (Lavin & Gray), 12 operations (a * b + c contracts to an fma)
       const f32x2 d0 = pp[0][cp], d1 = pp[1][cp], d2 = pp[2][cp], d3 = pp[3][cp], d4 = pp[4][cp], d5 = pp[5][cp];
@@ -218,14 +209,6 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
       tp[5][cp] = 4.f * d1 + (d5 - 5.f * d3);
     };
     auto commit_row = [&](float *Vd, int r) {  // positions (r, 0..5) of (B^T d) B
-#ifdef F4_EXP_HALFVALU /* ablation (wrong results): no row transform - half the vector work of the staging waves */
-      {
-        float *dst = Vd + ((2 * wave + half) * 36 + r * 6) * 32 + j;
-        dst[0 * 32] = tp[r][0][0]; dst[1 * 32] = tp[r][0][1]; dst[2 * 32] = tp[r][1][0];
-        dst[3 * 32] = tp[r][1][1]; dst[4 * 32] = tp[r][2][0]; dst[5 * 32] = tp[r][2][1];
-        return;
-      }
-#endif
       const f32x2 P0 = tp[r][0], P1 = tp[r][1], P2 = tp[r][2];
       const f32x2 lo1 = __builtin_shufflevector(P1, P1, 0, 0), hi1 = __builtin_shufflevector(P1, P1, 1, 1);  // d2, d3
       const f32x2 lo2 = __builtin_shufflevector(P2, P2, 0, 0), hi0 = __builtin_shufflevector(P0, P0, 1, 1);  // d4, d1
@@ -251,65 +234,48 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
       }
     };
 
-    // Pipeline of the staging waves, three chunks deep: in step k (the consumers multiply chunk k) the patch registers hold
-    // chunk k + 1 (read from its region at the end of step k - 1), chunk k + 2 is landing in the other region and chunk k + 3 is
-    // requested into the region just freed.  Neither the DMA latency nor the LDS read latency sits on the path to the barrier.
-    // ---- prologue: chunks 0 and 1 requested; chunk 0 -> registers -> stage 0; chunk 2 requested; chunk 1 -> registers
+    // ---- prologue: chunk 0 -> region -> registers -> stage 0; chunk 1 requested
     setup(item_first);
     load_begin(0);
-    dma_issue(0);
+    dma_issue();
+    read_patch();
     advance();
     load_begin(l_k * CK);
-    dma_issue(1);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // chunk 0 is in region 0
-    read_patch(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    dma_issue();
 #pragma unroll
     for (int cp = 0; cp < 3; ++cp) transform_cols(cp);
 #pragma unroll
     for (int r = 0; r < 6; ++r) commit_row(smem, r);
-    advance();
-    load_begin(l_k * CK);
-    dma_issue(0);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // chunk 1 is in region 1
-    read_patch(1);
     F4_BARRIER_T();
 
     int par = 0;  // stage the consumers read during the current step
-    int rg = 1;   // region the patch registers were read from (free once the reads have landed)
     for (int item = item_first; item < item_end; item += xcd_wgs) {
       int e_co_blk, e_img, e_ty0, e_tx0;
       decode(item, e_co_blk, e_img, e_ty0, e_tx0);
 #pragma unroll 1
       for (int k = 0; k < n_chunks; ++k) {
+        // the region holds chunk k + 1 (chunk 0 of the next item at the end): patches -> registers, request chunk k + 2,
+        // transform into the idle stage
         float *Vd = smem + (par ^ 1) * VSLAB;
 #ifndef F4_EXP_NOPROD  /* ablation: the producers only keep the barrier count */
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the patches of chunk k + 1 are in registers, their region is free
-        F4_PSTAMP(0);
+        read_patch();
         advance();
         load_begin(l_k * CK);
-        dma_issue(rg);  // chunk k + 3
-        F4_PSTAMP(1);
+        dma_issue();
+        F4_PSTAMP(2);
 #pragma unroll
         for (int cp = 0; cp < 3; ++cp) transform_cols(cp);
 #pragma unroll
         for (int r = 0; r < 6; ++r) commit_row(Vd, r);
-        F4_PSTAMP(2);
-        rg ^= 1;
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // everything but the request just issued has landed: chunk k + 2
         F4_PSTAMP(3);
-        read_patch(rg);
-        F4_BARRIER_TN("12");  // the stage is written (LDS operations complete in order; the 12 patch reads may still be out)
-#else
-        F4_BARRIER_T();
 #endif
+        F4_BARRIER_T();
         par ^= 1;
       }
 
-      // ---- column pass Y = A^T T + epilogue + stores: 16 phases (one accumulator register of the consumers each = 4 output
-      //      channels over the two channel halves), thread = (channel, tile, column pair).  The exchange area is double-buffered:
-      //      the consumers write phase p + 1 while phase p is read here (one barrier per phase).  Bias and residual / gate rows
-      //      of phase p + 1 are requested as soon as those of phase p are consumed.
+      // ---- column pass Y = A^T T + epilogue + stores: 8 phases of 8 output channels, one (channel, tile) per thread and phase.
+      //      The exchange area is double-buffered: the consumers write phase p + 1 while phase p is read here (one barrier per
+      //      phase).  Bias and residual / gate rows of phase p + 1 are requested as soon as those of phase p are consumed.
       const int plane = hw;
       float *y = d.y + (int64_t)e_img * d.y_img_stride;
       const float *r1 = d.res1 ? d.res1 + (int64_t)e_img * d.res1_img_stride : nullptr;
@@ -318,78 +284,106 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
       const float *rq = gt ? gt : r1;  // the tensor read per output element (gate and residuals exclude each other)
       const float slope = d.act == EDVR_ACT_LRELU ? 0.1f : (d.act == EDVR_ACT_RELU ? 0.f : 1.f);  // none/relu/lrelu = max(v, slope*v)
       const bool sig = d.act == EDVR_ACT_SIGMOID, shuffle = d.out_mode == EDVR_OUT_PIXEL_SHUFFLE2;
-      const bool vec = !shuffle && e_ty0 + 8 <= d.h && e_tx0 + 64 <= d.w;  // whole rows of the block inside the image (w % 4 == 0)
-      const int cl4 = wave, tile = (lane >> 1), jh = lane & 1;
-      const int oy = e_ty0 + 4 * (tile >> 4), ox = e_tx0 + 4 * (tile & 15) + 2 * jh;
-      const int co_t = e_co_blk + (cl4 >> 1) * 32 + 4 * (cl4 & 1);  // + (p & 3) + 8 (p >> 2) in phase p
+      const bool vec = e_tx0 + 64 <= d.w;  // the block is inside the image in x (w % 4 == 0): 16-byte rows, only the ROW is tested
+      const int cl8 = tid >> 5, tile = tid & 31;
+      const int oy = e_ty0 + 4 * (tile >> 4), ox = e_tx0 + 4 * (tile & 15);
+      const int co_t = e_co_blk + (cl8 >> 2) * 32 + 4 * ((cl8 >> 1) & 1) + 8 * (cl8 & 1);  // + (p & 3) + 16 (p >> 2) in phase p
       const int pix = oy * d.w + ox;
-      auto column_pass = [&](auto VEC) {
-        constexpr bool V = decltype(VEC)::value;  // aligned 8-byte pairs inside the image, NCHW: no per-element tests
-        constexpr int NP = (F4_EPI_PHASES);
-        auto co_of = [&](int p) { return co_t + (p & 3) + 8 * (p >> 2); };
-        // every global read of the epilogue is requested well ahead of its use: the bias of all 16 phases up front, residual /
-        // gate rows two phases ahead
-        float bias_r[NP > 0 ? NP : 1];
-#pragma unroll
-        for (int p = 0; p < NP; ++p) bias_r[p] = d.bias ? d.bias[min(co_of(p), d.co - 1)] : 0.f;
-        constexpr int RD = 2;  // residual prefetch depth (phases)
-        f32x2 rr[RD][4];
-        auto load_rr = [&](int p, int slot) {  // rows oy .. oy + 3 of the residual(s) / gate of channel co_of(p)
-          if (!(V && rq)) return;
+      const int rows_in = d.h - oy;  // rows of this lane's tile inside the image (>= 4: all of them)
+      auto column_pass = [&](auto VEC, auto SHUF) {
+        constexpr bool V = decltype(VEC)::value;     // whole 16-byte rows inside the image in x: no per-element tests
+        constexpr bool SHF = decltype(SHUF)::value;  // V && PixelShuffle(2): channels 2 q, 2 q + 1 (consecutive phases of this thread)
+                                                     // interleave along x - two 16-byte stores per row and channel pair
+        f32x4 Yprev[4];
+        f32x4 rr[4];
+        float b_next = 0.f;
+        auto co_of = [&](int p) { return co_t + (p & 3) + 16 * (p >> 2); };
+        auto prefetch = [&](int p) {  // bias and (V) rows oy .. oy + 3 of the residual(s) / gate of channel co_of(p)
           const int co = min(co_of(p), d.co - 1);
-          const float *q1 = rq + (int64_t)co * plane + pix;
+          b_next = d.bias ? d.bias[co] : 0.f;
+          if (V && !SHF && rq) {
+            const float *q1 = rq + (int64_t)co * plane + pix;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) rr[slot][i] = *reinterpret_cast<const f32x2 *>(q1 + i * d.w);
-          if (r2) {
-            const float *q2 = r2 + (int64_t)co * plane + pix;
+            for (int i = 0; i < 4; ++i) rr[i] = i < rows_in ? *reinterpret_cast<const f32x4 *>(q1 + i * d.w) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r2) {
+              const float *q2 = r2 + (int64_t)co * plane + pix;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rr[slot][i] += *reinterpret_cast<const f32x2 *>(q2 + i * d.w);
+              for (int i = 0; i < 4; ++i)
+                if (i < rows_in) rr[i] += *reinterpret_cast<const f32x4 *>(q2 + i * d.w);
+            }
           }
         };
+        prefetch(0);
+#pragma unroll 1
+        for (int p = 0; p < (F4_EPI_PHASES); ++p) {
+          F4_BARRIER_T();  // T of this phase is in its half of the exchange area
+          const float *Xb = Xs + (p & 1) * (XSZ / 2) + (cl8 * 32 + tile) * 4;
+          f32x4 T[6];
 #pragma unroll
-        for (int p = 0; p < RD && p < NP; ++p) load_rr(p, p);
-        f32x2 Y[4];
-        // finish(p): activation, residual / gate, stores of the phase whose Y is in registers - run AFTER the reads of the next
-        // phase have been issued, in the shadow of their LDS latency
-        auto finish = [&](int p) {
+          for (int r = 0; r < 6; ++r) T[r] = *reinterpret_cast<const f32x4 *>(Xb + r * (8 * 32 * 4));
           const int co = co_of(p);
+          const float b = b_next;
           const float sl = co >= d.act_from ? slope : 1.f;
+          f32x4 Y[4];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {  // A^T along the rows (6 -> 4), + bias
+            const float s1 = T[1][jj] + T[2][jj], d1 = T[1][jj] - T[2][jj], s2 = T[3][jj] + T[4][jj], d2 = T[3][jj] - T[4][jj];
+            Y[0][jj] = T[0][jj] + s1 + s2 + b;
+            Y[1][jj] = __builtin_fmaf(2.f, d2, d1) + b;
+            Y[2][jj] = __builtin_fmaf(4.f, s2, s1) + b;
+            Y[3][jj] = __builtin_fmaf(8.f, d2, d1) + T[5][jj] + b;
+          }
           if (sig) {
             if (co >= d.act_from) {
 #pragma unroll
               for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj) Y[i][jj] = __builtin_amdgcn_rcpf(1.f + __expf(-Y[i][jj]));
+                for (int jj = 0; jj < 4; ++jj) Y[i][jj] = __builtin_amdgcn_rcpf(1.f + __expf(-Y[i][jj]));
             }
           } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-              for (int jj = 0; jj < 2; ++jj) Y[i][jj] = fmaxf(Y[i][jj], sl * Y[i][jj]);
+              for (int jj = 0; jj < 4; ++jj) Y[i][jj] = fmaxf(Y[i][jj], sl * Y[i][jj]);
           }
-          if (V) {
+          if (SHF) {
+            if ((p & 1) == 0) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) Yprev[i] = Y[i];
+            } else if (co < d.co) {  // co odd; co - 1 is in Yprev.  Output plane co >> 2, row 2 y + ((co >> 1) & 1), columns 2 x + (co & 1)
+              float *q = y + (int64_t)(co >> 2) * plane * 4 + (2 * oy + ((co >> 1) & 1)) * (2 * d.w) + 2 * ox;
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                if (i < rows_in) {
+                  *reinterpret_cast<f32x4 *>(q + i * 4 * d.w) = f32x4{Yprev[i][0], Y[i][0], Yprev[i][1], Y[i][1]};
+                  *reinterpret_cast<f32x4 *>(q + i * 4 * d.w + 4) = f32x4{Yprev[i][2], Y[i][2], Yprev[i][3], Y[i][3]};
+                }
+            }
+          } else if (V) {
             if (gt) {
 #pragma unroll
               for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj) Y[i][jj] *= rr[p % RD][i][jj] > 0.f ? a.ys : a.ys_gs;
+                for (int jj = 0; jj < 4; ++jj) Y[i][jj] *= rr[i][jj] > 0.f ? a.ys : a.ys_gs;
             } else if (r1) {
 #pragma unroll
-              for (int i = 0; i < 4; ++i) Y[i] = Y[i] * a.ys + rr[p % RD][i];
+              for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) Y[i][jj] = __builtin_fmaf(Y[i][jj], a.ys, rr[i][jj]);
             }
             if (co < d.co) {
               float *q = y + (int64_t)co * plane + pix;
 #pragma unroll
-              for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x2 *>(q + i * d.w) = Y[i];
+              for (int i = 0; i < 4; ++i)
+                if (i < rows_in) *reinterpret_cast<f32x4 *>(q + i * d.w) = Y[i];
             }
-            if (p + RD < NP) load_rr(p + RD, p % RD);
           } else if (co < d.co) {
 #pragma unroll 1
             for (int i = 0; i < 4; ++i) {
               if (oy + i >= d.h) break;
               const int64_t off = (int64_t)co * plane + pix + i * d.w;
 #pragma unroll
-              for (int jj = 0; jj < 2; ++jj) {
+              for (int jj = 0; jj < 4; ++jj) {
                 if (ox + jj < d.w) {
                   float o = Y[i][jj];
                   if (gt) o *= gt[off + jj] > 0.f ? a.ys : a.ys_gs;
@@ -402,31 +396,12 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
               }
             }
           }
-        };
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          F4_BARRIER_T();  // T of this phase is in its half of the exchange area
-          const float *Xb = Xs + (p & 1) * (XSZ / 2) + (cl4 * 32 + tile) * 4 + 2 * jh;
-          f32x2 T[6];
-#pragma unroll
-          for (int r = 0; r < 6; ++r) T[r] = *reinterpret_cast<const f32x2 *>(Xb + r * (4 * 32 * 4));
-          if (p > 0) finish(p - 1);
-          const float b = bias_r[p];
-          // A^T along the rows (6 -> 4), + bias, on column pairs
-          const f32x2 s1 = T[1] + T[2], d1 = T[1] - T[2], s2 = T[3] + T[4], d2 = T[3] - T[4];
-          Y[0] = T[0] + s1 + s2 + b;
-          Y[1] = d1 + 2.f * d2 + b;
-          Y[2] = s1 + 4.f * s2 + b;
-          Y[3] = d1 + 8.f * d2 + T[5] + b;
+          prefetch(min(p + 1, 7));  // consumed one phase later
         }
-        if (NP > 0) finish(NP - 1);
       };
-      if (vec) column_pass(std::true_type{});
-      else column_pass(std::false_type{});
-      // vmcnt(0), as the BUILTIN (the compiler's wait-count bookkeeping reads it): without it the loads / stores above count as
-      // possibly outstanding at the top of the chunk loop and the compiler puts a vmcnt(0) INSIDE the loop - which would wait
-      // for the hand-issued DMA every step.  Costs the completion of this item's last stores once per item.
-      __builtin_amdgcn_s_waitcnt(0x0F70);
+      if (vec && shuffle) column_pass(std::true_type{}, std::true_type{});
+      else if (vec) column_pass(std::true_type{}, std::false_type{});
+      else column_pass(std::false_type{}, std::false_type{});
     }
   } else {
     // =========================================================================================== consumers
@@ -507,19 +482,24 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
 #pragma unroll
       for (int c = 0; c < 6; ++c) asm volatile("" ::"v"(acc[c]));  // keep the MFMAs alive
 #endif
-      // ---- row pass T = M A (6 -> 4) and hand-over to the producers: 16 phases of one accumulator register (4 output channels
+      // ---- row pass T = M A (6 -> 4) and hand-over to the producers: 8 phases of two accumulator registers (8 output channels
       //      over the two channel halves), alternating halves of the exchange area
 #pragma unroll
       for (int p = 0; p < (F4_EPI_PHASES); ++p) {
         float *Xb = Xs + (p & 1) * (XSZ / 2);
-        const float m0 = acc[0][p], m1 = acc[1][p], m2 = acc[2][p], m3 = acc[3][p], m4 = acc[4][p], m5 = acc[5][p];
-        const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
-        f32x4 T;
-        T[0] = m0 + s1 + s2;
-        T[1] = __builtin_fmaf(2.f, d2, d1);
-        T[2] = __builtin_fmaf(4.f, s2, s1);
-        T[3] = __builtin_fmaf(8.f, d2, d1) + m5;
-        *reinterpret_cast<f32x4 *>(Xb + ((row * 4 + wm * 2 + half) * 32 + j) * 4) = T;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          const int r = (p & 3) + 4 * (2 * (p >> 2) + rr);  // consecutive phases of a staging thread are consecutive channels
+          const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r], m5 = acc[5][r];
+          const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+          f32x4 T;
+          T[0] = m0 + s1 + s2;
+          T[1] = __builtin_fmaf(2.f, d2, d1);
+          T[2] = __builtin_fmaf(4.f, s2, s1);
+          T[3] = __builtin_fmaf(8.f, d2, d1) + m5;
+          const int cl8 = wm * 4 + half * 2 + rr;
+          *reinterpret_cast<f32x4 *>(Xb + ((row * 8 + cl8) * 32 + j) * 4) = T;
+        }
         F4_BARRIER_T();  // phase p written (and phase p - 1 read: its half may be overwritten next)
       }
 #pragma unroll

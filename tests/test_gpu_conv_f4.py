@@ -32,6 +32,9 @@ CASES = [
     (2, 64, 0, 14, 40, 64, 'none', 0, 0, None, 0.1),          # gate (LeakyReLU backward) epilogue
     (2, 64, 0, 16, 40, 64, 'relu', 1, 0, None, None),         # residual + y_scale (set below)
     (1, 8, 0, 8, 64, 64, 'none', 0, 0, None, None),           # a single chunk per item
+    (1, 32, 0, 12, 64, 64, 'lrelu', 0, 1, None, None),        # pixel shuffle on the vector path, second block row half outside
+    (2, 32, 0, 10, 128, 64, 'relu', 2, 0, None, None),        # two residuals on the vector path, rows 10..15 of the second block row outside
+    (1, 64, 0, 6, 64, 128, 'none', 0, 0, None, 0.0),          # gate on the vector path, 6 rows
 ]
 
 
