@@ -557,8 +557,9 @@ __global__ void winograd_f4_weight_kernel(const float *__restrict__ w, float *__
 
 bool winograd_f4_enabled() {
   static const bool on = []() {
-    const char *e = getenv("EDVR_WINOGRAD_F4");  // "0": never (F(2x2) / direct everywhere)
-    return !(e && e[0] == '0');
+    const char *e = getenv("EDVR_WINOGRAD_F4");    // "0": never (F(2x2) / direct everywhere)
+    const char *w = getenv("EDVR_CONV_WINOGRAD");  // "0": always the direct kernel (winograd.hip) - this kernel follows it
+    return !(e && e[0] == '0') && !(w && w[0] == '0');
   }();
   return on;
 }
