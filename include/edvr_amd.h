@@ -78,7 +78,8 @@ int edvr_check_device(void);
  * edvr_conv2d_pack_weight_f32 (layout [ci_pad][ks*ks][co_pad], co fastest; for 3x3 kernels followed by the
  * Winograd-transformed weights G g G^T as [ci_pad][16][co_pad64]).  3x3 / stride-1 layers with >= 48 output channels
  * and w > 16 run as Winograd F(2x2,3x3) on the fp32 MFMA (2.25x fewer multiplies, fp32 throughout; set the
- * environment variable EDVR_CONV_WINOGRAD=0 to force the direct kernel). */
+ * environment variable EDVR_CONV_WINOGRAD=0 to force the direct kernel); with `wpk_f4` present, layers with w >= 48 and
+ * w % 4 == 0 run as Winograd F(4x4,3x3) (4x fewer multiplies; EDVR_WINOGRAD_F4=0 switches it off). */
 typedef struct edvr_conv2d_desc {
   const float *x1;        /* (n, c1, h, w) */
   const float *x2;        /* optional second input, concatenated after x1 on the channel axis */
@@ -118,7 +119,10 @@ size_t edvr_conv2d_packed_weight_elems(int co, int ci, int ks);
  * w'(ci, co, ks, ks) with w'[c][o][i][j] = w[o][c][ks-1-i][ks-1-j] (then `co`/`ci` refer to w'). */
 int edvr_conv2d_pack_weight_f32(const float *w, float *wpk, int co, int ci, int ks, int transpose_flip,
                                 edvr_stream_t stream);
-/* F(4x4,3x3) weights of a 3x3 conv: U = G g G^T in MFMA operand order, edvr_conv2d_packed_weight_f4_elems(co, ci) floats. */
+/* F(4x4,3x3) weights of a 3x3 conv: U = G g G^T in MFMA operand order, edvr_conv2d_packed_weight_f4_elems(co, ci) floats.
+ * Replaces: the algorithm / filter-transform choice cuDNN makes for the reference's 3x3 nn.Conv2d layers under
+ * torch.backends.cudnn.benchmark = True (basicsr/train.py:132; edvr_arch.py:24-71,190-244,322-352, arch_util.py:86-95).
+ * transpose_flip as in edvr_conv2d_pack_weight_f32 (data-gradient kernel). */
 size_t edvr_conv2d_packed_weight_f4_elems(int co, int ci);
 int edvr_conv2d_pack_weight_f4_f32(const float *w, float *wpk_f4, int co, int ci, int transpose_flip, edvr_stream_t stream);
 int edvr_conv2d_f32(const edvr_conv2d_desc *d, edvr_stream_t stream);
