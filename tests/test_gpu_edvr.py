@@ -14,12 +14,12 @@ def _rel(a, ref):
     return ((a.double().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
 
 
-@pytest.mark.parametrize('algo', ['direct', 'winograd'])
+@pytest.mark.parametrize('algo', ['direct', 'winograd', 'auto'])  # auto: F(4x4) Winograd wherever it applies (w >= 48, w % 4 == 0)
 @pytest.mark.parametrize('name', list(CONFIGS))
 def test_edvr_forward_matches_oracle(gpu, name, algo, monkeypatch):
     from edvr_amd import ops
     from oracle import edvr_oracle as EO
-    monkeypatch.setattr(ops, 'CONV_ALGO', {'direct': ops.CONV_DIRECT, 'winograd': ops.CONV_WINOGRAD}[algo])
+    monkeypatch.setattr(ops, 'CONV_ALGO', {'direct': ops.CONV_DIRECT, 'winograd': ops.CONV_WINOGRAD, 'auto': ops.CONV_AUTO}[algo])
     net, x, kwargs = build(name)
     sd64 = {k: v.double() for k, v in net.state_dict().items()}
     taps_ref = {}
@@ -59,3 +59,61 @@ def test_pcd_and_tsa_public_forward(gpu):
         want = EO.tsa_fusion(sd, 'f.', al.double(), 1)
         got = tsa.to(gpu)(al.to(gpu))
         assert _rel(got, want) < INTERMEDIATE_RTOL
+
+
+def _kernels_of(fn):
+    """Names of the kernels edvr_amd.ops launches while fn() runs (the measurement hook of bench.py)."""
+    from edvr_amd import ops
+    names = []
+
+    def hook(name, flops, launch, nbytes):
+        names.append(name)
+        launch()
+
+    ops.LAUNCH_HOOK = hook
+    try:
+        fn()
+        torch.cuda.synchronize()
+    finally:
+        ops.LAUNCH_HOOK = None
+    return names
+
+
+def test_default_paths_run_the_f4_kernel(gpu):
+    """No silent fallback: with default settings the 3x3 convs of a no-grad forward AND of a training step (forward + data
+    gradient) run on conv3x3_winograd_f4_kernel where it applies (here: the 32x48 level of EDVR-L / 7 frames)."""
+    net, x, _ = build('L_T7')
+    net = net.to(gpu)
+    xg = x.to(gpu)
+    with torch.no_grad():
+        infer = _kernels_of(lambda: net(xg))
+    assert infer.count('conv3x3_winograd_f4_kernel') >= 10, sorted(set(infer))
+    net.train()
+    train = _kernels_of(lambda: net(xg).sum().backward())
+    assert train.count('conv3x3_winograd_f4_kernel') >= 20, sorted(set(train))  # forward + data gradient
+
+
+def test_f4_switch_off(gpu):
+    """EDVR_WINOGRAD_F4=0 / EDVR_WINOGRAD_F4_TRAIN=0 (read at import): F(2x2) / direct kernels only."""
+    import os
+    import subprocess
+    import sys
+    code = '''
+import torch, sys
+sys.path.insert(0, "tests")
+from test_gpu_edvr import _kernels_of
+from util_edvr import build
+net, x, _ = build("L_T7")
+net = net.cuda(); x = x.cuda()
+with torch.no_grad():
+    a = _kernels_of(lambda: net(x))
+net.train()
+b = _kernels_of(lambda: net(x).sum().backward())
+assert "conv3x3_winograd_f4_kernel" not in a + b, sorted(set(a + b))
+assert "conv3x3_winograd_kernel" in a and "conv3x3_winograd_kernel" in b
+print("ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, EDVR_WINOGRAD_F4='0', EDVR_WINOGRAD_F4_TRAIN='0', PYTHONPATH=root),
+                       cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'ok' in r.stdout, r.stdout + r.stderr
