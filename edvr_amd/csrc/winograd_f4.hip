@@ -78,7 +78,14 @@ __device__ long long f4_trace_p[4 * 4 * 512];  // producers: after the DMA wait,
 #define F4_PSTAMP(i)
 #endif
 
+// TXL: log2 of the tiles per block row.  4: blocks of 2 x 16 tiles = 8 x 64 output pixels; 3: 4 x 8 tiles = 16 x 32 pixels, for
+// images whose width wastes much of a 64-pixel block (160 wide: 17 %, 80 wide: 37 %) and for 32-wide pyramid levels.
+template <int TXL>
 __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const WinoF4Args a) {
+  constexpr int TX = 1 << TXL, TY = 32 / TX;               // tiles per block row / rows
+  constexpr int BW = 4 * TX, BH = 4 * TY;                  // output pixels of a block
+  constexpr int RROWS = BH + 2, RPIECES = TX + 2;          // raw input rows / 16-byte pieces per row (columns tx0 - 4 .. tx0 + BW + 3)
+  static_assert(RROWS * RPIECES == 180, "a wave's region holds 2 x 180 pieces either way");
   constexpr int CK = 8;
   constexpr int VSLAB = CK * 36 * 32;   // floats per V stage (36 KB): [channel 8][position 36][tile 32]
   constexpr int XSZ = 2 * 6 * 8 * 32 * 4;  // exchange area (2 x 24 KB): [phase parity][row 6][channel 8][tile 32][4]
@@ -115,8 +122,8 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
     co_blk = __builtin_amdgcn_readfirstlane((item % co_blocks) * 64);
     const int tile_blk = __builtin_amdgcn_readfirstlane((item / co_blocks) % (a.tiles_x * a.tiles_y));
     img = __builtin_amdgcn_readfirstlane(item / (co_blocks * a.tiles_x * a.tiles_y));
-    ty0 = __builtin_amdgcn_readfirstlane((tile_blk / a.tiles_x) * 8);  // output-pixel origin of the 8 x 64 block
-    tx0 = __builtin_amdgcn_readfirstlane((tile_blk % a.tiles_x) * 64);
+    ty0 = __builtin_amdgcn_readfirstlane((tile_blk / a.tiles_x) * BH);  // output-pixel origin of the block
+    tx0 = __builtin_amdgcn_readfirstlane((tile_blk % a.tiles_x) * BW);
   };
 
   if (wave < 4) {
@@ -125,9 +132,9 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
     // per MFMA slot and was the last at every barrier).  With the higher priority its ~85 instructions per chunk go first and
     // the three MFMA waves fill the rest; its instruction count is what it costs.
     __builtin_amdgcn_s_setprio(3);
-    const int p_ty = j >> 4, p_tx = j & 15;  // tile j of the 2 x 16; channel 2 wave + half of the chunk
-    // Raw input of this wave's two channels for one chunk: [channel 2][row 10][18 x 16 B] = image rows ty0 - 1 .. ty0 + 8,
-    // columns tx0 - 4 .. tx0 + 67, fetched by LDS-DMA (buffer_load_dwordx4 ... lds: lane l of instruction i delivers 16-byte piece
+    const int p_ty = j >> TXL, p_tx = j & (TX - 1);  // tile j of the TY x TX; channel 2 wave + half of the chunk
+    // Raw input of this wave's two channels for one chunk: [channel 2][row BH + 2][(TX + 2) x 16 B] = image rows ty0 - 1 .. ty0 + BH,
+    // columns tx0 - 4 .. tx0 + BW + 3 (10 x 18 or 18 x 10 pieces), fetched by LDS-DMA (buffer_load_dwordx4 ... lds: lane l of instruction i delivers 16-byte piece
     // 64 i + l; pieces outside the image get an out-of-range offset and arrive as zeros = the padding).  The region is PRIVATE
     // to the wave - it alone reads the patches of these two channels - so no cross-wave ordering is needed: read the patches of
     // chunk k + 1, then request chunk k + 2 into the same place; it has the rest of the step to arrive.
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
       }
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
-        const int q = i * 64 + lane, ch = q / 180, rem = q - ch * 180, row = rem / 18, cx = rem - row * 18;
+        const int q = i * 64 + lane, ch = q / 180, rem = q - ch * 180, row = rem / RPIECES, cx = rem - row * RPIECES;
         const int gy = ty0 - 1 + row, gx = tx0 - 4 + 4 * cx;  // w % 4 == 0: a piece is inside or outside the row as a whole
         dma_off[i] = (q < 360 && gy >= 0 && gy < d.h && gx >= 0 && gx < d.w) ? (ch * hw + gy * d.w + gx) * 4 : OOB;
       }
@@ -182,7 +189,7 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
     // The DMA writes the pieces ONE DWORD into the region: column tx0 - 4 + k of a row lands at dword k + 1, so the patch of tile
     // p_tx (columns 4 p_tx + 3 .. + 8) starts at the 16-byte aligned dword 4 p_tx + 4: one b128 + one b64 read per row, already
     // paired the way the packed transform wants them (no moves).
-    const float *patch = Rw + ((half * 10 + 4 * p_ty) * 18 + p_tx) * 4 + 4;  // patch row r, column c: patch[r * 72 + c]
+    const float *patch = Rw + ((half * RROWS + 4 * p_ty) * RPIECES + p_tx) * 4 + 4;  // patch row r, column c: patch[r * 4 RPIECES + c]
     auto read_patch = [&]() {
 #ifndef F4_EXP_NOWAIT /* ablation (wrong results): do not wait for the DMA */
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the requested chunk is in the region
@@ -190,10 +197,10 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
       F4_PSTAMP(0);
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
-        const f32x4 m = *reinterpret_cast<const f32x4 *>(patch + r * 72);
+        const f32x4 m = *reinterpret_cast<const f32x4 *>(patch + r * (4 * RPIECES));
         pp[r][0] = f32x2{m[0], m[1]};
         pp[r][1] = f32x2{m[2], m[3]};
-        pp[r][2] = *reinterpret_cast<const f32x2 *>(patch + r * 72 + 4);
+        pp[r][2] = *reinterpret_cast<const f32x2 *>(patch + r * (4 * RPIECES) + 4);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and in registers: the region may be overwritten
       F4_PSTAMP(1);
@@ -284,9 +291,9 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
       const float *rq = gt ? gt : r1;  // the tensor read per output element (gate and residuals exclude each other)
       const float slope = d.act == EDVR_ACT_LRELU ? 0.1f : (d.act == EDVR_ACT_RELU ? 0.f : 1.f);  // none/relu/lrelu = max(v, slope*v)
       const bool sig = d.act == EDVR_ACT_SIGMOID, shuffle = d.out_mode == EDVR_OUT_PIXEL_SHUFFLE2;
-      const bool vec = e_tx0 + 64 <= d.w;  // the block is inside the image in x (w % 4 == 0): 16-byte rows, only the ROW is tested
+      const bool vec = e_tx0 + BW <= d.w;  // the block is inside the image in x (w % 4 == 0): 16-byte rows, only the ROW is tested
       const int cl8 = tid >> 5, tile = tid & 31;
-      const int oy = e_ty0 + 4 * (tile >> 4), ox = e_tx0 + 4 * (tile & 15);
+      const int oy = e_ty0 + 4 * (tile >> TXL), ox = e_tx0 + 4 * (tile & (TX - 1));
       const int co_t = e_co_blk + (cl8 >> 2) * 32 + 4 * ((cl8 >> 1) & 1) + 8 * (cl8 & 1);  // + (p & 3) + 16 (p >> 2) in phase p
       const int pix = oy * d.w + ox;
       const int rows_in = d.h - oy;  // rows of this lane's tile inside the image (>= 4: all of them)
@@ -586,7 +593,7 @@ bool winograd_f4_eligible(const edvr_conv2d_desc &d) {
   if (!winograd_f4_supported(d)) return false;
   if (d.algo == EDVR_CONV_WINOGRAD_F4) return true;  // explicit request: any size the kernel can do
   if (d.algo != EDVR_CONV_AUTO || !winograd_f4_enabled()) return false;
-  return d.co >= 48 && d.c1 + d.c2 >= 32 && d.w >= 48 && d.h >= 8;  // auto: only where it beats F(2x2)
+  return d.co >= 48 && d.c1 + d.c2 >= 32 && d.w >= 32 && d.h >= 8;  // auto: only where it beats F(2x2)
 }
 
 int winograd_f4_launch(const edvr_conv2d_desc &d, hipStream_t stream) {
@@ -598,8 +605,11 @@ int winograd_f4_launch(const edvr_conv2d_desc &d, hipStream_t stream) {
   a.cop = (d.co + 63) / 64 * 64;
   a.ys = d.y_scale == 0.f ? 1.f : d.y_scale;
   a.ys_gs = a.ys * d.gate_slope;
-  a.tiles_x = cdiv(d.w, 64);
-  a.tiles_y = cdiv(d.h, 8);
+  // block shape: the one that pads the image less (8 x 64 output pixels on ties)
+  const int64_t pad16 = (int64_t)cdiv(d.w, 64) * 64 * cdiv(d.h, 8) * 8, pad8 = (int64_t)cdiv(d.w, 32) * 32 * cdiv(d.h, 16) * 16;
+  const bool tx8 = pad8 < pad16;
+  a.tiles_x = cdiv(d.w, tx8 ? 32 : 64);
+  a.tiles_y = cdiv(d.h, tx8 ? 16 : 8);
   a.items = a.tiles_x * a.tiles_y * cdiv(d.co, 64) * d.n;
   static const int n_cu = []() {
     int dev = 0, n = 256;
@@ -608,7 +618,8 @@ int winograd_f4_launch(const edvr_conv2d_desc &d, hipStream_t stream) {
     return n;
   }();
   const dim3 grid(std::min(a.items, n_cu));
-  hipLaunchKernelGGL(conv3x3_winograd_f4_kernel, grid, dim3(1024), 0, stream, a);
+  if (tx8) hipLaunchKernelGGL(conv3x3_winograd_f4_kernel<3>, grid, dim3(1024), 0, stream, a);
+  else hipLaunchKernelGGL(conv3x3_winograd_f4_kernel<4>, grid, dim3(1024), 0, stream, a);
   return check_launch("conv3x3_winograd_f4_kernel");
 }
 

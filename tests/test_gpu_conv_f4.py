@@ -35,6 +35,9 @@ CASES = [
     (1, 32, 0, 12, 64, 64, 'lrelu', 0, 1, None, None),        # pixel shuffle on the vector path, second block row half outside
     (2, 32, 0, 10, 128, 64, 'relu', 2, 0, None, None),        # two residuals on the vector path, rows 10..15 of the second block row outside
     (1, 64, 0, 6, 64, 128, 'none', 0, 0, None, 0.0),          # gate on the vector path, 6 rows
+    (2, 64, 0, 32, 32, 64, 'lrelu', 1, 0, None, None),        # 16 x 32 blocks (4 x 8 tiles): a 32-wide pyramid level, residual
+    (1, 32, 0, 30, 160, 128, 'lrelu', 0, 1, None, None),      # 16 x 32 blocks: 160 wide, pixel shuffle, last block row 14 rows
+    (1, 128, 0, 23, 80, 64, 'relu', 2, 0, None, None),        # 16 x 32 blocks: 80 wide (third block column half outside), two residuals
 ]
 
 
