@@ -173,9 +173,14 @@ def measured_traffic(workload, kernel):
         if os.path.exists(path):
             rep = json.load(open(path))
             base = kernel.split('<')[0]
-            for k, v in rep['kernels'].items():
-                if k.split('<')[0].endswith(base) and v.get('hbm_bytes_per_launch'):
-                    return v, os.path.relpath(path, ROOT)
+            # every template instantiation of the kernel (e.g. the two block shapes of the F(4x4) kernel), weighted by launches
+            hits = [v for k, v in rep['kernels'].items() if k.split('<')[0].endswith(base) and v.get('hbm_bytes_per_launch')]
+            if hits:
+                n = sum(v['launches'] for v in hits)
+                agg = {f: sum(v[f] * v['launches'] for v in hits) / n
+                       for f in ('fetch_bytes_per_launch', 'write_bytes_per_launch', 'hbm_bytes_per_launch')}
+                agg['launches'] = n
+                return agg, os.path.relpath(path, ROOT)
     return None, None
 
 
