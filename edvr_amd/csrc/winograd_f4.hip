@@ -12,12 +12,12 @@
 //   U = G g G^T      packed once per weight version in MFMA operand order (winograd_f4_pack)
 //
 // Work split: wave-specialised 1024-thread workgroups, one per CU, persistent over items of 64 output channels x 32 tiles
-// (2 x 16 tiles = 8 x 64 output pixels):
+// (2 x 16 tiles = 8 x 64 output pixels, or 4 x 8 = 16 x 32 where that pads the image less: template parameter TXL):
 //   * 12 consumer waves = (32-channel half wm, transform row r): 6 accumulator tiles (32 co x 32 tiles, positions (r, 0..5)) =
 //     96 registers, three per SIMD.  Their loop is ds_read (B operand, shared by the two wm waves) + MFMA only; the A operands
 //     (U) belong to exactly one wave each, so they come straight from global memory - one 16-byte and one 8-byte buffer load per
-//     six MFMAs, packed so that a wave reads 1.5 KB contiguous - two k-steps ahead.  No staging stall ever sits on a wave that
-//     issues MFMAs.
+//     six MFMAs, packed so that a wave reads 1.5 KB contiguous - two k-steps ahead (a third set does not fit 128 registers).
+//     No staging instruction sits on a wave that issues MFMAs.
 //   * 4 producer waves (one per SIMD): the raw input rows of a wave's two channels arrive by LDS-DMA in a 6 KB region private
 //     to the wave (requested one chunk ahead); thread = (channel of the 8-channel chunk, tile) reads its 6x6 patch from there,
 //     applies B^T . B and writes the 36 positions to the double-buffered V slab (2 x 36 KB).  They also own everything that
@@ -25,6 +25,10 @@
 //     after the consumers' row pass (T = M A, written to a double-buffered 2 x 24 KB exchange area in eight 8-channel phases)
 //     they finish Y = A^T T, apply bias / activation / residuals / gate / PixelShuffle and store 16-byte rows.
 //   One barrier per chunk (LDS only) + 8 per item.
+//
+// Measured: 0.62 of the F(2x2) kernel's time on the same layers, 0.59 of the fp32 MFMA peak in executed flops.
+// The staging waves arrive last at every barrier (scripts/f4_trace.py, -DF4_EXP_TRACE) and the input traffic delays the
+// consumers' weight loads: with the input fetch forced out of range (ablation builds, scripts/build_variant.sh) the kernel runs 22 % faster.
 #include <cstdlib>
 #include <type_traits>
 
