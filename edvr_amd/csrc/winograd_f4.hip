@@ -431,6 +431,12 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
       a4[set] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, voff4, soff, 0));
       a2[set] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(u_rsrc, voff2, soff, 0));
     };
+    auto load_a4 = [&](int set, int t) {
+      a4[set] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, voff4, u_base + t * (12 * 1536), 0));
+    };
+    auto load_a2 = [&](int set, int t) {
+      a2[set] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(u_rsrc, voff2, u_base + t * (12 * 1536), 0));
+    };
     int co_blk, img_, ty_, tx_;
     decode(item_first, co_blk, img_, ty_, tx_);
     set_item(co_blk);
@@ -473,9 +479,11 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
             for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[set][c], bv[cur][c], acc[c], 0, 0, 0);
           } else {
             acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[set][3], bv[cur][0], acc[3], 0, 0, 0);
+            const int t_next = min(4 * k + cp + 2, n_steps - 1);  // past the end of the item: a redundant reload of its last k-step
+            load_a4(set, t_next);  // the 16-byte part is free two MFMAs before the 8-byte part: requested that much earlier
             acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[set][0], bv[cur][1], acc[4], 0, 0, 0);
             acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[set][1], bv[cur][2], acc[5], 0, 0, 0);
-            load_a(set, min(4 * k + cp + 2, n_steps - 1));  // past the end of the item: a redundant reload of its last k-step
+            load_a2(set, t_next);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
