@@ -145,3 +145,16 @@ def test_f4_data_gradient_packing(gpu):
     dx = ops.conv2d(dy.float().to(gpu), ops.pack_conv_weight(wg, transpose_flip=True), None, 24, 3,
                     wpk_f4=ops.pack_conv_weight(wg, transpose_flip=True, f4=True), algo=ops.CONV_WINOGRAD_F4)
     assert _rel(dx, x.grad) < RTOL_F4
+
+
+@pytest.mark.parametrize('flip', [False, True])
+def test_f4_packed_weights_match_the_oracle_layout(gpu, flip):
+    """edvr_conv2d_pack_weight_f4_f32 (U = G g G^T in MFMA operand order) against oracle/winograd_f4_oracle.py, element by element."""
+    from edvr_amd import ops
+    from oracle import winograd_f4_oracle as W
+    g = torch.Generator().manual_seed(9)
+    wt = torch.randn(70, 20, 3, 3, generator=g) * 0.1
+    got = ops.pack_conv_weight(wt.to(gpu), transpose_flip=flip, f4=True).double().cpu()
+    want = W.pack_operand_order(wt, transpose_flip=flip)
+    assert got.shape == want.shape
+    assert (got - want).abs().max().item() < 2e-7 * want.abs().max().item()
