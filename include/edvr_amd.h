@@ -78,7 +78,7 @@ int edvr_check_device(void);
  * edvr_conv2d_pack_weight_f32 (layout [ci_pad][ks*ks][co_pad], co fastest; for 3x3 kernels followed by the
  * Winograd-transformed weights G g G^T as [ci_pad][16][co_pad64]).  3x3 / stride-1 layers with >= 48 output channels
  * and w > 16 run as Winograd F(2x2,3x3) on the fp32 MFMA (2.25x fewer multiplies, fp32 throughout; set the
- * environment variable EDVR_CONV_WINOGRAD=0 to force the direct kernel); with `wpk_f4` present, layers with w >= 48 and
+ * environment variable EDVR_CONV_WINOGRAD=0 to force the direct kernel); with `wpk_f4` present, layers with w >= 32 and
  * w % 4 == 0 run as Winograd F(4x4,3x3) (4x fewer multiplies; EDVR_WINOGRAD_F4=0 switches it off). */
 typedef struct edvr_conv2d_desc {
   const float *x1;        /* (n, c1, h, w) */

@@ -14,7 +14,7 @@ def _rel(a, ref):
     return ((a.double().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
 
 
-@pytest.mark.parametrize('algo', ['direct', 'winograd', 'auto'])  # auto: F(4x4) Winograd wherever it applies (w >= 48, w % 4 == 0)
+@pytest.mark.parametrize('algo', ['direct', 'winograd', 'auto'])  # auto: F(4x4) Winograd wherever it applies (w >= 32, w % 4 == 0)
 @pytest.mark.parametrize('name', list(CONFIGS))
 def test_edvr_forward_matches_oracle(gpu, name, algo, monkeypatch):
     from edvr_amd import ops
