@@ -132,9 +132,9 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
 
   if (wave < 4) {
     // =========================================================================================== producers
-    // Vector instructions are not issued while an MFMA of the same SIMD executes (measured: the staging wave got one instruction
-    // per MFMA slot and was the last at every barrier).  With the higher priority its ~85 instructions per chunk go first and
-    // the three MFMA waves fill the rest; its instruction count is what it costs.
+    // Next to three waves that issue MFMAs back to back this wave advances slowly (~160 instructions in ~6000 cycles per chunk)
+    // and is the last at every barrier.  The wave priority makes no measurable difference in either direction (raised here,
+    // raised on the consumers instead, default everywhere: same time); kept raised.
     __builtin_amdgcn_s_setprio(3);
     const int p_ty = j >> TXL, p_tx = j & (TX - 1);  // tile j of the TY x TX; channel 2 wave + half of the chunk
     // Raw input of this wave's two channels for one chunk: [channel 2][row BH + 2][(TX + 2) x 16 B] = image rows ty0 - 1 .. ty0 + BH,
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
     // to the wave - it alone reads the patches of these two channels - so no cross-wave ordering is needed: read the patches of
     // chunk k + 1, then request chunk k + 2 into the same place; it has the rest of the step to arrive.
     // (First version: every thread gathered its 6x6 patch with 24 buffer loads - 16 quad accesses per instruction in the
-    // texture addresser, 4160 L1 accesses per chunk and CU, address path 50 % busy: 1.24 ms where the MFMAs need 0.55.)
+    // texture addresser, 4160 L1 accesses per chunk and CU, address path 50 % busy: 1.24 ms where the MFMAs alone need 0.65.)
     typedef __attribute__((address_space(3))) void lvoid;
     constexpr int OOB = (int)0x80000000;
     float *const Rw = smem + 2 * VSLAB + XSZ + wave * RWAVE;
