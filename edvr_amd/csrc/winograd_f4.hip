@@ -591,6 +591,7 @@ bool winograd_f4_supported(const edvr_conv2d_desc &d) {
   if ((d.res2 && !d.res1) || (d.out_mode != EDVR_OUT_NCHW && has_res)) return false;
   if (d.y_scale != 0.f && d.y_scale != 1.f && !d.res1 && !d.gate) return false;  // the scale lives in the residual / gate epilogues
   if (d.c2 > 0 && (d.c1 & 1)) return false;                                      // a staging wave covers two consecutive channels
+  if ((int64_t)((d.co + 63) / 64 * 64) * ((d.c1 + d.c2 + 7) / 8 * 8) * 144 >= ((int64_t)1 << 31)) return false;  // the packed weights: 32-bit offsets
   if ((int64_t)d.h * d.w * 8 >= ((int64_t)1 << 31)) return false;                // two planes in 32-bit buffer offsets
   if (d.w & 3) return false;                                                     // input rows are fetched as aligned 16-byte pieces
   auto aligned = [](const float *p, int64_t img_stride, int a) { return !p || ((reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0 && (img_stride * 4 & (a - 1)) == 0); };
