@@ -1,0 +1,43 @@
+"""CPU: the flop / traffic accounting helpers of bench.py (no GPU work)."""
+import importlib.util
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location('bench_module', os.path.join(ROOT, 'bench.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_executed_flops_per_algorithm():
+    b = _bench()
+    assert b._executed('conv3x3_winograd_f4_kernel', 144.0) == 36.0        # F(4x4,3x3): 36 of 144 multiplies per 4x4 tile
+    assert b._executed('conv3x3_winograd_kernel<true, false>', 36.0) == 16.0  # F(2x2,3x3): 16 of 36
+    assert b._executed('conv3x3_winograd_wgrad_kernel', 36.0) == 16.0
+    assert b._executed('conv2d_mfma_kernel<3, 1, 4, 32, 1>', 10.0) == 10.0
+    assert b._is_mfma('conv3x3_winograd_f4_kernel') and not b._is_mfma('upsample2x')
+
+
+def test_roofline_fraction_is_executed_over_peak():
+    b = _bench()
+    flops, secs = 4.0 * 157.3e12, 2.0                                       # algorithmic flops of an F(4x4) kernel over 2 s
+    per = {'conv3x3_winograd_f4_kernel': [10, flops, secs, 0.0]}
+    r = b.roofline_object(per, 1, 4.0, 'no_such_workload', False)
+    assert r['kernel'] == 'conv3x3_winograd_f4_kernel' and r['bound'] == 'mfma'
+    assert abs(r['frac'] - 0.5) < 1e-3 and r['frac'] <= 1.0                 # executed = algorithmic / 4
+    assert abs(r['algorithmic_over_peak'] - 2.0) < 1e-3
+    assert r['traffic'] is None
+
+
+def test_measured_traffic_aggregates_template_instantiations():
+    b = _bench()
+    tr, src = b.measured_traffic('edvr_l_x4_t5_180x320', 'conv3x3_winograd_f4_kernel')
+    rep = json.load(open(os.path.join(ROOT, src)))
+    hits = [v for k, v in rep['kernels'].items() if 'conv3x3_winograd_f4_kernel' in k]
+    assert len(hits) >= 1 and tr['launches'] == sum(v['launches'] for v in hits)
+    want = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in hits) / tr['launches']
+    assert abs(tr['hbm_bytes_per_launch'] - want) < 1.0
