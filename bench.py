@@ -11,9 +11,14 @@ re-launches this script as N ranks through torch.distributed.run.  Rank 0 prints
 
 Objects in the line besides the contract's fields (everything below runs OUTSIDE the timed region):
   roofline            dominant kernel of the timed step, from an instrumented pass (every launch bracketed by HIP events on the
-                      launch stream): `achieved` = flops the matrix cores EXECUTE / time, `frac` = achieved / 157.3 TF/s (<= 1);
-                      the algorithmic figure (2*9*Ci*Co per pixel, what SURVEY 8(d) counts) is kept next to it.
+                      launch stream): `achieved` = flops the matrix cores EXECUTE (MFMA issues x 4096, tile and channel padding
+                      included - edvr_conv2d_executed_flops, the quantity SQ_INSTS_VALU_MFMA_MOPS_F32 counts) / time, `frac` =
+                      achieved / 157.3 TF/s (<= 1); the algorithmic figure (2*9*Ci*Co per pixel, what SURVEY 8(d) counts) and the
+                      padding-free executed figure (algorithmic / 4 for F(4x4)) are kept next to it.
   kernels             per-kernel table of that pass: launches, ms, TF/s (MFMA-bound) or GB/s (HBM-bound), share of the step.
+  target_4k           BASELINE.json north_star's target workload - EDVR-L x4, 5 frames, 720x1280 -> 2880x5120, 1 clip per GPU -
+                      timed the same way (barrier + synchronize, max over ranks), with its F(4x4) roofline fraction and parity
+                      (max rel err, dPSNR) against the stock-PyTorch-ROCm arm on the same clip.
   train               BASELINE.json's second headline (training iters/sec) on the cfg4 per-GPU shape, run on ALL ranks (DDP).
   parity              the headline workload's output on ONE clip vs the CPU oracle's output on the same clip.
   cpu_baseline        the CPU oracle timed on that clip (median of 3) on this box's host cores.
@@ -37,7 +42,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
 PEAK_HBM_GBPS = 8000.0        # same guide: HBM3E ~8 TB/s
-PROFILE_ROUND = 'r2'
+PROFILE_ROUND = 'r3'
 
 L5 = dict(num_feat=128, num_frame=5, num_reconstruct_block=40, center_frame_idx=None)
 WORKLOADS = {
@@ -71,9 +76,9 @@ WORKLOADS = {
     'edvr_m_x4_t5_64x64': dict(net=dict(num_feat=64, num_frame=5, num_reconstruct_block=10, center_frame_idx=2),
                                shape=(5, 3, 64, 64), batch=1, desc='EDVR-M x4, 5 frames, 64x64 LR crop, batch 1'),
 }
-MFMA_KERNELS = ('conv3x3_winograd_f4_kernel', 'conv3x3_winograd_kernel', 'conv3x3_winograd4_kernel', 'conv3x3_winograd_wgrad_kernel', 'conv2d_mfma_kernel', 'conv2d_wgrad_kernel',
+MFMA_KERNELS = ('conv3x3_winograd_f4_kernel', 'conv3x3_winograd_kernel', 'conv3x3_winograd_wgrad_kernel', 'conv2d_mfma_kernel', 'conv2d_wgrad_kernel',
                 'conv1x1_stream_kernel', 'gemm_nt_kernel', 'dcnv2_fwd', 'dcnv2_bwd')
-WINOGRAD = ('conv3x3_winograd_kernel', 'conv3x3_winograd4_kernel', 'conv3x3_winograd_wgrad_kernel')  # execute 16 instead of 36 multiplies per 2x2 tile
+WINOGRAD = ('conv3x3_winograd_kernel', 'conv3x3_winograd_wgrad_kernel')  # execute 16 instead of 36 multiplies per 2x2 tile
 WINOGRAD_F4 = ('conv3x3_winograd_f4_kernel',)  # F(4x4,3x3): 36 instead of 144 multiplies per 4x4 tile
 
 
@@ -93,6 +98,7 @@ def parse():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-train-leg', action='store_true', help='infer mode: skip the training leg (the `train` object)')
     ap.add_argument('--no-batch4', action='store_true', help='headline workload: skip the extra 4-clips-per-GPU measurement')
+    ap.add_argument('--no-target-4k', action='store_true', help='headline workload: skip the 720p -> 4K target leg (`target_4k`)')
     ap.add_argument('--train-steps', type=int, default=5)
     return ap.parse_args()
 
@@ -111,12 +117,12 @@ def instrumented_pass(step, steps):
     from edvr_amd import ops
     records = []
 
-    def hook(name, flops, launch, nbytes):
+    def hook(name, flops, launch, nbytes, executed=None):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         launch()
         e1.record()
-        records.append((name, flops, e0, e1, nbytes))
+        records.append((name, flops, e0, e1, nbytes, _executed(name, flops) if executed is None else executed))
 
     ops.LAUNCH_HOOK = hook
     try:
@@ -126,12 +132,13 @@ def instrumented_pass(step, steps):
     finally:
         ops.LAUNCH_HOOK = None
     per = {}
-    for name, flops, e0, e1, nbytes in records:
-        d = per.setdefault(name, [0, 0.0, 0.0, 0.0])
+    for name, flops, e0, e1, nbytes, executed in records:
+        d = per.setdefault(name, [0, 0.0, 0.0, 0.0, 0.0])
         d[0] += 1
         d[1] += flops
         d[2] += e0.elapsed_time(e1) * 1e-3
         d[3] += nbytes
+        d[4] += executed  # flops the matrix cores issue for the launch, padding included (ops.conv2d asks the C side)
     return per
 
 
@@ -140,6 +147,7 @@ def _is_mfma(name):
 
 
 def _executed(name, flops):
+    """Padding-free executed flops from the algorithmic count: what the algorithm needs on exactly-fitting tiles."""
     if name.startswith(WINOGRAD_F4):
         return flops / 4.0
     return flops / 2.25 if name.startswith(WINOGRAD) else flops
@@ -149,11 +157,13 @@ def kernel_table(per, steps, step_seconds):
     """Per-kernel roofline view of one step: MFMA-bound kernels in executed TF/s (fraction of 157.3), HBM-bound ones in
     algorithmic GB/s (fraction of 8 TB/s)."""
     rows = {}
-    for name, (n, flops, secs, nbytes) in sorted(per.items(), key=lambda kv: -kv[1][2]):
+    for name, rec in sorted(per.items(), key=lambda kv: -kv[1][2]):
+        n, flops, secs, nbytes = rec[:4]
+        executed = rec[4] if len(rec) > 4 else _executed(name, flops)
         row = {'launches_per_step': round(n / steps, 1), 'ms_per_step': round(secs / steps * 1e3, 3),
                'share_of_step': round(secs / steps / step_seconds, 4), 'avg_launch_us': round(secs / n * 1e6, 2)}
         if _is_mfma(name) and flops > 0:
-            ex = _executed(name, flops) / secs / 1e12
+            ex = executed / secs / 1e12
             row.update(bound='mfma', tflops_executed=round(ex, 2), frac_of_mfma_peak=round(ex / PEAK_F32_MFMA_TFLOPS, 4))
             if name.startswith(WINOGRAD + WINOGRAD_F4):
                 row['tflops_algorithmic'] = round(flops / secs / 1e12, 2)
@@ -167,8 +177,9 @@ def kernel_table(per, steps, step_seconds):
 def measured_traffic(workload, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this same command
     (scripts/prof_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate --pmc passes, calibrated on known-size copies as
-    MI355X_MICROARCH.md's HBM section prescribes).  PMC collection serialises kernels, so it is not redone inside the timed run."""
-    for rnd in (PROFILE_ROUND, 'r1'):
+    MI355X_MICROARCH.md's HBM section prescribes).  PMC collection serialises kernels, so it is not redone inside the timed run;
+    the summary records the hash of the kernel sources it was measured on (`csrc_sha16`), compared with the tree's below."""
+    for rnd in (PROFILE_ROUND, 'r2', 'r1'):
         path = os.path.join(ROOT, 'profiles', rnd, f'traffic_{workload}.json')
         if os.path.exists(path):
             rep = json.load(open(path))
@@ -180,6 +191,7 @@ def measured_traffic(workload, kernel):
                 agg = {f: sum(v[f] * v['launches'] for v in hits) / n
                        for f in ('fetch_bytes_per_launch', 'write_bytes_per_launch', 'hbm_bytes_per_launch')}
                 agg['launches'] = n
+                agg['csrc_sha16'] = rep.get('csrc_sha16')
                 return agg, os.path.relpath(path, ROOT)
     return None, None
 
@@ -187,16 +199,22 @@ def measured_traffic(workload, kernel):
 def roofline_object(per, steps, step_seconds, workload, default_batch):
     mf = {k: v for k, v in per.items() if _is_mfma(k) and v[1] > 0}
     name = max(mf, key=lambda k: mf[k][2])
-    n, flops, secs, nbytes = per[name]
-    ex = _executed(name, flops) / secs / 1e12
+    n, flops, secs, nbytes = per[name][:4]
+    executed = per[name][4] if len(per[name]) > 4 else _executed(name, flops)
+    ex = executed / secs / 1e12
     tr, tr_src = measured_traffic(workload, name) if default_batch else (None, None)
     wino = name.startswith(WINOGRAD)
     f4 = name.startswith(WINOGRAD_F4)
+    from edvr_amd.build import source_hash
     return {
         'bound': 'mfma', 'kernel': name, 'achieved': round(ex, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
         'frac': round(ex / PEAK_F32_MFMA_TFLOPS, 4),
-        'definition': 'achieved = flops the fp32 matrix cores execute (v_mfma_f32_32x32x2_f32 issues x 4096) / HIP-event time of '
-                      'the kernel; frac = achieved / peak',
+        'definition': 'achieved = flops the fp32 matrix cores execute = v_mfma_f32_32x32x2_f32 issues x 4096, tile and channel '
+                      'padding included (edvr_conv2d_executed_flops; rocprofv3 SQ_INSTS_VALU_MFMA_MOPS_F32 counts the same '
+                      'issues, profiles/*/winograd_f4_micro_pmc.json) / HIP-event time of the kernel; frac = achieved / peak',
+        # the same without the padded tiles / channels (algorithmic flops / 4 for F(4x4), / 2.25 for F(2x2)): the useful part
+        'executed_without_padding_tflops': round(_executed(name, flops) / secs / 1e12, 2),
+        'padding_overhead': round(executed / max(_executed(name, flops), 1.0) - 1.0, 4),
         'algorithm': 'winograd F(4x4,3x3), fp32: 36 instead of 144 multiplies per 4x4 tile and channel pair' if f4
                      else ('winograd F(2x2,3x3), fp32: 16 instead of 36 multiplies per 2x2 tile and channel pair' if wino
                            else 'direct implicit GEMM, fp32'),
@@ -209,7 +227,10 @@ def roofline_object(per, steps, step_seconds, workload, default_batch):
         'traffic': round(tr['hbm_bytes_per_launch']) if tr else None,
         'traffic_detail': ({'unit': 'bytes per launch (average over the launches of this kernel in one step)',
                             'fetch': round(tr['fetch_bytes_per_launch']), 'write': round(tr['write_bytes_per_launch']),
-                            'algorithmic': round(nbytes / n), 'source': tr_src} if tr else None),
+                            'algorithmic': round(nbytes / n), 'source': tr_src, 'measured_on_csrc_sha16': tr.get('csrc_sha16'),
+                            'csrc_sha16': source_hash(),
+                            # the committed PMC summary was taken on other kernel sources than the ones in the tree
+                            'stale': tr.get('csrc_sha16') != source_hash()} if tr else None),
     }
 
 
@@ -362,10 +383,60 @@ def train_leg(args, device, rank, world, dist):
         per = instrumented_pass(step, 1)
         tab = kernel_table(per, 1, elapsed / args.train_steps)
         out['dominant_kernels'] = {k: v for k, v in list(tab.items())[:8]}
-        for key, label in (('conv3x3_winograd_kernel', 'fwd_dgrad_8wave'), ('conv3x3_winograd4_kernel', 'fwd_dgrad'), ('conv3x3_winograd_wgrad_kernel', 'wgrad')):
+        for key, label in (('conv3x3_winograd_f4_kernel', 'fwd_dgrad_f4'), ('conv3x3_winograd_kernel', 'fwd_dgrad_f2'), ('conv3x3_winograd_wgrad_kernel', 'wgrad')):
             if key in tab:
                 out[f'{label}_mfma_frac'] = tab[key]['frac_of_mfma_peak']
     return out, step
+
+
+def target_4k_leg(net, args, device, rank, world, dist):
+    """BASELINE.json north_star "Target": x4 720p -> 4K, 5 frames, EDVR-L - one clip per GPU (67.7 algorithmic TFLOP), the
+    network (and weights) of the headline workload.  Timed like the headline: barrier + synchronize on both sides, max over ranks."""
+    cfg = WORKLOADS['edvr_l_x4_t5_720x1280']
+    x = torch.rand(1, *cfg['shape'], generator=torch.Generator().manual_seed(rank)).to(device)
+
+    def step():
+        with torch.no_grad():
+            return net(x)
+    steps = 5
+    elapsed = timed(step, steps, 2, dist, device)
+    out = None
+    if rank == 0:
+        out = {'workload': cfg['desc'], 'value': round(world * steps / elapsed, 4), 'unit': 'clips/s', 'ms_per_clip': round(elapsed / steps * 1e3, 2),
+               'steps': steps, 'warmup': 2, 'n_gpus': world, 'clips_per_gpu': 1,
+               'output_megapixels_per_sec': round(world * steps / elapsed * 2880 * 5120 / 1e6, 1)}
+        if not args.no_roofline:
+            per = instrumented_pass(step, 1)
+            tab = kernel_table(per, 1, elapsed / steps)
+            out['kernels'] = {k: v for k, v in list(tab.items())[:6]}
+            f4 = next((v for k, v in tab.items() if k.startswith(WINOGRAD_F4)), None)
+            if f4:
+                out['f4_frac_of_mfma_peak'] = f4['frac_of_mfma_peak']
+            out['fallbacks'] = {'conv1x1_stream_kernel_used': any(k.startswith('conv1x1_stream_kernel') for k in tab)}
+    if rank == 0 and world == 1 and not args.no_stock_baseline:
+        # parity witness at this size: the stock-PyTorch-ROCm arm on the same clip (the CPU oracle would need ~4 minutes)
+        from oracle import dcn_oracle, edvr_oracle as EO
+        try:
+            gt = torch.rand(1, 3, 2880, 5120, generator=torch.Generator().manual_seed(1)).to(device)
+            with torch.no_grad():
+                ours = net(x)
+                sd = net.state_dict()
+                ref = EO.edvr_forward(sd, x, dcn=dcn_oracle.dcnv2_torch, **oracle_kw(cfg))  # warm-up (MIOpen find) + the reference output
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                EO.edvr_forward(sd, x, dcn=dcn_oracle.dcnv2_torch, **oracle_kw(cfg))
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            err = float(((ours - ref).abs().max() / ref.abs().max()).item())
+            p_ours, p_ref = EO.psnr(ours, gt), EO.psnr(ref, gt)
+            out['parity'] = dict(against='oracle/edvr_oracle.py in stock PyTorch-ROCm fp32 ops (MIOpen convs, pure-torch DCNv2) on this GPU, same clip, '
+                                         'same weights; intermediates at this size: tests/test_gpu_fullsize_parity.py',
+                                 max_rel_err=err, psnr_ours=round(p_ours, 6), psnr_stock=round(p_ref, 6), d_psnr=round(abs(p_ours - p_ref), 8),
+                                 tolerance={'max_rel_err': 2e-4, 'd_psnr_db': 1e-3}, ok=bool(err < 2e-4 and abs(p_ours - p_ref) <= 1e-3))
+            out['stock_rocm_baseline'] = {'value': round(1.0 / dt, 3), 'unit': 'clips/s', 'ms_per_clip': round(dt * 1e3, 1)}
+        except Exception as e:  # (a baseline arm must never take the measurement down)
+            out['parity'] = {'error': f'{type(e).__name__}: {str(e)[:200]}'}
+    return out
 
 
 def self_spawn(args):
@@ -461,6 +532,14 @@ def main():
         result['roofline'] = roofline_object(per, isteps, elapsed / args.steps, args.workload, batch == cfg['batch'])
         result['kernels'] = kernel_table(per, isteps, elapsed / args.steps)
     del step
+    if args.workload == 'edvr_l_x4_t5_180x320' and args.mode == 'infer' and not args.no_target_4k:
+        del x
+        torch.cuda.empty_cache()
+        x = None
+        t4k = target_4k_leg(net, args, device, rank, world, dist)  # all ranks (barriers inside)
+        torch.cuda.empty_cache()
+        if rank == 0:
+            result['target_4k'] = t4k
     if args.mode == 'infer' and not args.no_train_leg:
         del net, x
         torch.cuda.empty_cache()

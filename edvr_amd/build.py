@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libedvr_amd.so')
 OBJDIR = os.path.join(HERE, 'build')
-SOURCES = ['api.hip', 'conv2d.hip', 'dcn.hip', 'elementwise.hip', 'wgrad.hip', 'backward.hip', 'dcn_fused.hip', 'winograd.hip', 'winograd4.hip', 'winograd_f4.hip', 'winograd_wgrad.hip', 'optim.hip', 'metrics.hip', 'conv_small.hip', 'conv1x1.hip', 'data.hip']
+SOURCES = ['api.hip', 'conv2d.hip', 'dcn.hip', 'elementwise.hip', 'wgrad.hip', 'backward.hip', 'dcn_fused.hip', 'winograd.hip', 'winograd_f4.hip', 'winograd_wgrad.hip', 'optim.hip', 'metrics.hip', 'conv_small.hip', 'conv1x1.hip', 'data.hip']
 LINK = []  # no library dependencies beyond the HIP runtime: every kernel of the path is in csrc/
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-ffp-contract=fast']
 
@@ -37,6 +37,18 @@ def _stale(target, sources):
         return True
     t = os.path.getmtime(target)
     return any(os.path.getmtime(s) > t for s in sources)
+
+
+def source_hash():
+    """sha256[:16] over the kernel sources (csrc/*, include/edvr_amd.h): recorded in every profiles/*.json so that a committed
+    measurement can be tied to - or flagged as older than - the kernels in the tree (bench.py `traffic_detail.stale`)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h', '.inc')))
+    for path in files + [os.path.join(HERE, '..', 'include', 'edvr_amd.h')]:
+        h.update(os.path.basename(path).encode() + b'\0')
+        h.update(open(path, 'rb').read())
+    return h.hexdigest()[:16]
 
 
 def build(force=False, verbose=False):

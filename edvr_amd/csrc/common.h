@@ -42,17 +42,14 @@ int gemm_nt_batched(const float *A, const float *B, float *C, int M, int N, int6
 // follows the direct packed layout inside the buffer edvr_conv2d_pack_weight_f32 fills.
 bool winograd_eligible(const edvr_conv2d_desc &d);
 int winograd_launch(const edvr_conv2d_desc &d, const float *U, int cop64, hipStream_t stream);
+double winograd_executed_flops(const edvr_conv2d_desc &d);
 int winograd_pack(const float *w, float *U, int co, int ci, int cop64, int cip, int transpose_flip, float *wpk_direct, int cop32,
                   hipStream_t stream);  // wpk_direct != nullptr: also writes the direct layout [cip][9][cop32] in the same launch
-
-// winograd4.hip: the same convolution as 4-wave workgroups, two per CU (takes over where winograd4_supported)
-bool winograd4_enabled();  // EDVR_WINOGRAD_4WAVE=1: the weights are then packed in that kernel's operand order
-bool winograd4_supported(const edvr_conv2d_desc &d);
-int winograd4_launch(const edvr_conv2d_desc &d, const float *U, int cop64, hipStream_t stream);
 
 // winograd_f4.hip: F(4x4,3x3), wave-specialised workgroups; needs edvr_conv2d_desc.wpk_f4 (inference path)
 bool winograd_f4_eligible(const edvr_conv2d_desc &d);
 int winograd_f4_launch(const edvr_conv2d_desc &d, hipStream_t stream);
+double winograd_f4_executed_flops(const edvr_conv2d_desc &d);
 
 // conv_small.hip: 3x3 / stride-1 conv with <= 4 output channels on the vector ALUs (EDVR's conv_last)
 bool conv_small_eligible(const edvr_conv2d_desc &d);
@@ -81,7 +78,7 @@ int winograd_wgrad_launch(const float *x1, const float *x2, const float *dz, flo
                           int splits, int want_db, hipStream_t stream);  // want_db: also [splits][co] partial sums of dz after the dW partials
 
 // dcn_fused.hip: column-buffer-free DCNv2 forward for the EDVR signature (3x3, stride 1, pad 1, dil 1, groups 1)
-bool dcn_fused_supported(int C, int Co, int kh, int kw, int stride, int pad, int dil, int groups, int dg);
+bool dcn_fused_supported(int C, int Co, int H, int W, int kh, int kw, int stride, int pad, int dil, int groups, int dg);  // incl. the 32-bit buffer-offset limits
 int dcn_fused_pack(const float *weight, float *wpk, int Co, int C, hipStream_t stream);  // (Co, C, 3, 3) -> the fused kernel's layout, C * 9 * round_up(Co, 32) floats
 int dcn_fused_forward(const float *x, const float *offset, const float *mask, const float *wpk, const float *bias, float *y, int B, int C,
                       int H, int W, int Co, int dg, int64_t off_bs, int64_t msk_bs, int act, int halo, hipStream_t stream);

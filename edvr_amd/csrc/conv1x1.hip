@@ -20,6 +20,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct Conv1x1Args {
   edvr_conv2d_desc d;
   int ci, cip, cop, co_start;  // ci rounded up to the 64-channel slab, cip = rows of the packed weight buffer
+  int seg_shift;               // channels are addressed in segments of 1 << seg_shift planes (below)
 };
 
 template <int MT>
@@ -36,26 +37,32 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const Conv1x1Arg
   const int p = (blockIdx.x * 4 + wave) * 32 + j;  // this lane's pixel
   const bool p_ok = p < hw;
 
-  auto rsrc_of = [&](const float *ptr) {
+  auto uniform_ptr = [&](const float *ptr) {
     const uint64_t pv = reinterpret_cast<uint64_t>(ptr);
-    const uint64_t pu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pv >> 32)) << 32) |
-                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pv);
-    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(pu), (short)0, 0x7fffffff, RSRC_FLAGS);
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pv >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pv);
   };
-  const __amdgpu_buffer_rsrc_t r1 = rsrc_of(d.x1 + (int64_t)img * d.x1_img_stride);
-  __amdgpu_buffer_rsrc_t r2 = r1;
+  const uint64_t b1 = uniform_ptr(d.x1 + (int64_t)img * d.x1_img_stride);
+  uint64_t b2 = b1;
   if (d.x2) {
     const int i2 = d.x2_div > 0 ? (img / d.x2_div) * d.x2_mul + d.x2_add : img;
-    r2 = rsrc_of(d.x2 + (int64_t)i2 * d.x2_img_stride);
+    b2 = uniform_ptr(d.x2 + (int64_t)i2 * d.x2_img_stride);
   }
   const int voff = p_ok ? (half * hw + p) * 4 : OOB;  // channel `half` of the pair; out-of-range pixels read as 0
-  // k-step s = channel pair (2s, 2s + 1) of cat(x1, x2); c1 is even (checked by the host), so a pair never straddles the inputs
+  // k-step s = channel pair (2s, 2s + 1) of cat(x1, x2); c1 is even (checked by the host), so a pair never straddles the inputs.
+  // Buffer offsets are 32 bits with the range check at 2^31 (OOB above), an image of 640 channels x 720 x 1280 is 2.4 GB: the
+  // resource is re-based per SEGMENT of (1 << seg_shift) channel planes (the host picks the largest segment that fits; one segment
+  // for every image below 2 GB), the channel inside the segment goes to the scalar offset.  All of it is scalar arithmetic on
+  // the unrolled k-step index - a handful of SALU instructions next to 4 MFMAs.
   const int real_steps = (d.c1 + d.c2) / 2;
-  auto load_b = [&](int s) -> float {  // branch-free: resource / channel offset / validity are scalar selects
+  const int seg_mask = (1 << a.seg_shift) - 1;
+  const int64_t plane_bytes = (int64_t)hw * 4;
+  auto load_b = [&](int s) -> float {  // branch-free: base / channel offset / validity are scalar selects
     const int c = 2 * s;
     const bool first = c < d.c1;
-    const __amdgpu_buffer_rsrc_t rs = first ? r1 : r2;
-    const int soff = (first ? c : c - d.c1) * hw * 4;
+    const int cc = first ? c : c - d.c1;
+    const uint64_t base = (first ? b1 : b2) + (uint64_t)((int64_t)(cc & ~seg_mask) * plane_bytes);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(base), (short)0, 0x7fffffff, RSRC_FLAGS);
+    const int soff = (cc & seg_mask) * hw * 4;
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, s < real_steps ? voff : OOB, s < real_steps ? soff : 0, 0));
   };
 
@@ -138,10 +145,10 @@ bool conv1x1_eligible(const edvr_conv2d_desc &d) {
   }();
   if (!enabled || d.ks != 1 || d.stride != 1 || d.out_mode != EDVR_OUT_NCHW || d.algo == EDVR_CONV_DIRECT) return false;
   if ((d.c1 & 1) || (d.c2 & 1)) return false;                                      // channel pairs must not straddle x1 / x2
-  const int64_t per_img = (int64_t)std::max(d.c1, d.c2) * d.h * d.w * 4;
-  // 32-bit buffer offsets; a deep K: at 128 input channels the one-sub-tile direct kernel (3 waves per SIMD) is faster - 82.6 vs
-  // 71.7 TF/s on the 128 -> 1152 `dcol` product of the DCN backward - while this kernel wins from 640 channels up (84 vs 71, 104 vs 82)
-  return per_img < ((int64_t)1 << 31) && d.co >= 32 && d.c1 + d.c2 >= 320;
+  // 32-bit buffer offsets inside a channel segment (conv1x1_launch): a channel PAIR must stay below 2 GB (h * w < 2^28); a deep K:
+  // at 128 input channels the one-sub-tile direct kernel (3 waves per SIMD) is faster - 82.6 vs 71.7 TF/s on the 128 -> 1152
+  // `dcol` product of the DCN backward - while this kernel wins from 640 channels up (84 vs 71, 104 vs 82)
+  return (int64_t)d.h * d.w * 8 < ((int64_t)1 << 31) && d.co >= 32 && d.c1 + d.c2 >= 320;
 }
 
 int conv1x1_launch(const edvr_conv2d_desc &d, hipStream_t stream) {
@@ -151,6 +158,8 @@ int conv1x1_launch(const edvr_conv2d_desc &d, hipStream_t stream) {
   a.cip = ((d.c1 + d.c2 + 31) / 32) * 32;
   a.cop = (d.co + 31) / 32 * 32;
   const int hw = d.h * d.w;
+  a.seg_shift = 30;  // largest power-of-two channel segment whose planes fit 32-bit offsets (>= 1: a pair always does, conv1x1_eligible)
+  while (((int64_t)1 << a.seg_shift) * hw * 4 >= ((int64_t)1 << 31)) --a.seg_shift;
   const int full = d.co / 128, rem_tiles = cdiv(d.co - full * 128, 32);
   if (full > 0) {
     a.co_start = 0;

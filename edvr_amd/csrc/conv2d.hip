@@ -376,7 +376,7 @@ int conv2d_launch(const edvr_conv2d_desc &d, hipStream_t stream) {
   if (winograd_f4_eligible(d)) return winograd_f4_launch(d, stream);
   if (winograd_eligible(d)) {
     const float *U = d.wpk + direct_packed_elems(d.co, a.ci, 3);
-    return winograd4_supported(d) ? winograd4_launch(d, U, round_up(d.co, 64), stream) : winograd_launch(d, U, round_up(d.co, 64), stream);
+    return winograd_launch(d, U, round_up(d.co, 64), stream);
   }
   if (d.ks == 3 && d.stride == 1) return launch_mt<3, 1>(a, stream);
   if (d.ks == 3 && d.stride == 2) return launch_mt<3, 2>(a, stream);
@@ -420,7 +420,7 @@ int edvr_conv2d_kernel_name(const edvr_conv2d_desc *d, char *buf, size_t buf_len
     return EDVR_OK;
   }
   if (edvr::winograd_eligible(*d)) {
-    snprintf(buf, buf_len, edvr::winograd4_supported(*d) ? "conv3x3_winograd4_kernel" : "conv3x3_winograd_kernel");
+    snprintf(buf, buf_len, "conv3x3_winograd_kernel");
     return EDVR_OK;
   }
   if (edvr::conv1x1_eligible(*d)) {
@@ -433,10 +433,20 @@ int edvr_conv2d_kernel_name(const edvr_conv2d_desc *d, char *buf, size_t buf_len
   return EDVR_OK;
 }
 
+int edvr_conv2d_executed_flops(const edvr_conv2d_desc *d, double *flops) {
+  EDVR_REQUIRE(d && flops, "executed_flops: bad arguments");
+  const int pad = d->ks / 2;
+  const double ho = (d->h + 2 * pad - d->ks) / d->stride + 1, wo = (d->w + 2 * pad - d->ks) / d->stride + 1;
+  if (!edvr::conv_small_eligible(*d) && edvr::winograd_f4_eligible(*d)) *flops = edvr::winograd_f4_executed_flops(*d);
+  else if (!edvr::conv_small_eligible(*d) && edvr::winograd_eligible(*d)) *flops = edvr::winograd_executed_flops(*d);
+  else *flops = 2.0 * d->n * ho * wo * d->co * (d->c1 + d->c2) * d->ks * d->ks;  // direct algorithm (tile padding not counted)
+  return EDVR_OK;
+}
+
 int edvr_conv2d_gate_supported(const edvr_conv2d_desc *d) {
   if (!d) return 0;
   edvr_conv2d_desc q = *d;
-  if (!q.gate) q.gate = q.x1;  // any non-null pointer: only the eligibility rules are evaluated
+  if (!q.gate) q.gate = reinterpret_cast<const float *>(&q);  // any non-null pointer (callers probe with x1 unset): only the eligibility rules are evaluated
   return edvr::winograd_eligible(q) ? 1 : 0;  // (the direct kernel takes a gate too - correct, slower; this asks for the fused-fast path)
 }
 

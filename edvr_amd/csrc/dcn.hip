@@ -683,7 +683,7 @@ static int fill_shape(DcnShape &s, int B, int C, int H, int W, int Co, int kh, i
 static bool use_fused(const DcnShape &s) {
   const char *e = getenv("EDVR_DCN_FUSED");  // "0": force the generic column-buffer path (A/B, tests)
   if (e && e[0] == '0') return false;
-  return dcn_fused_supported(s.C, s.Co, s.kh, s.kw, s.stride, s.pad, s.dil, s.groups, s.dg);
+  return dcn_fused_supported(s.C, s.Co, s.H, s.W, s.kh, s.kw, s.stride, s.pad, s.dil, s.groups, s.dg);
 }
 
 struct FwdWs { size_t col, wpk, total; };

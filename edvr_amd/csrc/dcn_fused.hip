@@ -333,8 +333,12 @@ int dcn_fused_pack(const float *weight, float *wpk, int Co, int C, hipStream_t s
   return check_launch("dcn_fused_pack_kernel");
 }
 
-bool dcn_fused_supported(int C, int Co, int kh, int kw, int stride, int pad, int dil, int groups, int dg) {
-  return kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1 && groups == 1 && C % dg == 0 && (C / dg) % 8 == 0 && Co > 0;
+bool dcn_fused_supported(int C, int Co, int H, int W, int kh, int kw, int stride, int pad, int dil, int groups, int dg) {
+  if (!(kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1 && groups == 1 && C % dg == 0 && (C / dg) % 8 == 0 && Co > 0)) return false;
+  // x, the offsets and the masks of one image are addressed through 32-bit buffer offsets (range-checked resources: a byte count
+  // of 2^31 or more would wrap and gather wrong data silently); larger images take the generic column-buffer path (64-bit pointers)
+  const int64_t P = (int64_t)H * W, lim = (int64_t)1 << 31;
+  return (int64_t)C * P * 4 < lim && (int64_t)dg * 18 * P * 4 < lim && (int64_t)C * 9 * ((Co + 31) / 32 * 32) * 4 < lim;
 }
 
 template <int MT>

@@ -481,10 +481,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_kernel(const WinoArgs
 // U[ci][xi][cop] = (G g G^T)[xi] of the 3x3 kernel g = w[co][ci] (or the data-gradient kernel when transpose_flip)
 // When `wpk` is given the same launch also writes the direct kernel's layout [cip][9][cop32] (training repacks every weight
 // each step: one launch per layer and orientation instead of two).
-// operand_order (the 4-wave kernel, winograd4.hip): [co block 64][channel pair][row 4][co half 2][channel parity 2][co 32][4
-// positions of the row] - the 16 bytes a lane of that kernel feeds to four MFMAs as A operands are contiguous.
 __global__ void winograd_weight_kernel(const float *__restrict__ w, float *__restrict__ U, int co, int ci, int cop, int cip,
-                                       int transpose_flip, float *__restrict__ wpk, int cop32, int operand_order) {
+                                       int transpose_flip, float *__restrict__ wpk, int cop32) {
   const int64_t total = (int64_t)cip * cop;
   if (wpk) {
     const int64_t dtotal = (int64_t)cip * 9 * cop32;
@@ -514,12 +512,6 @@ __global__ void winograd_weight_kernel(const float *__restrict__ w, float *__res
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {  // (G g) G^T
-      if (operand_order) {
-        float *dst = U + ((((int64_t)(o >> 6) * (cip >> 1) + (c >> 1)) * 4 + r) * 2 + ((o >> 5) & 1)) * 256 + ((c & 1) * 32 + (o & 31)) * 4;
-        *reinterpret_cast<f32x4 *>(dst) = f32x4{tmp[r * 3 + 0], 0.5f * (tmp[r * 3 + 0] + tmp[r * 3 + 1] + tmp[r * 3 + 2]),
-                                                0.5f * (tmp[r * 3 + 0] - tmp[r * 3 + 1] + tmp[r * 3 + 2]), tmp[r * 3 + 2]};
-        continue;
-      }
       float *dst = U + ((int64_t)c * 16 + r * 4) * cop + o;
       dst[0 * (int64_t)cop] = tmp[r * 3 + 0];
       dst[1 * (int64_t)cop] = 0.5f * (tmp[r * 3 + 0] + tmp[r * 3 + 1] + tmp[r * 3 + 2]);
@@ -542,10 +534,16 @@ bool winograd_eligible(const edvr_conv2d_desc &d) {
     return false;
   if (d.algo == EDVR_CONV_DIRECT) return false;
   if (d.y_scale != 0.f && d.y_scale != 1.f && !d.res1 && !d.gate) return false;  // the scale lives in the residual / gate epilogues
-  if (winograd4_enabled() && !winograd4_supported(d)) return false;  // that kernel reads its own weight order: no mixing
   const bool applicable = d.ks == 3 && d.stride == 1;  // any channel count: the loop runs over ci rounded up to 16
   if (d.algo == EDVR_CONV_WINOGRAD || d.algo == EDVR_CONV_WINOGRAD_F4) return applicable;  // explicit request: any size the kernel can do
   return enabled && applicable && d.co >= 48 && d.c1 + d.c2 >= 32 && d.w > 16 && d.h >= 4;  // auto: only where it beats the direct kernel
+}
+
+// flops the matrix cores execute for `d`, padding included: an item is 64 output channels x 64 tiles (8 x 32 pixels) x 16
+// positions, its k loop runs over the input channels rounded up to 16
+double winograd_executed_flops(const edvr_conv2d_desc &d) {
+  const double items = (double)cdiv(d.w, 32) * cdiv(d.h, 8) * cdiv(d.co, 64) * d.n;
+  return items * ((d.c1 + d.c2 + 15) / 16 * 16) * (64.0 * 64.0 * 16.0 * 2.0);
 }
 
 int winograd_launch(const edvr_conv2d_desc &d, const float *U, int cop, hipStream_t stream) {
@@ -581,7 +579,7 @@ int winograd_pack(const float *w, float *U, int co, int ci, int cop, int cip, in
                   hipStream_t stream) {
   const int64_t total = std::max((int64_t)cip * cop, wpk_direct ? (int64_t)cip * 9 * cop32 : (int64_t)0);
   hipLaunchKernelGGL(winograd_weight_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 4096)), dim3(256), 0, stream, w, U, co, ci,
-                     cop, cip, transpose_flip, wpk_direct, cop32, winograd4_enabled() ? 1 : 0);
+                     cop, cip, transpose_flip, wpk_direct, cop32);
   return check_launch("winograd_weight_kernel");
 }
 

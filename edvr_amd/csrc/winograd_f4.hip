@@ -609,6 +609,23 @@ bool winograd_f4_eligible(const edvr_conv2d_desc &d) {
   return d.co >= 48 && d.c1 + d.c2 >= 32 && d.w >= 32 && d.h >= 8;  // auto: only where it beats F(2x2)
 }
 
+// block shape: the one that pads the image less (8 x 64 output pixels on ties); returns the number of items (64 co x 32 tiles)
+static int f4_geometry(const edvr_conv2d_desc &d, int &tiles_x, int &tiles_y, bool &tx8) {
+  const int64_t pad16 = (int64_t)cdiv(d.w, 64) * 64 * cdiv(d.h, 8) * 8, pad8 = (int64_t)cdiv(d.w, 32) * 32 * cdiv(d.h, 16) * 16;
+  tx8 = pad8 < pad16;
+  tiles_x = cdiv(d.w, tx8 ? 32 : 64);
+  tiles_y = cdiv(d.h, tx8 ? 16 : 8);
+  return tiles_x * tiles_y * cdiv(d.co, 64) * d.n;
+}
+
+// flops the matrix cores execute for `d`, padding included: per item and 8-channel chunk 288 v_mfma_f32_32x32x2_f32 of 4096 flops
+double winograd_f4_executed_flops(const edvr_conv2d_desc &d) {
+  int tx, ty;
+  bool tx8;
+  const double items = f4_geometry(d, tx, ty, tx8);
+  return items * ((d.c1 + d.c2 + 7) / 8) * 288.0 * 4096.0;
+}
+
 int winograd_f4_launch(const edvr_conv2d_desc &d, hipStream_t stream) {
   WinoF4Args a;
   a.d = d;
@@ -618,12 +635,8 @@ int winograd_f4_launch(const edvr_conv2d_desc &d, hipStream_t stream) {
   a.cop = (d.co + 63) / 64 * 64;
   a.ys = d.y_scale == 0.f ? 1.f : d.y_scale;
   a.ys_gs = a.ys * d.gate_slope;
-  // block shape: the one that pads the image less (8 x 64 output pixels on ties)
-  const int64_t pad16 = (int64_t)cdiv(d.w, 64) * 64 * cdiv(d.h, 8) * 8, pad8 = (int64_t)cdiv(d.w, 32) * 32 * cdiv(d.h, 16) * 16;
-  const bool tx8 = pad8 < pad16;
-  a.tiles_x = cdiv(d.w, tx8 ? 32 : 64);
-  a.tiles_y = cdiv(d.h, tx8 ? 16 : 8);
-  a.items = a.tiles_x * a.tiles_y * cdiv(d.co, 64) * d.n;
+  bool tx8;
+  a.items = f4_geometry(d, a.tiles_x, a.tiles_y, tx8);
   static const int n_cu = []() {
     int dev = 0, n = 256;
     hipDeviceProp_t prop;

@@ -48,11 +48,12 @@ def _img_stride(t):
     return t.stride(0) if t.shape[0] > 1 else t.shape[1] * t.shape[2] * t.shape[3]
 
 
-def _run(name, launch, flops=0.0, nbytes=0.0):
+def _run(name, launch, flops=0.0, nbytes=0.0, executed=None):
     """Every launch of this module goes through here: LAUNCH_HOOK (bench.py's instrumented pass) brackets it with events on
-    the launch stream and books `flops` / `nbytes` (ALGORITHMIC work of the call: each input / output element once) under `name`."""
+    the launch stream and books `flops` / `nbytes` (ALGORITHMIC work of the call: each input / output element once) and
+    `executed` (flops the matrix cores issue for it, padding included; None = not known here) under `name`."""
     if LAUNCH_HOOK is not None:
-        LAUNCH_HOOK(name, float(flops), launch, float(nbytes))
+        LAUNCH_HOOK(name, float(flops), launch, float(nbytes), executed)
     else:
         launch()
 
@@ -194,22 +195,26 @@ def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NON
         require_gpu(wpk_f4)
         d.wpk_f4 = _ptr(wpk_f4)
     d.algo = CONV_ALGO if algo is None else algo
-    name, flops, nbytes = 'conv2d', 0.0, 0.0
+    name, flops, nbytes, executed = 'conv2d', 0.0, 0.0, None
     if LAUNCH_HOOK is not None:  # measurement only (bench.py): brackets the launch with events on this stream
         buf = ctypes.create_string_buffer(96)
         L.edvr_conv2d_kernel_name(ctypes.byref(d), buf, 96)
         name = buf.value.decode()
+        ex = ctypes.c_double(0.0)
+        if L.edvr_conv2d_executed_flops(ctypes.byref(d), ctypes.byref(ex)) == 0:
+            executed = ex.value
         flops = 2.0 * n * ho * wo * co * (c1 + d.c2) * ks * ks
         # algorithmic HBM bytes: every input / residual / gate / output element once, plus the weights
         nbytes = 4.0 * (n * (c1 + d.c2) * h * w + n * co * ho * wo * (1 + (res1 is not None) + (res2 is not None) + (gate is not None))
                         + co * (c1 + d.c2) * ks * ks)
-    _run(name, lambda: _lib.check(L.edvr_conv2d_f32(ctypes.byref(d), _stream()), 'edvr_conv2d_f32'), flops, nbytes)
+    _run(name, lambda: _lib.check(L.edvr_conv2d_f32(ctypes.byref(d), _stream()), 'edvr_conv2d_f32'), flops, nbytes, executed)
     return out
 
 
 def conv_gate_supported(n, c, h, w, co, algo=None):
-    """Would conv2d(..., gate=...) of a 3x3 / stride-1 conv on (n, c, h, w) -> co channels be accepted?  (C-side rules: the
-    Winograd kernel must apply - sizes, algorithm request, EDVR_CONV_WINOGRAD=0 switch.)"""
+    """Would conv2d(..., gate=...) of a 3x3 / stride-1 conv on (n, c, h, w) -> co channels run in a Winograd kernel's fused
+    epilogue?  (C-side rules: sizes, algorithm request, EDVR_CONV_WINOGRAD=0 switch.  The direct kernel accepts a gate as well -
+    also together with residuals - but the residual block only records the fused form where it is the fast one.)"""
     d = _lib.ConvDesc()
     d.c1, d.n, d.h, d.w, d.co, d.ks, d.stride = c, n, h, w, co, 3, 1
     d.algo = CONV_ALGO if algo is None else algo

@@ -79,7 +79,8 @@ int edvr_check_device(void);
  * Winograd-transformed weights G g G^T as [ci_pad][16][co_pad64]).  3x3 / stride-1 layers with >= 48 output channels
  * and w > 16 run as Winograd F(2x2,3x3) on the fp32 MFMA (2.25x fewer multiplies, fp32 throughout; set the
  * environment variable EDVR_CONV_WINOGRAD=0 to force the direct kernel); with `wpk_f4` present, layers with w >= 32 and
- * w % 4 == 0 run as Winograd F(4x4,3x3) (4x fewer multiplies; EDVR_WINOGRAD_F4=0 switches it off). */
+ * w % 4 == 0 run as Winograd F(4x4,3x3) (2.25 multiplies per output and channel pair where the direct algorithm needs 9 and
+ * F(2x2) 4; EDVR_WINOGRAD_F4=0 switches it off). */
 typedef struct edvr_conv2d_desc {
   const float *x1;        /* (n, c1, h, w) */
   const float *x2;        /* optional second input, concatenated after x1 on the channel axis */
@@ -99,19 +100,24 @@ typedef struct edvr_conv2d_desc {
   float *y;
   int64_t y_img_stride;   /* elements between images of y */
   int out_mode;           /* EDVR_OUT_* */
-  int algo;               /* EDVR_CONV_AUTO | EDVR_CONV_DIRECT | EDVR_CONV_WINOGRAD (falls back to direct where not applicable) */
+  int algo;               /* EDVR_CONV_AUTO | EDVR_CONV_DIRECT | EDVR_CONV_WINOGRAD (F(2x2); falls back to direct where not applicable) |
+                           * EDVR_CONV_WINOGRAD_F4 (needs wpk_f4; falls back to F(2x2), then direct) */
   const float *gate;      /* optional (n, co, ho, wo): y *= gate > 0 ? 1 : gate_slope, applied after bias / act.  This is the
                            * backward of a ReLU (slope 0) / LeakyReLU (0.1) fused into the data-gradient conv that produces its
-                           * input gradient (gate = the activation's forward output).  3x3 / stride 1 on the Winograd kernel only,
-                           * not together with residuals, sigmoid or PixelShuffle: EDVR_ERR_UNSUPPORTED otherwise. */
+                           * input gradient (gate = the activation's forward output).  3x3 kernels, NCHW output, no sigmoid
+                           * (EDVR_ERR_UNSUPPORTED otherwise).  The Winograd kernels take it when there are no residuals (their
+                           * fused-fast epilogue; edvr_conv2d_gate_supported asks for exactly that), every other 3x3 case - with
+                           * residuals, stride 2, small layers - runs in the direct kernel's generic store path. */
   int64_t gate_img_stride;
   float gate_slope;
   float y_scale;          /* y = y_scale * act(conv + bias) [gated] + res1 + res2; 0 means 1.  ResidualBlockNoBN's res_scale
-                           * (arch_util.py:95).  3x3 convs only (EDVR_ERR_UNSUPPORTED for 1x1 / <= 4 output channels / PixelShuffle). */
+                           * (arch_util.py:95).  3x3 kernels with the NCHW output only (EDVR_ERR_UNSUPPORTED for 1x1 / PixelShuffle); a scaled
+                           * conv with <= 4 output channels runs on the MFMA kernel instead of the small-co VALU kernel. */
   const float *wpk_f4;    /* optional: the same weights packed by edvr_conv2d_pack_weight_f4_f32.  Its presence ALLOWS the
                            * F(4x4,3x3) Winograd kernel (csrc/winograd_f4.hip: 2.25 instead of 4 multiplies per output; fp32
                            * rounding error ~1e-6 of the output scale instead of ~2e-7) under EDVR_CONV_AUTO where that kernel is the
-                           * fastest; NULL keeps the F(2x2) / direct choice.  Inference path: training leaves it NULL. */
+                           * fastest; NULL keeps the F(2x2) / direct choice.  edvr_amd's inference AND training paths (forward and
+                           * data-gradient convs; the weight gradient stays in the F(2x2) domain) pass it by default. */
 } edvr_conv2d_desc;
 
 size_t edvr_conv2d_packed_weight_elems(int co, int ci, int ks);
@@ -126,13 +132,18 @@ int edvr_conv2d_pack_weight_f32(const float *w, float *wpk, int co, int ci, int 
 size_t edvr_conv2d_packed_weight_f4_elems(int co, int ci);
 int edvr_conv2d_pack_weight_f4_f32(const float *w, float *wpk_f4, int co, int ci, int transpose_flip, edvr_stream_t stream);
 int edvr_conv2d_f32(const edvr_conv2d_desc *d, edvr_stream_t stream);
-/* 1 if edvr_conv2d_f32 would accept `d` with a `gate` (the Winograd kernel applies under d->algo, the sizes and the
- * EDVR_CONV_WINOGRAD environment switch), else 0.  Callers that fuse an activation backward into a data-gradient conv ask
- * first and keep the two-launch form otherwise. */
+/* 1 if `d` with a `gate` (and no residuals) would run in a Winograd kernel's fused epilogue (that kernel applies under d->algo,
+ * the sizes and the EDVR_CONV_WINOGRAD environment switch), else 0 (edvr_conv2d_f32 still accepts the gate on the direct
+ * kernel - correct, slower).  Callers that fuse an activation backward into a data-gradient conv ask first and keep the
+ * two-launch form otherwise.  Pointers of `d` need not be set. */
 int edvr_conv2d_gate_supported(const edvr_conv2d_desc *d);
 /* Name of the kernel template instantiation edvr_conv2d_f32 would launch for `d` (as rocprofv3 prints it),
  * written to buf; returns 0 or EDVR_ERR_*.  Measurement aid only. */
 int edvr_conv2d_kernel_name(const edvr_conv2d_desc *d, char *buf, size_t buf_len);
+/* Flops the fp32 matrix cores EXECUTE for that launch: for the two Winograd kernels the number of v_mfma_f32_32x32x2_f32 issued
+ * x 4096, tile and channel padding included (what rocprofv3's SQ_INSTS_VALU_MFMA_MOPS_F32 counts); for every other kernel the
+ * algorithmic 2 * n * ho * wo * co * ci * ks^2.  Measurement aid only (bench.py's roofline fraction). */
+int edvr_conv2d_executed_flops(const edvr_conv2d_desc *d, double *flops);
 
 /* ------------------------------------------------------------------ DCNv2 (modulated deformable conv)
  * x (B,C,H,W); offset (B, dg*2*kh*kw, Ho, Wo) channel = g*2K + 2k + {0:dy,1:dx};

@@ -30,6 +30,7 @@ from . import dcn_oracle
 # One flip right below `aligned` moves every PCD gradient by ~1e-3.  With _ACT_SIDES = {layer name: bool tensor "the other run
 # took the positive side"} every activation of this oracle takes the other run's side and keeps its own derivative there.
 _ACT_SIDES = None
+_FOLLOW_STATS = None  # list collecting, per followed decision point, how far the followed run is from this oracle's OWN values
 _FRAME = None  # (frame index, frames per clip) while the per-frame PCD loop runs: the other run batches all frames of a clip
 
 
@@ -47,6 +48,12 @@ def _side(z, name):
         i, t = _FRAME
         s = s.reshape(z.shape[0], t, *s.shape[1:])[:, i]
     assert s.shape == z.shape, (name, tuple(s.shape), tuple(z.shape))
+    if _FOLLOW_STATS is not None:  # elements where the followed run took the other side than this oracle would, and how close to
+        with torch.no_grad():      # the kink this oracle's pre-activation is there (a rounding-level |z|, or a real forward bug?)
+            flipped = (z > 0) != s
+            nf = int(flipped.sum())
+            band = float((z.abs() * flipped).max() / z.abs().max().clamp_min(1e-30)) if nf else 0.0
+        _FOLLOW_STATS.append(('act', name, nf, z.numel(), band))
     return s
 
 
@@ -114,7 +121,13 @@ def _follow(x, forced):
     """Value of `forced` (another run's tensor at this point), gradient of `x`: the discrete decisions taken downstream (which
     element a max-pool window routes its gradient to, which cell a deformable tap's floor() selects) then follow the other
     run, the derivative stays this run's."""
-    return x if forced is None else x + (forced.to(x) - x).detach()
+    if forced is None:
+        return x
+    forced = forced.to(x)
+    if _FOLLOW_STATS is not None:  # the followed tensor against this oracle's own value of it: a forward parity check per stage
+        with torch.no_grad():
+            _FOLLOW_STATS.append(('value', None, 0, x.numel(), float((forced - x).abs().max() / x.abs().max().clamp_min(1e-30))))
+    return x + (forced - x).detach()
 
 
 def tsa_fusion(sd, pre, aligned, center, taps=None, pool_inputs=None):
@@ -169,15 +182,18 @@ def _count(sd, prefix):
 
 
 def edvr_forward(sd, x, center=None, hr_in=False, with_predeblur=False, with_tsa=True, dg=8, dcn=None, taps=None,
-                 stats=None, pool_inputs=None, dcn_offsets=None, act_sides=None):
+                 stats=None, pool_inputs=None, dcn_offsets=None, act_sides=None, follow_stats=None):
     """x: (b, t, 3, h, w) -> (b, 3, 4h, 4w)  [or (b, 3, h, w) when hr_in].
-    pool_inputs / dcn_offsets / act_sides: test aids, the discrete decisions of another run (see _follow, _ACT_SIDES)."""
-    global _ACT_SIDES, _FRAME
-    _ACT_SIDES = act_sides
+    pool_inputs / dcn_offsets / act_sides: test aids, the discrete decisions of another run (see _follow, _ACT_SIDES).
+    follow_stats: a list; receives one record per followed decision point - ('act', layer, flipped elements, elements, largest
+    |pre-activation| among the flipped ones relative to the layer's max) or ('value', None, 0, elements, max |followed - own| /
+    max |own|) - so that a test can bound how far the followed run strays from this oracle's own forward pass."""
+    global _ACT_SIDES, _FRAME, _FOLLOW_STATS
+    _ACT_SIDES, _FOLLOW_STATS = act_sides, follow_stats
     try:
         return _edvr_forward(sd, x, center, hr_in, with_predeblur, with_tsa, dg, dcn, taps, stats, pool_inputs, dcn_offsets)
     finally:
-        _ACT_SIDES, _FRAME = None, None
+        _ACT_SIDES, _FRAME, _FOLLOW_STATS = None, None, None
 
 
 def _edvr_forward(sd, x, center, hr_in, with_predeblur, with_tsa, dg, dcn, taps, stats, pool_inputs, dcn_offsets):

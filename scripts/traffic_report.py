@@ -22,6 +22,14 @@ def load(path, counter):
     return per
 
 
+def source_hash():
+    """hash of the kernel sources this measurement was taken on (edvr_amd/build.py::source_hash)"""
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+    from edvr_amd.build import source_hash as h
+    return h()
+
+
 CALIB_BYTES = 20 * 128 * 180 * 320 * 4  # scripts/traffic_calib.py: every copy reads and writes this many bytes
 
 
@@ -63,6 +71,7 @@ def main():
         rep['calibration'] = {k: {'fetch': [v for v, _ in cf[k]], 'write': [v for v, _ in cw.get(k, [])], 'grid': [g for _, g in cf[k]]}
                               for k in cf if 'copy' in k.lower() or 'elementwise' in k.lower()}
     finalize(rep)
+    rep['csrc_sha16'] = source_hash()
     with open(out, 'w') as f:
         json.dump(rep, f, indent=1)
     for k, v in list(rep['kernels'].items())[:12]:

@@ -31,6 +31,33 @@ def test_roofline_fraction_is_executed_over_peak():
     assert abs(r['frac'] - 0.5) < 1e-3 and r['frac'] <= 1.0                 # executed = algorithmic / 4
     assert abs(r['algorithmic_over_peak'] - 2.0) < 1e-3
     assert r['traffic'] is None
+    # with the C side's count of the MFMAs actually issued (2 % padded tiles): the fraction is taken on THAT number
+    per = {'conv3x3_winograd_f4_kernel': [10, flops, secs, 0.0, 1.02 * flops / 4.0]}
+    r = b.roofline_object(per, 1, 4.0, 'no_such_workload', False)
+    assert abs(r['frac'] - 0.51) < 1e-3 and abs(r['padding_overhead'] - 0.02) < 1e-3
+    assert abs(r['executed_without_padding_tflops'] - 0.5 * 157.3) < 0.1
+    assert 'padding included' in r['definition']
+
+
+def test_executed_flops_of_the_c_side_equal_the_pmc_count():
+    """edvr_conv2d_executed_flops on the micro layer of profiles/r2/winograd_f4_micro_pmc.json (n = 20, 128 -> 128, 180 x 320):
+    rocprofv3 counted SQ_INSTS_VALU_MFMA_MOPS_F32 = 169 574 400 over 8 launches of that layer, one count per 512 flops."""
+    import ctypes
+    from edvr_amd import _lib
+    d = _lib.ConvDesc()
+    d.c1, d.n, d.h, d.w, d.co, d.ks, d.stride, d.algo = 128, 20, 180, 320, 128, 3, 1, _lib.CONV_AUTO
+    d.wpk_f4 = 16  # any non-null, 16-byte aligned address: only the eligibility rules look at it
+    ex = ctypes.c_double(0.0)
+    assert _lib.lib().edvr_conv2d_executed_flops(ctypes.byref(d), ctypes.byref(ex)) == 0
+    pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r2', 'winograd_f4_micro_pmc.json')))
+    assert ex.value == pmc['SQ_INSTS_VALU_MFMA_MOPS_F32'] * 512.0, (ex.value, pmc['SQ_INSTS_VALU_MFMA_MOPS_F32'])
+    assert abs(ex.value / (2.0 * 9 * 128 * 128 * 20 * 180 * 320 / 4.0) - 1.0) < 0.03  # ~2 % tile padding over algorithmic / 4
+    d.wpk_f4 = None  # without the F(4x4) weights the launch is the F(2x2) kernel: 8 x 32 pixel items, 16 positions
+    assert _lib.lib().edvr_conv2d_executed_flops(ctypes.byref(d), ctypes.byref(ex)) == 0
+    assert ex.value == 20 * 2 * (10 * 23) * 128 * (64.0 * 64 * 16 * 2)
+    d.algo = _lib.CONV_DIRECT
+    assert _lib.lib().edvr_conv2d_executed_flops(ctypes.byref(d), ctypes.byref(ex)) == 0
+    assert ex.value == 2.0 * 9 * 128 * 128 * 20 * 180 * 320
 
 
 def test_measured_traffic_aggregates_template_instantiations():

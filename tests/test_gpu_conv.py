@@ -109,47 +109,3 @@ def test_transpose_flip_pack_is_data_gradient(gpu):
     wpk = ops.pack_conv_weight(wt.float().to(gpu), transpose_flip=True)
     dx = ops.conv2d(dy.float().to(gpu), wpk, None, 24, 3)
     assert _rel(dx, x.grad) < RTOL
-
-
-def test_four_wave_winograd_kernel_matches_the_direct_kernel():
-    """csrc/winograd4.hip (opt-in experiment, EDVR_WINOGRAD_4WAVE=1 - read once per process, hence the child process): every
-    epilogue variant, a concatenated second input read through the frame map, ragged sizes, the gate - against the direct kernel."""
-    import os
-    import subprocess
-    import sys
-    import torch
-    if not torch.cuda.is_available():
-        pytest.skip('no GPU')
-    code = '''
-import ctypes, torch
-from edvr_amd import ops, _lib
-g = torch.Generator().manual_seed(21)
-dev = torch.device("cuda")
-def rel(a, b): return ((a - b).abs().max() / b.abs().max()).item()
-cases = [(2, 64, 0, 20, 36, 64, {}), (3, 128, 0, 33, 70, 128, dict(act=ops.ACT_LRELU)), (2, 48, 0, 12, 40, 80, dict(act=ops.ACT_RELU, res=1)),
-         (4, 64, 64, 18, 34, 64, dict(x2map=(2, 2, 1))), (1, 32, 0, 16, 32, 216, dict(act=ops.ACT_SIGMOID, act_from=144)),
-         (1, 64, 0, 10, 34, 256, dict(act=ops.ACT_LRELU, out_mode=ops.OUT_PIXEL_SHUFFLE2)), (2, 64, 0, 9, 21, 64, dict(res=2)), (2, 64, 0, 14, 38, 64, dict(gate=0.1))]
-for n, c1, c2, h, w, co, kw in cases:
-    x1 = torch.randn(n, c1, h, w, generator=g).to(dev)
-    x2 = torch.randn(n, c2, h, w, generator=g).to(dev) if c2 else None
-    wt = (torch.randn(co, c1 + c2, 3, 3, generator=g) * 0.05).to(dev)
-    b = torch.randn(co, generator=g).to(dev)
-    args = dict(x2=x2, x2_map=kw.get("x2map"), act=kw.get("act", 0), act_from=kw.get("act_from", 0), out_mode=kw.get("out_mode", 0))
-    nres = kw.get("res", 0)
-    if nres: args["res1"] = torch.randn(n, co, h, w, generator=g).to(dev)
-    if nres > 1: args["res2"] = torch.randn(n, co, h, w, generator=g).to(dev)
-    if "gate" in kw: args.update(gate=torch.randn(n, co, h, w, generator=g).relu().to(dev), gate_slope=kw["gate"])
-    wpk = ops.pack_conv_weight(wt)
-    d = _lib.ConvDesc(); d.c1, d.c2, d.n, d.h, d.w, d.co, d.ks, d.stride, d.algo = c1, c2, n, h, w, co, 3, 1, ops.CONV_WINOGRAD
-    d.x1 = x1.data_ptr(); d.x2 = x2.data_ptr() if c2 else None
-    buf = ctypes.create_string_buffer(96); _lib.lib().edvr_conv2d_kernel_name(ctypes.byref(d), buf, 96)
-    assert buf.value == b"conv3x3_winograd4_kernel", buf.value
-    a4 = ops.conv2d(x1, wpk, b, co, 3, algo=ops.CONV_WINOGRAD, **args)
-    ad = ops.conv2d(x1, wpk, b, co, 3, algo=ops.CONV_DIRECT, **args)
-    assert rel(a4, ad) < 2e-5, (n, c1, c2, h, w, co, kw, rel(a4, ad))
-print("ok")
-'''
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, EDVR_WINOGRAD_4WAVE='1', PYTHONPATH=root), capture_output=True,
-                       text=True, timeout=600)
-    assert r.returncode == 0 and 'ok' in r.stdout, r.stdout + r.stderr

@@ -66,7 +66,7 @@ def _kernels_of(fn):
     from edvr_amd import ops
     names = []
 
-    def hook(name, flops, launch, nbytes):
+    def hook(name, flops, launch, nbytes, executed=None):
         names.append(name)
         launch()
 

@@ -114,3 +114,63 @@ def test_edvr_l_full_size_forward_is_finite_and_batch_consistent(gpu):
         one = torch.cat([net(x[:1]), net(x[1:])], 0)
     assert torch.isfinite(both).all() and both.shape == (2, 3, 4 * H, 4 * W)
     assert _rel(both, one) < 1e-5
+
+
+# ---- the F(4x4,3x3) Winograd kernel at the launch shape of the headline workload: 10 clips x 5 frames = 50 images, 128 -> 128
+#      channels, 180 x 320 (11 250 items of 64 channels x 32 tiles walked by 256 persistent workgroups)
+N50 = 50
+
+
+@pytest.fixture(scope='module')
+def data50(gpu):
+    g = torch.Generator(device=gpu).manual_seed(11)
+    x = torch.randn(N50, C, H, W, device=gpu, generator=g)
+    y = torch.randn(N50, C, H, W, device=gpu, generator=g)
+    w = torch.randn(C, C, 3, 3, device=gpu, generator=g) * 0.03
+    b = torch.randn(C, device=gpu, generator=g)
+    return x, y, w, b
+
+
+def _f4(ops, x, w, b=None, flip=False, **kw):
+    import ctypes
+    from edvr_amd import _lib
+    wpk, wf4 = ops.pack_conv_weight(w, transpose_flip=flip), ops.pack_conv_weight(w, transpose_flip=flip, f4=True)
+    d = _lib.ConvDesc()
+    d.c1, d.n, d.h, d.w, d.co, d.ks, d.stride, d.algo = x.shape[1], x.shape[0], x.shape[2], x.shape[3], C, 3, 1, ops.CONV_WINOGRAD_F4
+    d.x1, d.wpk_f4 = x.data_ptr(), wf4.data_ptr()
+    buf = ctypes.create_string_buffer(96)
+    _lib.lib().edvr_conv2d_kernel_name(ctypes.byref(d), buf, 96)
+    assert buf.value == b'conv3x3_winograd_f4_kernel', buf.value
+    return ops.conv2d(x, wpk, b, C, 3, wpk_f4=wf4, algo=ops.CONV_WINOGRAD_F4, **kw)
+
+
+def test_f4_agrees_with_the_direct_kernel_at_the_bench_launch_shape(gpu, data50):
+    """Independent algorithm, tiling, staging and epilogue code on the full 50-image launch, three epilogues."""
+    from edvr_amd import ops
+    x, y, w, b = data50
+    wpk = ops.pack_conv_weight(w)
+    for kw in (dict(act=ops.ACT_LRELU), dict(act=ops.ACT_RELU, res1=y), dict()):
+        d = ops.conv2d(x, wpk, b, C, 3, algo=ops.CONV_DIRECT, **kw)
+        f = _f4(ops, x, w, b, **kw)
+        assert _rel(f, d) < 3e-5
+        del d, f
+
+
+def test_f4_is_linear_at_the_bench_launch_shape(gpu, data50):
+    from edvr_amd import ops
+    x, y, w, _ = data50
+    lhs = _f4(ops, 1.5 * x - 0.25 * y, w)
+    rhs = 1.5 * _f4(ops, x, w) - 0.25 * _f4(ops, y, w)
+    assert _rel(lhs, rhs) < 3e-5
+
+
+def test_f4_data_gradient_is_the_adjoint_at_the_bench_launch_shape(gpu, data50):
+    """<dy, conv_W(x)> == <conv_{W^T flipped}(dy), x>: the transpose_flip packing run through the same kernel is the adjoint
+    of the forward - ties the F(4x4) data gradient of the training path to its forward at full size."""
+    from edvr_amd import ops
+    x, dy, w, _ = data50
+    out = _f4(ops, x, w)
+    lhs = (dy.double() * out.double()).sum().item()
+    del out
+    dx = _f4(ops, dy, w, flip=True)
+    assert abs((dx.double() * x.double()).sum().item() - lhs) / abs(lhs) < 1e-4
