@@ -347,19 +347,21 @@ def make_train_step(net, cfg, batch, device, rank, optimizer, x=None):
 
 
 def timed(step, steps, warmup, dist, device):
+    """W untimed steps, then EXACTLY `steps` steps bracketed by barrier + synchronize on both sides; returns the MAX over ranks."""
+    sync = torch.cuda.synchronize if device.type == 'cuda' else (lambda: None)  # (cpu: the world-size-2 gloo test of this function)
     for _ in range(warmup):
         step()
-    torch.cuda.synchronize()
+    sync()
     if dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         out = step()
-    torch.cuda.synchronize()
+    sync()
     if dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -439,6 +441,17 @@ def target_4k_leg(net, args, device, rank, world, dist):
     return out
 
 
+def spawn_command(gpus, port, argv):
+    """The launch `python bench.py --gpus N` performs outside a torchrun environment: N ranks of this script on this node, one
+    per GPU, rendezvous on 127.0.0.1 (the container hostname may not resolve), the script's own arguments passed through."""
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={gpus}', '--master-addr', '127.0.0.1',
+            '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def spawn_env(environ):
+    return dict(environ, HSA_ENABLE_IPC_MODE_LEGACY='0')  # the host driver only supports dmabuf IPC (RCCL / tensor sharing across processes)
+
+
 def self_spawn(args):
     """`python bench.py --gpus N` outside torchrun: run N ranks of this script on this node (RCCL over xGMI)."""
     n = torch.cuda.device_count()
@@ -446,10 +459,13 @@ def self_spawn(args):
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    sys.exit(subprocess.call(cmd, env=env))
+    sys.exit(subprocess.call(spawn_command(args.gpus, port, sys.argv[1:]), env=spawn_env(os.environ)))
+
+
+def emit(result, rank):
+    """Rank 0 prints the ONE JSON line of the run; every other rank prints nothing."""
+    if rank == 0:
+        print(json.dumps(result), flush=True)
 
 
 def main():
@@ -557,8 +573,7 @@ def main():
                 result['stock_rocm_baseline'] = stock_rocm_baseline(cfg, device, ours)
             except Exception as e:  # a baseline arm must never take the measurement down (e.g. MIOpen workspace failure)
                 result['stock_rocm_baseline'] = {'error': f'{type(e).__name__}: {str(e)[:200]}'}
-    if rank == 0:
-        print(json.dumps(result), flush=True)
+    emit(result, rank)
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,0 +1,89 @@
+"""`deform_conv_ext` over libedvr_amd.so: the five functions of the reference's pybind11 CUDA extension
+(basicsr/models/ops/dcn/src/deform_conv_ext.cpp:149-164) with the SAME argument lists, so that the reference's own Python
+(basicsr/models/ops/dcn/deform_conv.py, unchanged) runs on the HIP kernels.  Drop this file in as
+`basicsr/models/ops/dcn/deform_conv_ext.py` (or put `edvr_amd.compat` on the import path under that name); nothing is compiled
+on the BasicSR side.
+
+    modulated_deform_conv_forward / _backward     deform_conv_ext.cpp:106-147  ->  edvr_dcnv2_{fwd,bwd}_f32
+    deform_conv_forward                           deform_conv_ext.cpp:51-66    ->  edvr_dcnv1_fwd_f32
+    deform_conv_backward_input / _parameters      deform_conv_ext.cpp:68-104   ->  edvr_dcnv1_bwd_f32
+
+Semantics kept from deform_conv_cuda.cpp (the callers rely on them):
+  * every tensor is allocated by the caller (deform_conv.py:37-41,71-86,138-140,154-158); `output` is overwritten;
+  * the gradients the reference ACCUMULATES into - grad_input (col2im's atomicAdd, .cu:688 / :322), grad_weight and grad_bias
+    (addmm_ with beta = 1, deform_conv_cuda.cpp:460-468,659-672; `scale` for DCNv1) - are accumulated here too: the caller's
+    pre-zeroed buffers give the plain gradient, non-zero buffers keep their contents; grad_offset / grad_mask are overwritten
+    as the reference's coord kernels do;
+  * `columns` / `ones` / `im2col_step` are scratch / blocking arguments of the reference's implementation: accepted, unused (the
+    workspace is the explicit, grow-only one of edvr_amd.ops);
+  * launches go to the current stream under the tensors' device; no host synchronisation;
+  * contiguity of input / weight is required like deform_conv_cuda.cpp:497-498, kernel sizes are checked against the weight like
+    :507-512; CPU tensors are refused ("not implemented on CPU", deform_conv_ext.cpp:66,85,103,123,145).
+"""
+import torch
+
+from .. import ops
+
+
+def _check(input, weight, kh, kw, group):
+    for t in (input, weight):
+        if not t.is_cuda:
+            raise RuntimeError('deformable conv is not implemented on CPU')  # deform_conv_ext.cpp:66
+        if not t.is_contiguous():
+            raise RuntimeError('input tensor has to be contiguous')
+    if weight.shape[2] != kh or weight.shape[3] != kw:
+        raise RuntimeError(f'Input shape and kernel shape wont match: ({kh} x {kw} vs {weight.shape[2]} x {weight.shape[3]}).')
+    if input.shape[1] != weight.shape[1] * group:
+        raise RuntimeError(f'Input shape and kernel channels wont match: ({input.shape[1]} vs {weight.shape[1] * group}).')
+
+
+# ------------------------------------------------------------------------------------------------ DCNv2
+def modulated_deform_conv_forward(input, weight, bias, ones, offset, mask, output, columns, kernel_h, kernel_w, stride_h, stride_w,
+                                  pad_h, pad_w, dilation_h, dilation_w, group, deformable_group, with_bias):
+    _check(input, weight, kernel_h, kernel_w, group)
+    y = ops.dcnv2_forward(input, offset, mask, weight, bias if with_bias else None, (stride_h, stride_w), (pad_h, pad_w),
+                          (dilation_h, dilation_w), group, deformable_group)
+    output.view_as(y).copy_(y)
+
+
+def modulated_deform_conv_backward(input, weight, bias, ones, offset, mask, columns, grad_input, grad_weight, grad_bias, grad_offset,
+                                   grad_mask, grad_output, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w,
+                                   group, deformable_group, with_bias):
+    _check(input, weight, kernel_h, kernel_w, group)
+    dx, doff, dmsk, dw, db = ops.dcnv2_backward(input, offset, mask, weight, grad_output, bool(with_bias), (stride_h, stride_w),
+                                                (pad_h, pad_w), (dilation_h, dilation_w), group, deformable_group)
+    grad_input.view_as(dx).add_(dx)
+    grad_weight.add_(dw)
+    if with_bias:
+        grad_bias.add_(db)
+    grad_offset.copy_(doff)
+    grad_mask.copy_(dmsk)
+
+
+# ------------------------------------------------------------------------------------------------ DCNv1
+def deform_conv_forward(input, weight, offset, output, columns, ones, kW, kH, dW, dH, padW, padH, dilationW, dilationH, group,
+                        deformable_group, im2col_step):
+    _check(input, weight, kH, kW, group)
+    y = ops.dcnv1_forward(input, offset, weight, (dH, dW), (padH, padW), (dilationH, dilationW), group, deformable_group)
+    output.view_as(y).copy_(y)
+    return 1  # the reference returns 1 on success (deform_conv_cuda.cpp:242)
+
+
+def deform_conv_backward_input(input, offset, gradOutput, gradInput, gradOffset, weight, columns, kW, kH, dW, dH, padW, padH, dilationW,
+                               dilationH, group, deformable_group, im2col_step):
+    _check(input, weight, kH, kW, group)
+    dx, doff, _ = ops.dcnv1_backward(input, offset, weight, gradOutput, (dH, dW), (padH, padW), (dilationH, dilationW), group,
+                                     deformable_group)
+    gradInput.view_as(dx).add_(dx)
+    gradOffset.copy_(doff)
+    return 1
+
+
+def deform_conv_backward_parameters(input, offset, gradOutput, gradWeight, columns, ones, kW, kH, dW, dH, padW, padH, dilationW,
+                                    dilationH, group, deformable_group, scale, im2col_step):
+    _check(input, gradWeight, kH, kW, group)
+    weight = torch.zeros_like(gradWeight)  # d(weight) does not depend on the weight values; the one-call ABI wants a pointer
+    _, _, dw = ops.dcnv1_backward(input, offset, weight, gradOutput, (dH, dW), (padH, padW), (dilationH, dilationW), group,
+                                  deformable_group)
+    gradWeight.add_(dw, alpha=float(scale))
+    return 1

@@ -37,7 +37,8 @@ namespace edvr {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct DcnShape {
-  int B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, Ho, Wo;
+  int B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, Ho, Wo;  // stride / pad / dil: along h
+  int stride_w, pad_w, dil_w;                                        // along w (EDVR_HW pairs of the C ABI; equal to the h values otherwise)
   int64_t off_bs, msk_bs;    // image strides of offset / mask (inputs)
   int64_t doff_bs, dmsk_bs;  // image strides of doffset / dmask (backward outputs)
 };
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(const float *__restrict
     const float *off_b = offset + (int64_t)b * s.off_bs + (int64_t)(g * 2 * K + 2 * k) * P + p;
     const float dy = off_b[0], dx = off_b[P];
     const float m = mask[(int64_t)b * s.msk_bs + (int64_t)(g * K + k) * P + p];
-    const Tap t = resolve_tap((float)(ho * s.stride - s.pad + i * s.dil) + dy, (float)(wo * s.stride - s.pad + j * s.dil) + dx, s.H, s.W);
+    const Tap t = resolve_tap((float)(ho * s.stride - s.pad + i * s.dil) + dy, (float)(wo * s.stride_w - s.pad_w + j * s.dil_w) + dx, s.H, s.W);
     const float *xp = x + ((int64_t)b * s.C + (int64_t)g * cpg) * s.H * s.W;
     float *cp = col + ((int64_t)b * s.C * K + (int64_t)(g * cpg) * K + k) * P + p;
     const int64_t plane = (int64_t)s.H * s.W;
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_coord_kernel(const float *__restr
     const float *off_b = offset + (int64_t)b * s.off_bs + (int64_t)(g * 2 * K + 2 * k) * P + p;
     const float dy = off_b[0], dxo = off_b[P];
     const float m = mask[(int64_t)b * s.msk_bs + (int64_t)(g * K + k) * P + p];
-    const Tap t = resolve_tap((float)(ho * s.stride - s.pad + i * s.dil) + dy, (float)(wo * s.stride - s.pad + j * s.dil) + dxo, s.H, s.W);
+    const Tap t = resolve_tap((float)(ho * s.stride - s.pad + i * s.dil) + dy, (float)(wo * s.stride_w - s.pad_w + j * s.dil_w) + dxo, s.H, s.W);
     // d(bilinear)/dh and /dw weights per corner (zero where the corner is outside or the tap invalid)
     const float hh = 1.f - t.lh, hw = 1.f - t.lw;
     const bool ok00 = t.ok00, ok01 = t.ok01, ok10 = t.ok10, ok11 = t.ok11;
@@ -663,14 +664,25 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 static int fill_shape(DcnShape &s, int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil, int groups,
                       int dg, int64_t off_bs, int64_t msk_bs) {
-  EDVR_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Co > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0 && dil > 0 && groups > 0 && dg > 0,
+  // stride / pad / dil may carry an (h, w) pair: EDVR_HW(h, w) = h | (w + 1) << 16 (include/edvr_amd.h); a plain value means h == w
+  auto hw_pair = [](int v, int &h, int &w) {
+    h = v & 0xffff;
+    w = (v >> 16) ? (v >> 16) - 1 : h;
+  };
+  int stride_w, pad_w, dil_w;
+  EDVR_REQUIRE(stride > 0 && pad >= 0 && dil > 0, "dcnv2: non-positive stride / dilation or negative padding");
+  hw_pair(stride, stride, stride_w);
+  hw_pair(pad, pad, pad_w);
+  hw_pair(dil, dil, dil_w);
+  EDVR_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Co > 0 && kh > 0 && kw > 0 && stride > 0 && stride_w > 0 && dil > 0 && dil_w > 0 && groups > 0 && dg > 0,
                "dcnv2: non-positive size");
   EDVR_REQUIRE(C % groups == 0 && Co % groups == 0, "dcnv2: channels (%d -> %d) not divisible by groups %d", C, Co, groups);
   EDVR_REQUIRE(C % dg == 0, "dcnv2: channels %d not divisible by deformable_groups %d", C, dg);
   s.B = B; s.C = C; s.H = H; s.W = W; s.Co = Co; s.kh = kh; s.kw = kw; s.stride = stride; s.pad = pad; s.dil = dil;
+  s.stride_w = stride_w; s.pad_w = pad_w; s.dil_w = dil_w;
   s.groups = groups; s.dg = dg;
   s.Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1;
-  s.Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
+  s.Wo = (W + 2 * pad_w - (dil_w * (kw - 1) + 1)) / stride_w + 1;
   EDVR_REQUIRE(s.Ho > 0 && s.Wo > 0, "dcnv2: convolution input is too small (output would be %dx%d)", s.Ho, s.Wo);
   const int64_t P = (int64_t)s.Ho * s.Wo, K = kh * kw;
   s.off_bs = off_bs ? off_bs : (int64_t)dg * 2 * K * P;
@@ -683,6 +695,7 @@ static int fill_shape(DcnShape &s, int B, int C, int H, int W, int Co, int kh, i
 static bool use_fused(const DcnShape &s) {
   const char *e = getenv("EDVR_DCN_FUSED");  // "0": force the generic column-buffer path (A/B, tests)
   if (e && e[0] == '0') return false;
+  if (s.stride != s.stride_w || s.pad != s.pad_w || s.dil != s.dil_w) return false;
   return dcn_fused_supported(s.C, s.Co, s.H, s.W, s.kh, s.kw, s.stride, s.pad, s.dil, s.groups, s.dg);
 }
 
@@ -844,7 +857,7 @@ int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, c
     const char *e = getenv("EDVR_DCN_BWD_TILE");  // "0": never use the LDS-window kernel (A/B)
     return !(e && e[0] == '0');
   }();
-  const bool edvr_sig = kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1;
+  const bool edvr_sig = kh == 3 && kw == 3 && s.stride == 1 && s.pad == 1 && s.dil == 1 && s.stride_w == 1 && s.pad_w == 1 && s.dil_w == 1;
   if (scatter_hint == EDVR_DCN_SCATTER_STRIP && edvr_sig && dg * cdiv(W, 64) <= 65535) {
     // dX by the register-ring kernel (reads dcol before the next kernel rewrites it), then dOffset / dMask / columns without dX
     hipLaunchKernelGGL(dcn_bwd_dx_strip_kernel, dim3(dg * cdiv(W, 64), B), dim3(256), 0, stream, offset, mask, col, dx, s);

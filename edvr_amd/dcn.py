@@ -119,15 +119,13 @@ class DeformConvFunction(Function):
     def forward(ctx, input, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1, im2col_step=64):
         if input is not None and input.dim() != 4:
             raise ValueError(f'Expected 4D tensor as input, got {input.dim()}D tensor instead.')
-        stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
-        if stride[0] != stride[1] or padding[0] != padding[1] or dilation[0] != dilation[1]:
-            raise NotImplementedError('edvr_amd DeformConv: square stride / padding / dilation only')
+        stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)  # (h, w) pairs, :33-35
         if not input.is_cuda:
             raise NotImplementedError
         cur = min(im2col_step, input.shape[0])
         assert (input.shape[0] % cur) == 0, 'im2col step must divide batchsize'
         DeformConvFunction._output_size(input, weight, padding, dilation, stride)  # raises like the reference if too small
-        ctx.cfg = (stride[0], padding[0], dilation[0], groups, deformable_groups)
+        ctx.cfg = (stride, padding, dilation, groups, deformable_groups)  # rectangular pairs travel as EDVR_HW(h, w) (ops._enc_hw)
         ctx.save_for_backward(input, offset, weight)
         return ops.dcnv1_forward(input.contiguous(), offset, weight.contiguous(), *ctx.cfg)
 

@@ -14,7 +14,10 @@ What differs is how the graph is executed:
     of being cloned t times (:392-401);
   * conv_offset's output is consumed as zero-copy channel slices with the mask sigmoid fused;
     the `offset abs mean > 50` check (arch_util.py:248-253) is evaluated once per forward instead
-    of forcing 4*t host synchronisations;
+    of forcing 4*t host synchronisations - and WITHOUT any host synchronisation in no-grad
+    (inference) mode: the statistics travel to pinned memory asynchronously and are examined when
+    the next forward starts (or on `EDVR.check_offsets()`), so a b = 1 streaming loop keeps
+    running ahead of the GPU;
   * TSA temporal attention (t dot-products + sigmoid + broadcast multiply, :171-184) is one
     bandwidth-bound kernel; max+avg pooling and their concat are one kernel.
 """
@@ -194,6 +197,7 @@ class EDVR(nn.Module):
         self.conv_last = _conv3(64, 3)
         self.lrelu = nn.LeakyReLU(negative_slope=0.1, inplace=True)
         self.taps = None  # set to a dict to collect intermediates (parity tests)
+        self._pending_offset_stats = []  # (pinned host tensor, copy-done event, per-layer records) of earlier no-grad forwards
 
     def forward(self, x):
         b, t, c, h, w = x.shape
@@ -203,6 +207,7 @@ class EDVR(nn.Module):
             assert h % 4 == 0 and w % 4 == 0, 'The height and width must be multiple of 4.'
         x = x.contiguous()
         ctr = self.center_frame_idx
+        self.check_offsets(wait=False)  # offset statistics of earlier forwards whose copy has landed: no synchronisation
         frames = x.view(b * t, c, h, w)
         if self.with_predeblur:
             f1 = F_.conv(self.conv_1x1, self.predeblur(frames))
@@ -242,19 +247,46 @@ class EDVR(nn.Module):
             out = F_.conv(self.conv_last, out, res1=x_center)
         else:
             out = F_.upsample4x_add(F_.conv(self.conv_last, out), x_center)
-        self._check_offsets(sink, b, t)
+        self._queue_offset_check(sink, b, t)
         return out
 
-    @staticmethod
-    def _check_offsets(sink, b, t):
-        """arch_util.py:248-253, evaluated per (DCN layer, frame) like the reference's per-call check,
-        with ONE device->host copy per forward."""
+    def _queue_offset_check(self, sink, b, t):
+        """arch_util.py:248-253, evaluated per (DCN layer, frame) like the reference's per-call check, with ONE device->host
+        copy per forward.  Training (grad mode) evaluates it right away - the backward of the same iteration picks its dX
+        strategy from these statistics.  No-grad forwards do not wait for the GPU: the copy goes to pinned memory behind an
+        event and is examined by `check_offsets` (called when the next forward starts, or by the user)."""
         if not sink:
             return
         import torch
-        sums = torch.stack([e[0] for e in sink]).view(len(sink), b, t).sum(1).cpu()  # (layers, t)
-        for li, (_, per_img, module) in enumerate(sink):
-            per_frame = (sums[li] / (b * per_img)).tolist()
+        sums = torch.stack([e[0] for e in sink]).view(len(sink), b, t).sum(1)  # (layers, t), on the device
+        recs = [(per_img * b, module) for _, per_img, module in sink]
+        if torch.is_grad_enabled():
+            self._examine_offsets(sums.cpu(), recs)
+            return
+        host = torch.empty(sums.shape, dtype=sums.dtype, pin_memory=True)
+        host.copy_(sums, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        self._pending_offset_stats.append((host, done, recs))
+        if len(self._pending_offset_stats) > 64:  # a caller that never lets the GPU catch up: bound the queue
+            self.check_offsets(wait=True)
+
+    def check_offsets(self, wait=True):
+        """Evaluate the `Offset abs mean is ..., larger than 50` check of the no-grad forwards issued so far.  wait=False only
+        looks at forwards whose statistics have already arrived on the host (never blocks)."""
+        while self._pending_offset_stats:
+            host, done, recs = self._pending_offset_stats[0]
+            if wait:
+                done.synchronize()
+            elif not done.query():
+                return
+            self._pending_offset_stats.pop(0)
+            self._examine_offsets(host, recs)
+
+    @staticmethod
+    def _examine_offsets(sums, recs):
+        for li, (count, module) in enumerate(recs):
+            per_frame = (sums[li] / count).tolist()
             module.last_offset_absmean = sum(per_frame) / len(per_frame)
             for v in per_frame:
                 warn_offset_absmean(v)

@@ -258,10 +258,21 @@ def dcnv1_backward(x, offset, weight, dy, stride, pad, dil, groups, dg, scatter_
 
 
 # ------------------------------------------------------------------------------------------------ DCNv2
+def _hw(v):
+    """int or (h, w) pair -> (h, w)"""
+    return (int(v[0]), int(v[1])) if isinstance(v, (tuple, list)) else (int(v), int(v))
+
+
+def _enc_hw(v):
+    """EDVR_HW of include/edvr_amd.h: one int for an (h, w) pair; a square pair stays the plain value."""
+    h, w = _hw(v)
+    return h if h == w else (h | ((w + 1) << 16))
+
+
 def _dcn_dims(x, weight, stride, pad, dil, groups, dg):
     B, C, H, W = x.shape
     Co, cig, kh, kw = weight.shape
-    return [B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg]
+    return [B, C, H, W, Co, kh, kw, _enc_hw(stride), _enc_hw(pad), _enc_hw(dil), groups, dg]
 
 
 def _bstride(t):
@@ -279,8 +290,9 @@ def dcnv2_forward(x, offset, mask, weight, bias, stride, pad, dil, groups, dg, a
     B, C, H, W, Co, kh, kw = dims[:7]
     if C != weight.shape[1] * groups:
         raise RuntimeError(f'Input shape and kernel channels wont match: ({C} vs {weight.shape[1] * groups}).')
-    Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1
-    Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) // stride + 1
+    (sh, sw), (ph, pw), (dh, dw) = _hw(stride), _hw(pad), _hw(dil)
+    Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
+    Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
     if Ho <= 0 or Wo <= 0:
         raise ValueError(f'convolution input is too small (output would be {Ho}x{Wo})')
     assert tuple(offset.shape[1:]) == (dg * 2 * kh * kw, Ho, Wo), f'offset shape {tuple(offset.shape)}'

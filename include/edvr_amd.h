@@ -145,6 +145,12 @@ int edvr_conv2d_kernel_name(const edvr_conv2d_desc *d, char *buf, size_t buf_len
  * algorithmic 2 * n * ho * wo * co * ci * ks^2.  Measurement aid only (bench.py's roofline fraction). */
 int edvr_conv2d_executed_flops(const edvr_conv2d_desc *d, double *flops);
 
+/* stride / pad / dil arguments of the DCN entry points below: a plain value n means (h, w) = (n, n); EDVR_HW(h, w) passes a
+ * rectangular pair in one int (h <= 65535 in the low half, w + 1 in the high half).  The reference's DCNv1 Python takes pairs
+ * (deform_conv.py:33-36,56-58 -> kW, kH, dW, dH, padW, padH, dilationW, dilationH of deform_conv_ext.cpp:51-104); its DCNv2 Python
+ * only ever passes equal values (deform_conv.py:141-146).  Rectangular geometries run on the generic column-buffer kernels. */
+#define EDVR_HW(h, w) ((int)(h) | (((int)(w) + 1) << 16))
+
 /* ------------------------------------------------------------------ DCNv2 (modulated deformable conv)
  * x (B,C,H,W); offset (B, dg*2*kh*kw, Ho, Wo) channel = g*2K + 2k + {0:dy,1:dx};
  * mask (B, dg*kh*kw, Ho, Wo); weight (Co, C/groups, kh, kw); bias (Co) or NULL; y (B,Co,Ho,Wo).

@@ -59,8 +59,14 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+def _hw(v):
+    """int or (h, w) pair -> (h, w)  (deform_conv.py:33-36 `_pair`)"""
+    return (int(v[0]), int(v[1])) if isinstance(v, (tuple, list)) else (int(v), int(v))
+
+
 def _out_hw(H, W, kh, kw, stride, pad, dil):
-    return ((H + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1, (W + 2 * pad - (dil * (kw - 1) + 1)) // stride + 1)
+    (sh, sw), (ph, pw), (dh, dw) = _hw(stride), _hw(pad), _hw(dil)
+    return ((H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1, (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1)
 
 
 def _prep(*ts):
@@ -153,11 +159,12 @@ def dcnv2_torch(x, offset, mask, weight, bias=None, stride=1, padding=0, dilatio
     Co, cig, kh, kw = weight.shape
     K, cpg, dt = kh * kw, C // dg, x.dtype
     Ho, Wo = _out_hw(H, W, kh, kw, stride, padding, dilation)
+    (sh, sw), (ph, pw), (dh, dw) = _hw(stride), _hw(padding), _hw(dilation)  # pairs: DCNv1 (deform_conv.py:33-36), .cu:211-216
     dev = x.device
-    ys = (torch.arange(Ho, dtype=dt, device=dev) * stride - padding).view(1, 1, 1, Ho, 1)
-    xs = (torch.arange(Wo, dtype=dt, device=dev) * stride - padding).view(1, 1, 1, 1, Wo)
-    ki = (torch.arange(kh, dtype=dt, device=dev) * dilation).repeat_interleave(kw).view(1, 1, K, 1, 1)
-    kj = (torch.arange(kw, dtype=dt, device=dev) * dilation).repeat(kh).view(1, 1, K, 1, 1)
+    ys = (torch.arange(Ho, dtype=dt, device=dev) * sh - ph).view(1, 1, 1, Ho, 1)
+    xs = (torch.arange(Wo, dtype=dt, device=dev) * sw - pw).view(1, 1, 1, 1, Wo)
+    ki = (torch.arange(kh, dtype=dt, device=dev) * dh).repeat_interleave(kw).view(1, 1, K, 1, 1)
+    kj = (torch.arange(kw, dtype=dt, device=dev) * dw).repeat(kh).view(1, 1, K, 1, 1)
     off = offset.reshape(B, dg, K, 2, Ho, Wo)
     py = ys + ki + off[:, :, :, 0]
     px = xs + kj + off[:, :, :, 1]
@@ -188,8 +195,9 @@ def ref_dcn1_forward(x, offset, weight, stride=1, padding=0, dilation=1, groups=
     Co, _, kh, kw = weight.shape
     Ho, Wo = _out_hw(H, W, kh, kw, stride, padding, dilation)
     y = torch.empty(B, Co, Ho, Wo, dtype=torch.float64)
-    rc = lib.ref_dcn1_forward_f64(_p(x), _p(weight), _p(offset), _p(y), B, C, H, W, Co, kh, kw, stride, padding, dilation, groups,
-                                  deformable_groups)
+    (sh, sw), (ph, pw), (dh, dw) = _hw(stride), _hw(padding), _hw(dilation)
+    rc = lib.ref_dcn1_forward_rect_f64(_p(x), _p(weight), _p(offset), _p(y), B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, groups,
+                                       deformable_groups)
     assert rc == 0
     return y
 
@@ -201,8 +209,9 @@ def ref_dcn1_backward(x, offset, weight, dy, stride=1, padding=0, dilation=1, gr
     B, C, H, W = x.shape
     Co, _, kh, kw = weight.shape
     dx, dw, doff = torch.zeros_like(x), torch.zeros_like(weight), torch.zeros_like(offset)
-    rc = lib.ref_dcn1_backward_f64(_p(x), _p(weight), _p(offset), _p(dy), _p(dx), _p(dw), _p(doff), B, C, H, W, Co, kh, kw, stride,
-                                   padding, dilation, groups, deformable_groups)
+    (sh, sw), (ph, pw), (dh, dw_) = _hw(stride), _hw(padding), _hw(dilation)
+    rc = lib.ref_dcn1_backward_rect_f64(_p(x), _p(weight), _p(offset), _p(dy), _p(dx), _p(dw), _p(doff), B, C, H, W, Co, kh, kw, sh, sw,
+                                        ph, pw, dh, dw_, groups, deformable_groups)
     assert rc == 0
     return dx, doff, dw
 
@@ -219,3 +228,17 @@ def c_dcn1_backward(x, offset, weight, dy, stride=1, padding=0, dilation=1, grou
     ones = torch.ones(B, offset.shape[1] // 2, Ho, Wo, dtype=offset.dtype)
     dx, doff, _, dw, _ = c_backward(x, offset, ones, weight, dy, False, stride, padding, dilation, groups, deformable_groups)
     return dx, doff, dw
+
+
+def torch_dcn1_forward(x, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1):
+    """DCNv1 on the floor/gather restatement (dcnv2_torch with an all-ones mask): the one oracle that takes rectangular
+    stride / padding / dilation pairs (pinned against the reference's own kernels on tests/golden/dcn1_rect.pt)."""
+    B, _, Ho, Wo = offset.shape
+    ones = torch.ones(B, offset.shape[1] // 2, Ho, Wo, dtype=offset.dtype, device=offset.device)
+    return dcnv2_torch(x, offset, ones, weight, None, stride, padding, dilation, groups, deformable_groups)
+
+
+def torch_dcn1_backward(x, offset, weight, dy, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1):
+    t = [v.detach().clone().requires_grad_() for v in (x, offset, weight)]
+    torch_dcn1_forward(*t, stride, padding, dilation, groups, deformable_groups).backward(dy)
+    return t[0].grad, t[1].grad, t[2].grad

@@ -60,6 +60,23 @@ def dcn_case(name):
 DCN1_CASES = ('edvr_like', 'half_taps', 'stride2_groups2', 'dilation2')  # same shapes; DCNv1 = no mask, no bias
 
 
+def dcn1_rect_case():
+    """DCNv1 with RECTANGULAR stride / padding / dilation pairs (deform_conv.py:33-36,56-58: h first), groups 2, dg 2."""
+    B, C, H, W, Co, k, groups, dg = 2, 8, 9, 11, 6, 3, 2, 2
+    stride, pad, dil = (2, 1), (1, 2), (1, 2)
+    g = torch.Generator().manual_seed(sum(map(ord, 'dcn1_rect')))
+    Ho, Wo = O._out_hw(H, W, k, k, stride, pad, dil)
+    dt = torch.float64
+    x = torch.randn(B, C, H, W, generator=g, dtype=dt)
+    w = torch.randn(Co, C // groups, k, k, generator=g, dtype=dt) * 0.1
+    off = torch.randn(B, dg * 2 * k * k, Ho, Wo, generator=g, dtype=dt) * 1.5
+    dy = torch.randn(B, Co, Ho, Wo, generator=g, dtype=dt)
+    cfg = (stride, pad, dil, groups, dg)
+    y = O.ref_dcn1_forward(x, off, w, *cfg)
+    dx, doff, dw = O.ref_dcn1_backward(x, off, w, dy, *cfg)
+    return dict(cfg=cfg, x=x, offset=off, weight=w, dy=dy, y=y, dx=dx, doffset=doff, dweight=dw)
+
+
 def dcn1_case(name):
     d = dcn_case(name)  # same seeded inputs
     cfg = d['cfg']
@@ -440,6 +457,7 @@ def main():
         torch.save(dcn_case(name), os.path.join(OUT, f'dcn_{name}.pt'))
     for name in DCN1_CASES:
         torch.save(dcn1_case(name), os.path.join(OUT, f'dcn1_{name}.pt'))
+    torch.save(dcn1_rect_case(), os.path.join(OUT, 'dcn1_rect.pt'))
     lr_sched_case()
     psnr_case()
     ssim_case()

@@ -138,9 +138,9 @@ int mdcn_backward(const T *input, const T *weight, const T *offset, const T *mas
 //      restated per sample (im2col_step = 1, so parallel_imgs = 1 and the column layout has batch_size 1).
 template <typename T>
 int dcn1_forward(const T *input, const T *weight, const T *offset, T *output, int batch, int channels, int height, int width,
-                 int channels_out, int kh, int kw, int stride, int pad, int dil, int group, int dg) {
-  const int Ho = (height + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1;
-  const int Wo = (width + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
+                 int channels_out, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int group, int dg) {
+  const int Ho = (height + 2 * ph - (dh * (kh - 1) + 1)) / sh + 1;  // deform_conv_cuda.cpp:186-189
+  const int Wo = (width + 2 * pw - (dw * (kw - 1) + 1)) / sw + 1;
   const int K = kh * kw, P = Ho * Wo;
   if (channels % group || channels_out % group || channels % dg) return -1;
   std::vector<T> columns((size_t)channels * K * P, (T)0);
@@ -148,7 +148,7 @@ int dcn1_forward(const T *input, const T *weight, const T *offset, T *output, in
   const int cig = channels / group, cog = channels_out / group;
   for (int b = 0; b < batch; ++b) {
     deformable_im2col_gpu_kernel<T>(channels * Ho * Wo * 1, input + (size_t)b * channels * height * width,
-                                    offset + (size_t)b * dg * 2 * K * P, height, width, kh, kw, pad, pad, stride, stride, dil, dil,
+                                    offset + (size_t)b * dg * 2 * K * P, height, width, kh, kw, ph, pw, sh, sw, dh, dw,
                                     channels / dg, 1, channels, dg, Ho, Wo, columns.data());  // .cu:252-276 launcher
     for (int g = 0; g < group; ++g)                                                             // .cpp:214-222
       gemm_nn_acc(weight + (size_t)g * cog * cig * K, columns.data() + (size_t)g * cig * K * P,
@@ -160,10 +160,10 @@ int dcn1_forward(const T *input, const T *weight, const T *offset, T *output, in
 // grad_* must be zero-filled by the caller (deform_conv.py:71-76 allocates zeros)
 template <typename T>
 int dcn1_backward(const T *input, const T *weight, const T *offset, const T *grad_output, T *grad_input, T *grad_weight,
-                  T *grad_offset, int batch, int channels, int height, int width, int channels_out, int kh, int kw, int stride,
-                  int pad, int dil, int group, int dg) {
-  const int Ho = (height + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1;
-  const int Wo = (width + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
+                  T *grad_offset, int batch, int channels, int height, int width, int channels_out, int kh, int kw, int sh, int sw,
+                  int ph, int pw, int dh, int dw, int group, int dg) {
+  const int Ho = (height + 2 * ph - (dh * (kh - 1) + 1)) / sh + 1;
+  const int Wo = (width + 2 * pw - (dw * (kw - 1) + 1)) / sw + 1;
   const int K = kh * kw, P = Ho * Wo;
   if (channels % group || channels_out % group || channels % dg) return -1;
   std::vector<T> columns((size_t)channels * K * P, (T)0);
@@ -176,12 +176,12 @@ int dcn1_backward(const T *input, const T *weight, const T *offset, const T *gra
       gemm_tn_set(weight + (size_t)g * cog * cig * K, go_b + (size_t)g * cog * P, columns.data() + (size_t)g * cig * K * P, cig * K,
                   cog, P);
     deformable_col2im_coord_gpu_kernel<T>(Ho * Wo * 2 * K * dg * 1, columns.data(), in_b, off_b, channels, height, width, kh, kw,
-                                          pad, pad, stride, stride, dil, dil, channels * K / dg, 1, 2 * K * dg, dg, Ho, Wo,
+                                          ph, pw, sh, sw, dh, dw, channels * K / dg, 1, 2 * K * dg, dg, Ho, Wo,
                                           grad_offset + (size_t)b * dg * 2 * K * P);  // .cpp:341-344
-    deformable_col2im_gpu_kernel<T>(channels * K * Ho * Wo * 1, columns.data(), off_b, channels, height, width, kh, kw, pad, pad,
-                                    stride, stride, dil, dil, channels / dg, 1, dg, Ho, Wo,
+    deformable_col2im_gpu_kernel<T>(channels * K * Ho * Wo * 1, columns.data(), off_b, channels, height, width, kh, kw, ph, pw,
+                                    sh, sw, dh, dw, channels / dg, 1, dg, Ho, Wo,
                                     grad_input + (size_t)b * channels * height * width);  // .cpp:346-348
-    deformable_im2col_gpu_kernel<T>(channels * Ho * Wo * 1, in_b, off_b, height, width, kh, kw, pad, pad, stride, stride, dil, dil,
+    deformable_im2col_gpu_kernel<T>(channels * Ho * Wo * 1, in_b, off_b, height, width, kh, kw, ph, pw, sh, sw, dh, dw,
                                     channels / dg, 1, channels, dg, Ho, Wo, columns.data());  // .cpp:445-447
     for (int g = 0; g < group; ++g)  // .cpp:460-468 (scale = 1)
       gemm_nt_acc(go_b + (size_t)g * cog * P, columns.data() + (size_t)g * cig * K * P, grad_weight + (size_t)g * cog * cig * K, cog, P,
@@ -196,14 +196,28 @@ extern "C" {
 
 int ref_dcn1_forward_f64(const double *input, const double *weight, const double *offset, double *output, int batch, int channels,
                          int height, int width, int channels_out, int kh, int kw, int stride, int pad, int dil, int group, int dg) {
-  return dcn1_forward<double>(input, weight, offset, output, batch, channels, height, width, channels_out, kh, kw, stride, pad, dil,
-                              group, dg);
+  return dcn1_forward<double>(input, weight, offset, output, batch, channels, height, width, channels_out, kh, kw, stride, stride, pad,
+                              pad, dil, dil, group, dg);
+}
+// rectangular stride / padding / dilation (deform_conv.py:33-36 takes pairs; the kernels take h and w values separately)
+int ref_dcn1_forward_rect_f64(const double *input, const double *weight, const double *offset, double *output, int batch, int channels,
+                              int height, int width, int channels_out, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                              int group, int dg) {
+  return dcn1_forward<double>(input, weight, offset, output, batch, channels, height, width, channels_out, kh, kw, sh, sw, ph, pw, dh,
+                              dw, group, dg);
+}
+int ref_dcn1_backward_rect_f64(const double *input, const double *weight, const double *offset, const double *grad_output,
+                               double *grad_input, double *grad_weight, double *grad_offset, int batch, int channels, int height,
+                               int width, int channels_out, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int group,
+                               int dg) {
+  return dcn1_backward<double>(input, weight, offset, grad_output, grad_input, grad_weight, grad_offset, batch, channels, height,
+                               width, channels_out, kh, kw, sh, sw, ph, pw, dh, dw, group, dg);
 }
 int ref_dcn1_backward_f64(const double *input, const double *weight, const double *offset, const double *grad_output,
                           double *grad_input, double *grad_weight, double *grad_offset, int batch, int channels, int height,
                           int width, int channels_out, int kh, int kw, int stride, int pad, int dil, int group, int dg) {
   return dcn1_backward<double>(input, weight, offset, grad_output, grad_input, grad_weight, grad_offset, batch, channels, height,
-                               width, channels_out, kh, kw, stride, pad, dil, group, dg);
+                               width, channels_out, kh, kw, stride, stride, pad, pad, dil, dil, group, dg);
 }
 
 

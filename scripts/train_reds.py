@@ -34,7 +34,21 @@ def train(args, log=print):
                with_predeblur=False, with_tsa=True).to(device)
     if args.pretrain:  # path.pretrain_network_g of the reference's option files; on resume: net_g_<iter>.pth next to <iter>.state
         load_network(net, args.pretrain)
-    model = D.wrap_ddp(net, find_unused_parameters=bool(args.tsa_iter)) if world > 1 else net
+    it, epoch = 0, 0
+    state = None
+    if args.resume:
+        state = torch.load(args.resume, map_location='cpu')  # optimizer 'step' counters stay host-side (no per-parameter sync in step())
+        it, epoch = state['iter'], state['epoch']
+    # phase of the TSA schedule the run (re)starts in: during the warm-up (1 <= it < tsa_iter) only the fusion module trains and the
+    # DDP reducer must skip the frozen parameters; past it every parameter trains and no unused-parameter search is needed.  (The
+    # reference re-applies neither on resume - edvr_model.py:55-69 acts at it == 1 and it == tsa_iter only - and so trains the
+    # frozen parameters after a resume inside the warm-up.)
+    warmup = bool(args.tsa_iter) and it < args.tsa_iter
+    if warmup and it >= 1:
+        for name, p in net.named_parameters():
+            if 'fusion' not in name:
+                p.requires_grad = False
+    model = D.wrap_ddp(net, find_unused_parameters=warmup) if world > 1 else net
     opt = make_optimizer(net, lr=args.lr, dcn_lr_mul=args.dcn_lr_mul, betas=(0.9, 0.99))
     sched = CosineAnnealingRestartLR(opt, periods=args.periods, restart_weights=args.restart_weights, eta_min=1e-7)
     data_opt = dict(dataroot_gt=args.gt, dataroot_lq=args.lq, dataroot_flow=None, meta_info_file=args.meta, val_partition=args.val_partition,
@@ -46,11 +60,8 @@ def train(args, log=print):
     if args.val_lq:
         val = VideoTestClips(dict(name='REDS4', dataroot_gt=args.val_gt, dataroot_lq=args.val_lq, io_backend=dict(type='disk'),
                                   cache_data=True, num_frame=args.num_frame, padding='reflection_circle'), device=device)
-    it, epoch = 0, 0
-    if args.resume:
-        state = torch.load(args.resume, map_location='cpu')  # optimizer 'step' counters stay host-side (no per-parameter sync in step())
+    if state is not None:
         resume_training(state, [opt], [sched])
-        it, epoch = state['iter'], state['epoch']
         loader.reset(epoch)
     losses = []
     while it < args.iters:

@@ -62,3 +62,68 @@ def test_single_process_defaults():
     assert D.shard_indices(5) == [0, 1, 2, 3, 4] and D.shard_batch(9) == 9
     net = torch.nn.Linear(2, 2)
     assert D.wrap_ddp(net) is net
+
+
+# ---------------------------------------------------------------------------------------------- bench.py's multi-GPU contract
+def _bench():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_module', os.path.join(root, 'bench.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_gpus_8_builds_the_torchrun_launch():
+    """`python bench.py --gpus 8 --steps 20 --warmup 5` outside torchrun re-launches itself as the driver would launch it:
+    one node, 8 ranks, rendezvous on 127.0.0.1, its own flags passed through, dmabuf IPC mode in the environment."""
+    import sys
+    b = _bench()
+    cmd = b.spawn_command(8, 29512, ['--gpus', '8', '--steps', '20', '--warmup', '5'])
+    assert cmd[:3] == [sys.executable, '-m', 'torch.distributed.run']
+    assert '--nnodes=1' in cmd and '--nproc-per-node=8' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[cmd.index('--master-port') + 1] == '29512'
+    script = cmd.index(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py'))
+    assert cmd[script + 1:] == ['--gpus', '8', '--steps', '20', '--warmup', '5']
+    assert b.spawn_env({'A': '1'}) == {'A': '1', 'HSA_ENABLE_IPC_MODE_LEGACY': '0'}
+
+
+def _bench_worker(rank, world, port, q):
+    import contextlib
+    import io
+    import time
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group(backend='gloo')
+    b = _bench()
+    calls = []
+
+    def step():  # rank 1 is the slow rank: the reported time must be ITS time on every rank
+        calls.append(1)
+        time.sleep(0.02 * (1 + 2 * rank))
+        return torch.ones(1)
+    elapsed = b.timed(step, 5, 2, dist, torch.device('cpu'))
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        b.emit({'value': 1.0, 'n_gpus': world}, rank)
+    q.put((rank, elapsed, len(calls), buf.getvalue()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_timing_is_max_over_ranks_and_only_rank0_prints():
+    import json
+    world, port = 2, 30533 + os.getpid() % 1000
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, e0, n0, out0), (_, e1, n1, out1) = got
+    assert n0 == n1 == 7                      # 2 warm-up + exactly 5 timed steps
+    assert e0 == e1 and e0 >= 5 * 0.06 * 0.9  # both ranks report the slow rank's time (5 x 60 ms)
+    assert json.loads(out0) == {'value': 1.0, 'n_gpus': 2} and out0.count('\n') == 1
+    assert out1 == ''                         # rank > 0 prints nothing

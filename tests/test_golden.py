@@ -40,9 +40,13 @@ def test_oracle_reproduces_dcn_golden(f):
 @pytest.mark.parametrize('f', DCN1_FILES, ids=os.path.basename)
 def test_oracle_reproduces_dcn1_golden(f):
     d = _load(f)
-    assert (O.c_dcn1_forward(d['x'], d['offset'], d['weight'], *d['cfg']) - d['y']).abs().max().item() < 1e-12
-    for name, got in zip(('dx', 'doffset', 'dweight'), O.c_dcn1_backward(d['x'], d['offset'], d['weight'], d['dy'], *d['cfg'])):
-        assert (got - d[name]).abs().max().item() <= 1e-12 * max(1.0, d[name].abs().max().item()), name
+    # the plain-C restatement takes square geometries; rectangular stride / padding / dilation pairs (dcn1_rect.pt, from the
+    # reference's own kernels like the others) pin the floor/gather restatement, the oracle of the rectangular GPU tests
+    rect = isinstance(d['cfg'][0], tuple)
+    fwd, bwd = (O.torch_dcn1_forward, O.torch_dcn1_backward) if rect else (O.c_dcn1_forward, O.c_dcn1_backward)
+    assert (fwd(d['x'], d['offset'], d['weight'], *d['cfg']) - d['y']).abs().max().item() < 1e-12
+    for name, got in zip(('dx', 'doffset', 'dweight'), bwd(d['x'], d['offset'], d['weight'], d['dy'], *d['cfg'])):
+        assert (got - d[name]).abs().max().item() <= 1e-11 * max(1.0, d[name].abs().max().item()), name
 
 
 def _rebuild(d):

@@ -44,6 +44,43 @@ def test_dcnv1_forward_backward_vs_oracle(gpu, case):
             assert _rel(a, r) < 1e-4, (name, hint)
 
 
+RECT_CASES = [  # B, C, H, W, Co, (kh, kw), stride, pad, dil, groups, dg, sigma: (h, w) pairs as deform_conv.py:33-36 takes them
+    (2, 8, 9, 11, 6, (3, 3), (2, 1), (1, 2), (1, 2), 2, 2, 1.5),   # the geometry of tests/golden/dcn1_rect.pt
+    (1, 16, 12, 10, 8, (3, 3), (1, 2), (0, 1), (1, 1), 1, 4, 1.0),
+    (2, 12, 8, 13, 12, (1, 3), (1, 1), (0, 1), (1, 2), 1, 3, 2.0),  # rectangular kernel as well
+]
+
+
+@pytest.mark.parametrize('case', RECT_CASES)
+def test_dcnv1_rectangular_geometry(gpu, case):
+    """Pair-valued stride / padding / dilation through the op, the autograd Function and the module (generic column-buffer
+    kernels; EDVR_HW pairs in the C ABI) against the floor/gather oracle, which tests/test_golden.py pins to the reference's
+    own kernels on exactly such a geometry."""
+    from edvr_amd import DeformConv, deform_conv, ops
+    from oracle import dcn_oracle as O
+    B, C, H, W, Co, (kh, kw), stride, pad, dil, groups, dg, sigma = case
+    g = torch.Generator().manual_seed(B + C + H + W + Co + kh + kw)
+    Ho, Wo = O._out_hw(H, W, kh, kw, stride, pad, dil)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(Co, C // groups, kh, kw, generator=g) * 0.1
+    off = torch.randn(B, dg * 2 * kh * kw, Ho, Wo, generator=g) * sigma
+    dy = torch.randn(B, Co, Ho, Wo, generator=g)
+    cfg = (stride, pad, dil, groups, dg)
+    ref_y = O.torch_dcn1_forward(x.double(), off.double(), w.double(), *cfg)
+    ref_g = O.torch_dcn1_backward(x.double(), off.double(), w.double(), dy.double(), *cfg)
+    xg, og, wg = (t.to(gpu).requires_grad_() for t in (x, off, w))
+    assert _rel(ops.dcnv1_forward(xg.detach(), og.detach(), wg.detach(), *cfg), ref_y) < 2e-5
+    y = deform_conv(xg, og, wg, stride, pad, dil, groups, dg)
+    assert tuple(y.shape) == (B, Co, Ho, Wo) and _rel(y.detach(), ref_y) < 2e-5
+    y.backward(dy.to(gpu))
+    for name, t, r in zip(('dx', 'doffset', 'dweight'), (xg, og, wg), ref_g):
+        assert _rel(t.grad, r) < 1e-4, name
+    m = DeformConv(C, Co, (kh, kw), stride=stride, padding=pad, dilation=dil, groups=groups, deformable_groups=dg).to(gpu)
+    with torch.no_grad():
+        m.weight.copy_(w)
+        assert _rel(m(x.to(gpu), off.to(gpu)), ref_y) < 2e-5
+
+
 def test_deform_conv_autograd_and_module_contract(gpu):
     from edvr_amd import DeformConv, DeformConvPack, deform_conv
     from oracle import dcn_oracle as O

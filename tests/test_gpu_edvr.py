@@ -117,3 +117,39 @@ print("ok")
     r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, EDVR_WINOGRAD_F4='0', EDVR_WINOGRAD_F4_TRAIN='0', PYTHONPATH=root),
                        cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'ok' in r.stdout, r.stdout + r.stderr
+
+
+def test_offset_check_is_lazy_in_inference_and_eager_in_training(gpu, caplog):
+    """arch_util.py:248-253's `Offset abs mean is ..., larger than 50` warning: no host synchronisation in a no-grad forward
+    (the statistics are examined when the next forward starts or on check_offsets()); evaluated right away in grad mode."""
+    import logging
+    net, x, _ = build('M_T5')
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if n.endswith('cas_dcnpack.conv_offset.bias'):
+                p.fill_(80.0)  # every offset of the cascade DCN ~80 px; its masks saturate, the output stays finite
+    net = net.to(gpu)
+    xg = x.to(gpu)
+    cas = net.pcd_align.cas_dcnpack
+    with caplog.at_level(logging.WARNING, logger='basicsr'):
+        with torch.no_grad():
+            out = net(xg)
+        assert len(net._pending_offset_stats) == 1 and cas.last_offset_absmean is None  # nothing examined, nothing waited for
+        assert not [r for r in caplog.records if 'larger than 50' in r.getMessage()]
+        net.check_offsets()
+        assert not net._pending_offset_stats and cas.last_offset_absmean > 50
+        n_inf = len([r for r in caplog.records if 'larger than 50' in r.getMessage()])
+        assert n_inf == x.shape[1]  # one per frame of the clip, like the reference's per-call check of that layer
+        with torch.no_grad():
+            net(xg)
+            torch.cuda.synchronize()
+            net(xg)  # the start of this forward examines the previous one (its copy has landed)
+        assert len(net._pending_offset_stats) == 1
+        assert len([r for r in caplog.records if 'larger than 50' in r.getMessage()]) == 2 * n_inf
+        net.check_offsets()
+        caplog.clear()
+        net.train()
+        net(xg).sum().backward()  # grad mode: evaluated inside the forward (the backward's scatter strategy needs it)
+        assert not net._pending_offset_stats
+        assert len([r for r in caplog.records if 'larger than 50' in r.getMessage()]) == n_inf
+    assert torch.isfinite(out).all()

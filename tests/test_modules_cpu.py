@@ -86,3 +86,23 @@ def test_kernel_hints_from_offset_statistics():
     hdr = open(os.path.join(os.path.dirname(__file__), '..', 'include', 'edvr_amd.h')).read()
     for name, val in (('AUTO', 0), ('DEVICE', 1), ('LDS', 2), ('STRIP', 3)):
         assert f'#define EDVR_DCN_SCATTER_{name} {val}' in hdr
+
+
+def test_compat_ext_matches_the_reference_call_sites():
+    """edvr_amd/compat/deform_conv_ext.py takes exactly the positional arguments the reference's Python passes to its pybind
+    module at every call site of basicsr/models/ops/dcn/deform_conv.py (authoring container only: needs /root/reference)."""
+    import ast
+    import inspect
+    import os
+    src = '/root/reference/basicsr/models/ops/dcn/deform_conv.py'
+    if not os.path.exists(src):
+        pytest.skip('reference sources not present')
+    from edvr_amd.compat import deform_conv_ext as ext
+    calls = {}
+    for node in ast.walk(ast.parse(open(src).read())):
+        if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and getattr(node.func.value, 'id', None) == 'deform_conv_ext':
+            calls[node.func.attr] = len(node.args)
+    assert sorted(calls) == ['deform_conv_backward_input', 'deform_conv_backward_parameters', 'deform_conv_forward',
+                             'modulated_deform_conv_backward', 'modulated_deform_conv_forward']
+    for name, n in calls.items():
+        assert len(inspect.signature(getattr(ext, name)).parameters) == n, name
