@@ -423,19 +423,19 @@ def target_4k_leg(net, args, device, rank, world, dist):
             with torch.no_grad():
                 ours = net(x)
                 sd = net.state_dict()
-                ref = EO.edvr_forward(sd, x, dcn=dcn_oracle.dcnv2_torch, **oracle_kw(cfg))  # warm-up (MIOpen find) + the reference output
-                torch.cuda.synchronize()
+                # convs as F.unfold + rocBLAS GEMM: on a fresh box MIOpen compiles a kernel per new conv shape (~4 minutes for
+                # this workload's ~20 shapes), im2col + GEMM needs none; the MIOpen-based arm is timed on the headline workload
                 t0 = time.perf_counter()
-                EO.edvr_forward(sd, x, dcn=dcn_oracle.dcnv2_torch, **oracle_kw(cfg))
+                ref = EO.edvr_forward(sd, x, dcn=dcn_oracle.dcnv2_torch, conv_impl='unfold', **oracle_kw(cfg))
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
             err = float(((ours - ref).abs().max() / ref.abs().max()).item())
             p_ours, p_ref = EO.psnr(ours, gt), EO.psnr(ref, gt)
-            out['parity'] = dict(against='oracle/edvr_oracle.py in stock PyTorch-ROCm fp32 ops (MIOpen convs, pure-torch DCNv2) on this GPU, same clip, '
+            out['parity'] = dict(against='oracle/edvr_oracle.py in stock PyTorch-ROCm fp32 ops (convs = F.unfold + rocBLAS GEMM, pure-torch DCNv2) on this GPU, same clip, '
                                          'same weights; intermediates at this size: tests/test_gpu_fullsize_parity.py',
                                  max_rel_err=err, psnr_ours=round(p_ours, 6), psnr_stock=round(p_ref, 6), d_psnr=round(abs(p_ours - p_ref), 8),
                                  tolerance={'max_rel_err': 2e-4, 'd_psnr_db': 1e-3}, ok=bool(err < 2e-4 and abs(p_ours - p_ref) <= 1e-3))
-            out['stock_rocm_baseline'] = {'value': round(1.0 / dt, 3), 'unit': 'clips/s', 'ms_per_clip': round(dt * 1e3, 1)}
+            out['parity']['witness_seconds'] = round(dt, 2)
         except Exception as e:  # (a baseline arm must never take the measurement down)
             out['parity'] = {'error': f'{type(e).__name__}: {str(e)[:200]}'}
     return out

@@ -42,6 +42,9 @@ PROTOTYPES = {
     'edvr_dcnv2_fwd_ws_bytes': (sz, [i32] * 12),
     'edvr_dcnv2_fwd_f32': (i32, [vp] * 6 + [i32] * 12 + [i64, i64, i32, i32, vp, sz, vp]),
     'edvr_dcnv2_bwd_ws_bytes': (sz, [i32] * 12),
+    'edvr_dcnv2_any_ws_bytes': (sz, [i32] * 13),
+    'edvr_dcnv2_fwd_any': (i32, [i32] + [vp] * 6 + [i32] * 12 + [i64, i64, vp, sz, vp]),
+    'edvr_dcnv2_bwd_any': (i32, [i32] + [vp] * 10 + [i32] * 12 + [i64, i64, i64, i64, vp, sz, vp]),
     'edvr_psnr_sse_f32': (i32, [vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, vp]),
     'edvr_ssim_partials': (sz, [i32, i32, i32]),
     'edvr_ssim_f32': (i32, [vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, vp]),
@@ -79,6 +82,7 @@ PROTOTYPES = {
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
 OUT_NCHW, OUT_PIXEL_SHUFFLE2 = 0, 1
 CONV_AUTO, CONV_DIRECT, CONV_WINOGRAD, CONV_WINOGRAD_F4 = 0, 1, 2, 3
+DTYPE_F32, DTYPE_F64, DTYPE_F16 = 0, 1, 2  # EDVR_DTYPE_*
 
 _lib = None
 

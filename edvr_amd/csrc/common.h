@@ -77,6 +77,17 @@ int winograd_wgrad_launch(const float *x1, const float *x2, const float *dz, flo
                           int64_t x1_img_stride, int64_t x2_img_stride, int x2_div, int x2_mul, int x2_add, int64_t dz_img_stride,
                           int splits, int want_db, hipStream_t stream);  // want_db: also [splits][co] partial sums of dz after the dW partials
 
+// dcn.hip: geometry of one DCN call, shared with dcn_any.hip
+struct DcnShape {
+  int B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, Ho, Wo;  // stride / pad / dil: along h
+  int stride_w, pad_w, dil_w;                                        // along w (EDVR_HW pairs of the C ABI; equal to the h values otherwise)
+  int64_t off_bs, msk_bs;    // image strides of offset / mask (inputs)
+  int64_t doff_bs, dmsk_bs;  // image strides of doffset / dmask (backward outputs)
+};
+// validates the sizes, decodes EDVR_HW pairs, computes Ho / Wo and the default image strides (0 = contiguous)
+int dcn_fill_shape(DcnShape &s, int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil, int groups, int dg,
+                   int64_t off_bs, int64_t msk_bs);
+
 // dcn_fused.hip: column-buffer-free DCNv2 forward for the EDVR signature (3x3, stride 1, pad 1, dil 1, groups 1)
 bool dcn_fused_supported(int C, int Co, int H, int W, int kh, int kw, int stride, int pad, int dil, int groups, int dg);  // incl. the 32-bit buffer-offset limits
 int dcn_fused_pack(const float *weight, float *wpk, int Co, int C, hipStream_t stream);  // (Co, C, 3, 3) -> the fused kernel's layout, C * 9 * round_up(Co, 32) floats

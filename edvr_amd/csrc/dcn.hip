@@ -36,13 +36,6 @@ namespace edvr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-struct DcnShape {
-  int B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, Ho, Wo;  // stride / pad / dil: along h
-  int stride_w, pad_w, dil_w;                                        // along w (EDVR_HW pairs of the C ABI; equal to the h values otherwise)
-  int64_t off_bs, msk_bs;    // image strides of offset / mask (inputs)
-  int64_t doff_bs, dmsk_bs;  // image strides of doffset / dmask (backward outputs)
-};
-
 __global__ void fill_kernel(float *__restrict__ p, float v, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -662,8 +655,8 @@ int gemm_nt_launch(const float *A, const float *B, float *C, int M, int N, int64
 // ---------------------------------------------------------------------------------------------
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-static int fill_shape(DcnShape &s, int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil, int groups,
-                      int dg, int64_t off_bs, int64_t msk_bs) {
+int dcn_fill_shape(DcnShape &s, int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil, int groups,
+                   int dg, int64_t off_bs, int64_t msk_bs) {
   // stride / pad / dil may carry an (h, w) pair: EDVR_HW(h, w) = h | (w + 1) << 16 (include/edvr_amd.h); a plain value means h == w
   auto hw_pair = [](int v, int &h, int &w) {
     h = v & 0xffff;
@@ -736,14 +729,14 @@ extern "C" {
 size_t edvr_dcnv2_fwd_ws_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil, int groups,
                                int dg) {
   edvr::DcnShape s;
-  if (edvr::fill_shape(s, B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, 0, 0)) return 0;
+  if (edvr::dcn_fill_shape(s, B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, 0, 0)) return 0;
   return edvr::fwd_ws(s).total;
 }
 
 size_t edvr_dcnv2_bwd_ws_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil, int groups,
                                int dg) {
   edvr::DcnShape s;
-  if (edvr::fill_shape(s, B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, 0, 0)) return 0;
+  if (edvr::dcn_fill_shape(s, B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, 0, 0)) return 0;
   return edvr::bwd_ws(s).total;
 }
 
@@ -754,7 +747,7 @@ int edvr_dcnv2_fwd_f32(const float *x, const float *offset, const float *mask, c
   using namespace edvr;
   EDVR_REQUIRE(x && offset && mask && weight && y, "dcnv2_fwd: null pointer");
   DcnShape s;
-  int rc = fill_shape(s, B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, offset_bstride, mask_bstride);
+  int rc = dcn_fill_shape(s, B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, offset_bstride, mask_bstride);
   if (rc) return rc;
   const FwdWs wsz = fwd_ws(s);
   if (!ws || ws_bytes < wsz.total) {
@@ -809,7 +802,7 @@ int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, c
   using namespace edvr;
   EDVR_REQUIRE(x && offset && mask && weight && dy && dx && doffset && dmask && dweight, "dcnv2_bwd: null pointer");
   DcnShape s;
-  int rc = fill_shape(s, B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, offset_bstride, mask_bstride);
+  int rc = dcn_fill_shape(s, B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, offset_bstride, mask_bstride);
   if (rc) return rc;
   if (doffset_bstride) s.doff_bs = doffset_bstride;
   if (dmask_bstride) s.dmsk_bs = dmask_bstride < 0 ? 0 : dmask_bstride;  // < 0: every image writes the same (discarded) planes
@@ -899,7 +892,7 @@ int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, c
 // The reference's im2col_step batching is a workspace-size knob of its column buffer and has no counterpart here.
 size_t edvr_dcnv1_fwd_ws_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil, int groups, int dg) {
   edvr::DcnShape s;
-  if (edvr::fill_shape(s, B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, 0, 0)) return 0;
+  if (edvr::dcn_fill_shape(s, B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, 0, 0)) return 0;
   return edvr::fwd_ws(s).total + edvr::align_up((size_t)dg * kh * kw * s.Ho * s.Wo * 4, 256);
 }
 
@@ -925,7 +918,7 @@ int edvr_dcnv1_fwd_f32(const float *x, const float *offset, const float *weight,
 
 size_t edvr_dcnv1_bwd_ws_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil, int groups, int dg) {
   edvr::DcnShape s;
-  if (edvr::fill_shape(s, B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, 0, 0)) return 0;
+  if (edvr::dcn_fill_shape(s, B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, 0, 0)) return 0;
   return edvr::bwd_ws(s).total + 2 * edvr::align_up((size_t)dg * kh * kw * s.Ho * s.Wo * 4, 256);
 }
 

@@ -474,6 +474,31 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
           __builtin_amdgcn_sched_barrier(0);
           continue;
 #endif
+#ifdef F4_EXP_MFMA16 /* ablation (wrong results): every 16-pass MFMA as two 8-pass v_mfma_f32_16x16x4_f32 - same matrix-pipe time,
+                        twice the issue slots in between.  Does the staging wave get further? */
+          {
+            auto two = [&](f32x16 &A, float a_, float b_) {
+              f32x4 q0 = {A[0], A[1], A[2], A[3]}, q1 = {A[4], A[5], A[6], A[7]};
+              q0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b_, q0, 0, 0, 0);
+              q1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b_, q1, 0, 0, 0);
+              A[0] = q0[0]; A[1] = q0[1]; A[2] = q0[2]; A[3] = q0[3];
+              A[4] = q1[0]; A[5] = q1[1]; A[6] = q1[2]; A[7] = q1[3];
+            };
+            if (!hi) {
+#pragma unroll
+              for (int c = 0; c < 3; ++c) two(acc[c], a4[set][c], bv[cur][c]);
+            } else {
+              two(acc[3], a4[set][3], bv[cur][0]);
+              const int t_next = min(4 * k + cp + 2, n_steps - 1);
+              load_a4(set, t_next);
+              two(acc[4], a2[set][0], bv[cur][1]);
+              two(acc[5], a2[set][1], bv[cur][2]);
+              load_a2(set, t_next);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            continue;
+          }
+#endif
           if (!hi) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[set][c], bv[cur][c], acc[c], 0, 0, 0);

@@ -23,15 +23,24 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
-def require_gpu(*tensors):
-    """Same refusal as the reference (deform_conv.py:133-134): no CPU path exists."""
+def require_gpu(*tensors, dtypes=(torch.float32,)):
+    """Same refusal as the reference (deform_conv.py:133-134): no CPU path exists.  Everything is fp32 except the DCN operators,
+    which also take float64 / float16 like the reference's dispatch (`dtypes`); the tensors of one call share one type."""
+    seen = None
     for t in tensors:
         if t is None:
             continue
         if not t.is_cuda:
             raise NotImplementedError('edvr_amd ops run on the GPU only (HIP/gfx950); got a CPU tensor')
-        if t.dtype != torch.float32:
-            raise NotImplementedError(f'edvr_amd ops are fp32 only; got {t.dtype}')
+        if t.dtype not in dtypes:
+            raise NotImplementedError(f'edvr_amd: {t.dtype} is not supported here (supported: {", ".join(map(str, dtypes))})')
+        if seen is not None and t.dtype != seen:
+            raise RuntimeError(f'expected every tensor of the call to be {seen}, got {t.dtype}')  # (the reference: "expected scalar type ...")
+        seen = t.dtype
+    return seen
+
+
+DCN_DTYPES = {torch.float32: _lib.DTYPE_F32, torch.float64: _lib.DTYPE_F64, torch.float16: _lib.DTYPE_F16}
 
 
 def _plane_contig(t):
@@ -222,9 +231,14 @@ def conv_gate_supported(n, c, h, w, co, algo=None):
 
 
 # ------------------------------------------------------------------------------------------------ DCNv1
+def _ones_mask(offset):
+    return torch.ones(offset.shape[0], offset.shape[1] // 2, offset.shape[2], offset.shape[3], dtype=offset.dtype, device=offset.device)
+
+
 def dcnv1_forward(x, offset, weight, stride, pad, dil, groups, dg, halo_hint=0):
-    """DeformConv forward (no mask, no bias): edvr_dcnv1_fwd_f32."""
-    require_gpu(x, offset, weight)
+    """DeformConv forward (no mask, no bias): edvr_dcnv1_fwd_f32; float64 / float16: DCNv2 with an all-ones mask on edvr_dcnv2_fwd_any."""
+    if require_gpu(x, offset, weight, dtypes=tuple(DCN_DTYPES)) != torch.float32:
+        return dcnv2_forward(x, offset, _ones_mask(offset), weight, None, stride, pad, dil, groups, dg)
     L = _lib.lib()
     offset = _as_planes(offset)
     dims = _dcn_dims(x, weight, stride, pad, dil, groups, dg)
@@ -240,8 +254,10 @@ def dcnv1_forward(x, offset, weight, stride, pad, dil, groups, dg, halo_hint=0):
 
 
 def dcnv1_backward(x, offset, weight, dy, stride, pad, dil, groups, dg, scatter_hint=0):
-    """Returns (dx, doffset, dweight) of DeformConv: edvr_dcnv1_bwd_f32."""
-    require_gpu(x, offset, weight, dy)
+    """Returns (dx, doffset, dweight) of DeformConv: edvr_dcnv1_bwd_f32 (float64 / float16: through edvr_dcnv2_bwd_any)."""
+    if require_gpu(x, offset, weight, dy, dtypes=tuple(DCN_DTYPES)) != torch.float32:
+        dx, doff, _, dw, _ = dcnv2_backward(x, offset, _ones_mask(offset), weight, dy, False, stride, pad, dil, groups, dg)
+        return dx, doff, dw
     L = _lib.lib()
     offset = _as_planes(offset)
     dy = dy.contiguous()
@@ -281,7 +297,7 @@ def _bstride(t):
 
 
 def dcnv2_forward(x, offset, mask, weight, bias, stride, pad, dil, groups, dg, act=ACT_NONE, halo_hint=0):
-    require_gpu(x, offset, mask, weight, bias)
+    dt = require_gpu(x, offset, mask, weight, bias, dtypes=tuple(DCN_DTYPES))
     L = _lib.lib()
     if not x.is_contiguous() or not weight.is_contiguous():
         raise RuntimeError('input tensor has to be contiguous')  # deform_conv_cuda.cpp:497-498
@@ -297,7 +313,15 @@ def dcnv2_forward(x, offset, mask, weight, bias, stride, pad, dil, groups, dg, a
         raise ValueError(f'convolution input is too small (output would be {Ho}x{Wo})')
     assert tuple(offset.shape[1:]) == (dg * 2 * kh * kw, Ho, Wo), f'offset shape {tuple(offset.shape)}'
     assert tuple(mask.shape[1:]) == (dg * kh * kw, Ho, Wo), f'mask shape {tuple(mask.shape)}'
-    y = torch.empty(B, Co, Ho, Wo, dtype=torch.float32, device=x.device)
+    y = torch.empty(B, Co, Ho, Wo, dtype=dt, device=x.device)
+    if dt != torch.float32:  # float64 / float16: the reference's other dispatch legs (csrc/dcn_any.hip); no fused activation there
+        if act != ACT_NONE:
+            raise NotImplementedError('the fused activation of dcnv2_forward exists in fp32 only')
+        nbytes = L.edvr_dcnv2_any_ws_bytes(DCN_DTYPES[dt], *dims)
+        ws = workspace(nbytes, x.device)
+        _lib.check(L.edvr_dcnv2_fwd_any(DCN_DTYPES[dt], _ptr(x), _ptr(offset), _ptr(mask), _ptr(weight), _ptr(bias), _ptr(y), *dims,
+                                        _bstride(offset), _bstride(mask), _ptr(ws), nbytes, _stream()), 'edvr_dcnv2_fwd_any')
+        return y
     nbytes = L.edvr_dcnv2_fwd_ws_bytes(*dims)
     ws = workspace(nbytes, x.device)
     _run('dcnv2_fwd', lambda: _lib.check(L.edvr_dcnv2_fwd_f32(_ptr(x), _ptr(offset), _ptr(mask), _ptr(weight), _ptr(bias), _ptr(y), *dims,
@@ -310,17 +334,24 @@ def dcnv2_backward(x, offset, mask, weight, dy, with_bias, stride, pad, dil, gro
                    scatter_hint=0):
     """Returns (dx, doffset, dmask, dweight, dbias).  `doffset` / `dmask` may be preallocated channel slices of one
     buffer (image-strided views): the kernels write them in place."""
-    require_gpu(x, offset, mask, weight, dy)
+    dt = require_gpu(x, offset, mask, weight, dy, dtypes=tuple(DCN_DTYPES))
     L = _lib.lib()
     offset, mask = _as_planes(offset), _as_planes(mask)
     dy = dy.contiguous()
     dims = _dcn_dims(x, weight, stride, pad, dil, groups, dg)
     dx = torch.empty_like(x)
-    doff = doffset if doffset is not None else torch.empty(offset.shape, dtype=torch.float32, device=x.device)
-    dmsk = dmask if dmask is not None else torch.empty(mask.shape, dtype=torch.float32, device=x.device)
+    doff = doffset if doffset is not None else torch.empty(offset.shape, dtype=dt, device=x.device)
+    dmsk = dmask if dmask is not None else torch.empty(mask.shape, dtype=dt, device=x.device)
     assert _plane_contig(doff) and _plane_contig(dmsk)
     dw = torch.empty_like(weight)
-    db = torch.empty(weight.shape[0], dtype=torch.float32, device=x.device) if with_bias else None
+    db = torch.empty(weight.shape[0], dtype=dt, device=x.device) if with_bias else None
+    if dt != torch.float32:
+        nbytes = L.edvr_dcnv2_any_ws_bytes(DCN_DTYPES[dt], *dims)
+        ws = workspace(nbytes, x.device)
+        _lib.check(L.edvr_dcnv2_bwd_any(DCN_DTYPES[dt], _ptr(x), _ptr(offset), _ptr(mask), _ptr(weight), _ptr(dy), _ptr(dx), _ptr(doff),
+                                        _ptr(dmsk), _ptr(dw), _ptr(db), *dims, _bstride(offset), _bstride(mask), _bstride(doff),
+                                        _bstride(dmsk), _ptr(ws), nbytes, _stream()), 'edvr_dcnv2_bwd_any')
+        return dx, doff, dmsk, dw, db
     nbytes = L.edvr_dcnv2_bwd_ws_bytes(*dims)
     ws = workspace(nbytes, x.device)
     _run('dcnv2_bwd', lambda: _lib.check(L.edvr_dcnv2_bwd_f32(_ptr(x), _ptr(offset), _ptr(mask), _ptr(weight), _ptr(dy), _ptr(dx), _ptr(doff), _ptr(dmsk),

@@ -193,6 +193,24 @@ int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, c
  * doffset_bstride / dmask_bstride (0 = contiguous): image strides of the two gradient outputs, so both can be
  * written straight into channel slices of one (B, 3*dg*K, Ho, Wo) buffer = the gradient of conv_offset's output. */
 
+/* The same operator in float64 / float16: the other legs of the reference's AT_DISPATCH_FLOATING_TYPES_AND_HALF
+ * (deform_conv_cuda_kernel.cu:781,811,843).  All tensors of one call have the type `dtype` names; EDVR_DTYPE_F32 forwards to the
+ * entry points above (no activation, default hints).  float64 computes in float64 throughout (torch.autograd.gradcheck users);
+ * float16 keeps tensors in float16 and every intermediate in float32.  Plain VALU kernels (csrc/dcn_any.hip): any geometry, not
+ * the measured path.  Gradients are overwritten; dbias may be NULL.  One workspace size serves both directions. */
+#define EDVR_DTYPE_F32 0
+#define EDVR_DTYPE_F64 1
+#define EDVR_DTYPE_F16 2
+size_t edvr_dcnv2_any_ws_bytes(int dtype, int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil, int groups,
+                               int dg);
+int edvr_dcnv2_fwd_any(int dtype, const void *x, const void *offset, const void *mask, const void *weight, const void *bias, void *y, int B,
+                       int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil, int groups, int dg,
+                       int64_t offset_bstride, int64_t mask_bstride, void *ws, size_t ws_bytes, edvr_stream_t stream);
+int edvr_dcnv2_bwd_any(int dtype, const void *x, const void *offset, const void *mask, const void *weight, const void *dy, void *dx,
+                       void *doffset, void *dmask, void *dweight, void *dbias, int B, int C, int H, int W, int Co, int kh, int kw, int stride,
+                       int pad, int dil, int groups, int dg, int64_t offset_bstride, int64_t mask_bstride, int64_t doffset_bstride,
+                       int64_t dmask_bstride, void *ws, size_t ws_bytes, edvr_stream_t stream);
+
 /* DCNv1 (DeformConv / DeformConvPack: no mask, no bias) <- deform_conv_forward, deform_conv_backward_input,
  * deform_conv_backward_parameters, basicsr/models/ops/dcn/src/deform_conv_ext.cpp:51-104 (drivers deform_conv_cuda.cpp:152-488,
  * kernels .cu:190-465).  Same offset layout and gather as DCNv2; gradients are overwritten; dx by fp32 atomics.

@@ -57,9 +57,39 @@ def _side(z, name):
     return s
 
 
+_CONV_IMPL = 'conv2d'  # 'unfold': im2col (F.unfold) + one GEMM per image instead of F.conv2d, see conv_unfold
+
+
+def conv_unfold(x, w, b, stride, pad):
+    """F.conv2d restated as im2col + GEMM in stock torch ops (F.unfold, torch.addmm -> rocBLAS on a GPU), one image at a time.
+    For the GPU arm of the big full-size parity checks: MIOpen compiles a kernel per new convolution shape on a fresh box
+    (minutes for the ~20 shapes of a 720x1280 -> 4K forward), unfold and the GEMM library do not."""
+    co, ci, kh, kw = w.shape
+    n, _, h, wd = x.shape
+    ho, wo = (h + 2 * pad - kh) // stride + 1, (wd + 2 * pad - kw) // stride + 1
+    wm = w.reshape(co, ci * kh * kw)
+    out = x.new_empty(n, co, ho, wo)
+    pointwise = kh == 1 and kw == 1 and stride == 1 and pad == 0
+    xp = x if (pointwise or pad == 0) else F.pad(x, (pad, pad, pad, pad))
+    rows = ho if pointwise else max(1, min(ho, (1 << 28) // (ci * kh * kw * wo)))  # column strips of <= 2^28 elements (1 GB)
+    for i in range(n):
+        o = out[i].view(co, ho * wo)
+        for r0 in range(0, ho, rows):
+            r1 = min(ho, r0 + rows)
+            if pointwise:
+                cols = x[i].reshape(ci, h * wd)
+            else:
+                cols = F.unfold(xp[i:i + 1, :, r0 * stride:(r1 - 1) * stride + kh], (kh, kw), stride=stride)[0]
+            res = wm @ cols
+            o[:, r0 * wo:r1 * wo] = res if b is None else res + b.view(co, 1)
+    return out
+
+
 def _conv(sd, name, x, stride=1, padding=None):
     w = sd[name + '.weight']
     pad = (w.shape[-1] // 2) if padding is None else padding
+    if _CONV_IMPL == 'unfold' and not torch.is_grad_enabled():
+        return _tag(conv_unfold(x, w, sd.get(name + '.bias'), stride, pad), name)
     return _tag(F.conv2d(x, w, sd.get(name + '.bias'), stride, pad), name)
 
 
@@ -182,18 +212,19 @@ def _count(sd, prefix):
 
 
 def edvr_forward(sd, x, center=None, hr_in=False, with_predeblur=False, with_tsa=True, dg=8, dcn=None, taps=None,
-                 stats=None, pool_inputs=None, dcn_offsets=None, act_sides=None, follow_stats=None):
+                 stats=None, pool_inputs=None, dcn_offsets=None, act_sides=None, follow_stats=None, conv_impl='conv2d'):
     """x: (b, t, 3, h, w) -> (b, 3, 4h, 4w)  [or (b, 3, h, w) when hr_in].
     pool_inputs / dcn_offsets / act_sides: test aids, the discrete decisions of another run (see _follow, _ACT_SIDES).
+    conv_impl: 'conv2d' (F.conv2d) or 'unfold' (conv_unfold: im2col + GEMM, no-grad runs only).
     follow_stats: a list; receives one record per followed decision point - ('act', layer, flipped elements, elements, largest
     |pre-activation| among the flipped ones relative to the layer's max) or ('value', None, 0, elements, max |followed - own| /
     max |own|) - so that a test can bound how far the followed run strays from this oracle's own forward pass."""
-    global _ACT_SIDES, _FRAME, _FOLLOW_STATS
-    _ACT_SIDES, _FOLLOW_STATS = act_sides, follow_stats
+    global _ACT_SIDES, _FRAME, _FOLLOW_STATS, _CONV_IMPL
+    _ACT_SIDES, _FOLLOW_STATS, _CONV_IMPL = act_sides, follow_stats, conv_impl
     try:
         return _edvr_forward(sd, x, center, hr_in, with_predeblur, with_tsa, dg, dcn, taps, stats, pool_inputs, dcn_offsets)
     finally:
-        _ACT_SIDES, _FRAME, _FOLLOW_STATS = None, None, None
+        _ACT_SIDES, _FRAME, _FOLLOW_STATS, _CONV_IMPL = None, None, None, 'conv2d'
 
 
 def _edvr_forward(sd, x, center, hr_in, with_predeblur, with_tsa, dg, dcn, taps, stats, pool_inputs, dcn_offsets):

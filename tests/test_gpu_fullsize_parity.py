@@ -13,8 +13,9 @@ errors):
   EDVR-L x4, 5 frames, 180x320, one clip                 vs the CPU oracle (fp32 torch ops + C DCNv2)
   configs[2]  EDVR-L x4, 7 frames, 180x320, one clip     \
   configs[4]  EDVR-L deblur (hr_in, predeblur), 720x1280   > vs the same functional oracle (oracle/edvr_oracle.py) executed on the
-  north_star  EDVR-L x4, 5 frames, 720x1280 -> 4K        /   GPU in stock PyTorch-ROCm fp32 ops (MIOpen convs, pure-torch DCNv2) -
-                                                             the CPU oracle would need minutes per clip at these sizes
+  north_star  EDVR-L x4, 5 frames, 720x1280 -> 4K        /   GPU in stock PyTorch-ROCm fp32 ops (convs as F.unfold + rocBLAS GEMM
+                                                             or MIOpen, pure-torch DCNv2) - the CPU oracle would need minutes
+                                                             per clip at these sizes
 """
 import pytest
 import torch
@@ -86,10 +87,11 @@ def test_edvr_l_one_clip_with_intermediates_matches_the_cpu_oracle(gpu):
 
 
 BIG = {
-    # name: (ctor kwargs, clip shape, output scale)
-    'cfg2_L_T7_180x320': (dict(num_feat=128, num_frame=7, num_reconstruct_block=40, center_frame_idx=None), (7, 3, 180, 320), 4),
-    'cfg4_L_deblur_720x1280': (dict(EDVR_L, hr_in=True, with_predeblur=True), (5, 3, 720, 1280), 1),
-    'north_star_L_720x1280_to_4k': (EDVR_L, (5, 3, 720, 1280), 4),
+    # name: (ctor kwargs, clip shape, output scale, convolution of the oracle arm)
+    'cfg2_L_T7_180x320': (dict(num_feat=128, num_frame=7, num_reconstruct_block=40, center_frame_idx=None), (7, 3, 180, 320), 4, 'conv2d'),
+    'cfg4_L_deblur_720x1280': (dict(EDVR_L, hr_in=True, with_predeblur=True), (5, 3, 720, 1280), 1, 'conv2d'),
+    # (MIOpen compiles ~20 kernels for the new shapes of this one on a fresh box: 4 minutes; im2col + GEMM needs no compilation)
+    'north_star_L_720x1280_to_4k': (EDVR_L, (5, 3, 720, 1280), 4, 'unfold'),
 }
 
 
@@ -97,13 +99,14 @@ BIG = {
 def test_edvr_l_big_configs_match_stock_rocm_ops_with_intermediates(gpu, name):
     """One clip of BASELINE.json's configs[2], configs[4] and the north_star's 720p -> 4K target at their REAL sizes.  Oracle =
     oracle/edvr_oracle.py (the restatement pinned against the reference's own Python, tests/test_golden.py) executed on the GPU
-    in stock fp32 ops: F.conv2d -> MIOpen, DCNv2 = the floor/gather restatement oracle/dcn_oracle.py::dcnv2_torch.  Nothing of
+    in stock fp32 ops: F.conv2d -> MIOpen (or F.unfold + torch.addmm -> rocBLAS, oracle/edvr_oracle.py::conv_unfold), DCNv2 = the
+    floor/gather restatement oracle/dcn_oracle.py::dcnv2_torch.  Nothing of
     edvr_amd runs in that arm.  4K exercises what smaller runs do not: planes beyond 2^31 bytes per image (the 1x1 stream
     kernel's channel segments, csrc/conv1x1.hip), the 32-bit buffer-offset eligibility of the F(4x4) and fused-DCN kernels."""
     from edvr_amd import EDVR
     from oracle import dcn_oracle as O, edvr_oracle as EO
     from util_edvr import randomize_offsets
-    cfg, shape, scale = BIG[name]
+    cfg, shape, scale, conv_impl = BIG[name]
     torch.manual_seed(10)
     net = randomize_offsets(EDVR(**cfg)).eval().to(gpu)
     x = torch.rand(1, *shape, generator=torch.Generator().manual_seed(0)).to(gpu)
@@ -115,5 +118,5 @@ def test_edvr_l_big_configs_match_stock_rocm_ops_with_intermediates(gpu, name):
         torch.cuda.synchronize()
         sd = net.state_dict()
         ref = EO.edvr_forward(sd, x, center=cfg.get('center_frame_idx'), hr_in=cfg.get('hr_in', False),
-                              with_predeblur=cfg.get('with_predeblur', False), dcn=O.dcnv2_torch, taps=taps_ref)
+                              with_predeblur=cfg.get('with_predeblur', False), dcn=O.dcnv2_torch, taps=taps_ref, conv_impl=conv_impl)
     _compare(out, ref, taps, taps_ref, gt, EO)

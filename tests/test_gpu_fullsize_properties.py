@@ -168,9 +168,12 @@ def test_f4_data_gradient_is_the_adjoint_at_the_bench_launch_shape(gpu, data50):
     """<dy, conv_W(x)> == <conv_{W^T flipped}(dy), x>: the transpose_flip packing run through the same kernel is the adjoint
     of the forward - ties the F(4x4) data gradient of the training path to its forward at full size."""
     from edvr_amd import ops
-    x, dy, w, _ = data50
+    x, y, w, _ = data50
     out = _f4(ops, x, w)
+    # dy correlated with the output, so that <dy, out> is ~ |out|^2 and not the near-cancelling sum of 3.7e8 random products (a
+    # purely random dy gives |<dy, out>| ~ 1e-7 of sum |dy . out|: relative errors of THAT number measure nothing)
+    dy = 0.5 * out + y
     lhs = (dy.double() * out.double()).sum().item()
     del out
     dx = _f4(ops, dy, w, flip=True)
-    assert abs((dx.double() * x.double()).sum().item() - lhs) / abs(lhs) < 1e-4
+    assert abs((dx.double() * x.double()).sum().item() - lhs) / abs(lhs) < 1e-5
