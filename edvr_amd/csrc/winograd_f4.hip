@@ -40,6 +40,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// v_max_f32 as it is: fmaxf() compiles to a canonicalising v_max_f32 v, v, v in front of the real one (IEEE sNaN quieting), a third
+// instruction per output element of the activation on waves whose instruction count is what the epilogue costs
+__device__ __forceinline__ float max_raw(float a, float b) {
+  float o;
+  asm("v_max_f32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b));
+  return o;
+}
+
 struct WinoF4Args {
   edvr_conv2d_desc d;
   const float *U;  // [co block 64][channel pair][row 6][co half 2][lane 64 x 4 | lane 64 x 2]
@@ -94,12 +102,17 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
   constexpr int VSLAB = CK * 36 * 32;   // floats per V stage (36 KB): [channel 8][position 36][tile 32]
   constexpr int XSZ = 2 * 6 * 8 * 32 * 4;  // exchange area (2 x 24 KB): [phase parity][row 6][channel 8][tile 32][4]
   constexpr int RWAVE = 6 * 64 * 4 + 4;     // raw-input region of one producer wave: 6 DMA instructions x 64 lanes x 16 B, + one-dword shift (below)
-  __shared__ __attribute__((aligned(16))) float smem[2 * VSLAB + XSZ + 4 * RWAVE];  // 144 KB
+  __shared__ __attribute__((aligned(16))) float smem[2 * VSLAB + XSZ + 4 * RWAVE + 64];  // 144 KB
   float *const Xs = smem + 2 * VSLAB;
+  float *const bias_s = smem + 2 * VSLAB + XSZ + 4 * RWAVE;  // the 64 biases of the item's channel block (below)
 
   const edvr_conv2d_desc &d = a.d;
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, j = lane & 31;
+#ifdef F4_EXP_PRODLAST /* experiment: the staging waves are the LAST four hardware waves of the workgroup instead of the first */
+  const int wave = __builtin_amdgcn_readfirstlane(((tid >> 6) + 4) & 15);
+#else
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
   const int hw = d.h * d.w, plane_bytes = hw * 4;
   const int co_blocks = (d.co + 63) / 64;
   const int n_chunks = a.ci / CK;
@@ -199,6 +212,9 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the requested chunk is in the region
 #endif
       F4_PSTAMP(0);
+#ifdef F4_EXP_NOPREAD /* ablation (wrong results): no patch reads */
+      return;
+#endif
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
         const f32x4 m = *reinterpret_cast<const f32x4 *>(patch + r * (4 * RPIECES));
@@ -210,6 +226,10 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
       F4_PSTAMP(1);
     };
     auto transform_cols = [&](int cp) {  // 1-D input transform B^T (Lavin & Gray), 12 operations (a * b + c contracts to an fma)
+#ifdef F4_EXP_NOXFORM /* ablation (wrong results): no transform arithmetic */
+      for (int r = 0; r < 6; ++r) tp[r][cp] = pp[r][cp];
+      return;
+#endif
       const f32x2 d0 = pp[0][cp], d1 = pp[1][cp], d2 = pp[2][cp], d3 = pp[3][cp], d4 = pp[4][cp], d5 = pp[5][cp];
       const f32x2 p_ = d4 - 4.f * d2, q_ = d3 - 4.f * d1, r_ = d4 - d2, s_ = d3 - d1;
       tp[0][cp] = 4.f * d0 + (d4 - 5.f * d2);
@@ -221,6 +241,17 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
     };
     auto commit_row = [&](float *Vd, int r) {  // positions (r, 0..5) of (B^T d) B
       const f32x2 P0 = tp[r][0], P1 = tp[r][1], P2 = tp[r][2];
+#ifdef F4_EXP_NOVW /* ablation (wrong results): no V writes (the values are kept alive) */
+      asm volatile("" ::"v"(P0), "v"(P1), "v"(P2));
+      return;
+#endif
+#ifdef F4_EXP_NOXFORM
+      {
+        float *dst = Vd + ((2 * wave + half) * 36 + r * 6) * 32 + j;
+        dst[0 * 32] = P0[0]; dst[1 * 32] = P0[1]; dst[2 * 32] = P1[0]; dst[3 * 32] = P1[1]; dst[4 * 32] = P2[0]; dst[5 * 32] = P2[1];
+        return;
+      }
+#endif
       const f32x2 lo1 = __builtin_shufflevector(P1, P1, 0, 0), hi1 = __builtin_shufflevector(P1, P1, 1, 1);  // d2, d3
       const f32x2 lo2 = __builtin_shufflevector(P2, P2, 0, 0), hi0 = __builtin_shufflevector(P0, P0, 1, 1);  // d4, d1
       const f32x2 t05 = 4.f * P0 + (P2 - 5.f * P1);
@@ -296,22 +327,24 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
       const float slope = d.act == EDVR_ACT_LRELU ? 0.1f : (d.act == EDVR_ACT_RELU ? 0.f : 1.f);  // none/relu/lrelu = max(v, slope*v)
       const bool sig = d.act == EDVR_ACT_SIGMOID, shuffle = d.out_mode == EDVR_OUT_PIXEL_SHUFFLE2;
       const bool vec = e_tx0 + BW <= d.w;  // the block is inside the image in x (w % 4 == 0): 16-byte rows, only the ROW is tested
-      const int cl8 = tid >> 5, tile = tid & 31;
+      const int cl8 = (wave * 64 + lane) >> 5, tile = lane & 31;  // (thread index within the four staging waves)
       const int oy = e_ty0 + 4 * (tile >> TXL), ox = e_tx0 + 4 * (tile & (TX - 1));
       const int co_t = e_co_blk + (cl8 >> 2) * 32 + 4 * ((cl8 >> 1) & 1) + 8 * (cl8 & 1);  // + (p & 3) + 16 (p >> 2) in phase p
       const int pix = oy * d.w + ox;
       const int rows_in = d.h - oy;  // rows of this lane's tile inside the image (>= 4: all of them)
+      // The biases of the item's 64 channels go through LDS: a vector-memory load inside the phase loop would have to be waited
+      // for with vmcnt(0) - the counter is in issue order and counts stores - i.e. every phase would also wait for the store
+      // acknowledgements of its predecessor.  Layers without residual / gate then have no vector-memory load in the loop at all.
+      if (wave == 0) bias_s[lane] = (d.bias && e_co_blk + lane < d.co) ? d.bias[e_co_blk + lane] : 0.f;  // read after the first phase barrier
       auto column_pass = [&](auto VEC, auto SHUF) {
         constexpr bool V = decltype(VEC)::value;     // whole 16-byte rows inside the image in x: no per-element tests
         constexpr bool SHF = decltype(SHUF)::value;  // V && PixelShuffle(2): channels 2 q, 2 q + 1 (consecutive phases of this thread)
                                                      // interleave along x - two 16-byte stores per row and channel pair
         f32x4 Yprev[4];
         f32x4 rr[4];
-        float b_next = 0.f;
         auto co_of = [&](int p) { return co_t + (p & 3) + 16 * (p >> 2); };
-        auto prefetch = [&](int p) {  // bias and (V) rows oy .. oy + 3 of the residual(s) / gate of channel co_of(p)
+        auto prefetch = [&](int p) {  // (V) rows oy .. oy + 3 of the residual(s) / gate of channel co_of(p)
           const int co = min(co_of(p), d.co - 1);
-          b_next = d.bias ? d.bias[co] : 0.f;
           if (V && !SHF && rq) {
             const float *q1 = rq + (int64_t)co * plane + pix;
 #pragma unroll
@@ -333,7 +366,7 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
 #pragma unroll
           for (int r = 0; r < 6; ++r) T[r] = *reinterpret_cast<const f32x4 *>(Xb + r * (8 * 32 * 4));
           const int co = co_of(p);
-          const float b = b_next;
+          const float b = bias_s[co - e_co_blk];
           const float sl = co >= d.act_from ? slope : 1.f;
           f32x4 Y[4];
 #pragma unroll
@@ -355,9 +388,13 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-              for (int jj = 0; jj < 4; ++jj) Y[i][jj] = fmaxf(Y[i][jj], sl * Y[i][jj]);
+              for (int jj = 0; jj < 4; ++jj) Y[i][jj] = max_raw(Y[i][jj], sl * Y[i][jj]);
           }
+          // The bias / residual / gate rows of the NEXT phase are requested BEFORE this phase's stores: the memory counter is
+          // in issue order, so their use then only waits for operations issued up to them (vmcnt(4): the four stores below stay
+          // in flight) - requested after the stores, every phase waited for its predecessor's store acknowledgements.
           if (SHF) {
+            prefetch(min(p + 1, 7));
             if ((p & 1) == 0) {
 #pragma unroll
               for (int i = 0; i < 4; ++i) Yprev[i] = Y[i];
@@ -382,6 +419,7 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) Y[i][jj] = __builtin_fmaf(Y[i][jj], a.ys, rr[i][jj]);
             }
+            prefetch(min(p + 1, 7));
             if (co < d.co) {
               float *q = y + (int64_t)co * plane + pix;
 #pragma unroll
@@ -406,8 +444,10 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
                 }
               }
             }
+            prefetch(min(p + 1, 7));
+          } else {
+            prefetch(min(p + 1, 7));
           }
-          prefetch(min(p + 1, 7));  // consumed one phase later
         }
       };
       if (vec && shuffle) column_pass(std::true_type{}, std::true_type{});
@@ -432,9 +472,15 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
       a2[set] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(u_rsrc, voff2, soff, 0));
     };
     auto load_a4 = [&](int set, int t) {
+#ifdef F4_EXP_NOULOAD /* ablation (wrong results): the weights are fetched once per item, not per k-step */
+      return;
+#endif
       a4[set] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, voff4, u_base + t * (12 * 1536), 0));
     };
     auto load_a2 = [&](int set, int t) {
+#ifdef F4_EXP_NOULOAD
+      return;
+#endif
       a2[set] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(u_rsrc, voff2, u_base + t * (12 * 1536), 0));
     };
     int co_blk, img_, ty_, tx_;
@@ -510,6 +556,9 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
             acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[set][1], bv[cur][2], acc[5], 0, 0, 0);
             load_a2(set, t_next);
           }
+#ifdef F4_EXP_SLEEP /* experiment: a consumer yields the issue port after every group of three MFMAs */
+          __builtin_amdgcn_s_sleep(F4_EXP_SLEEP);
+#endif
           __builtin_amdgcn_sched_barrier(0);
         }
         F4_BARRIER_T();
