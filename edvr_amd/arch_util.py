@@ -79,9 +79,8 @@ class DCNv2Pack(ModulatedDeformConvPack):
     last_offset_absmean = None  # mean |offset| of the previous call: picks the fused kernel's halo class (perf hint only)
 
     def forward(self, x, feat, act=F_.ACT_NONE):
-        om = F_.offset_mask_conv(self.conv_offset, feat)
+        om, sums = F_.offset_mask_conv_stats(self.conv_offset, feat)
         offset = om.detach()[:, :2 * om.shape[1] // 3]
-        sums = F_.ops.abs_sum_per_image(offset)
         if self.stats_sink is not None:
             self.stats_sink.append((sums, offset[0].numel(), self))
         else:

@@ -372,6 +372,10 @@ int conv2d_launch(const edvr_conv2d_desc &d, hipStream_t stream) {
     set_error("conv2d: gate together with a sigmoid epilogue is not supported");
     return EDVR_ERR_UNSUPPORTED;
   }
+  if (d.abs_sum && (conv_small_eligible(d) || !winograd_f4_eligible(d))) {
+    set_error("conv2d: abs_sum is an epilogue of the F(4x4) Winograd kernel only (ask edvr_conv2d_abs_sum_supported)");
+    return EDVR_ERR_UNSUPPORTED;
+  }
   if (!d.gate && !scaled && conv_small_eligible(d)) return conv_small_launch(d, stream);
   if (winograd_f4_eligible(d)) return winograd_f4_launch(d, stream);
   if (winograd_eligible(d)) {
@@ -441,6 +445,11 @@ int edvr_conv2d_executed_flops(const edvr_conv2d_desc *d, double *flops) {
   else if (!edvr::conv_small_eligible(*d) && edvr::winograd_eligible(*d)) *flops = edvr::winograd_executed_flops(*d);
   else *flops = 2.0 * d->n * ho * wo * d->co * (d->c1 + d->c2) * d->ks * d->ks;  // direct algorithm (tile padding not counted)
   return EDVR_OK;
+}
+
+int edvr_conv2d_abs_sum_supported(const edvr_conv2d_desc *d) {
+  if (!d) return 0;
+  return (!edvr::conv_small_eligible(*d) && edvr::winograd_f4_eligible(*d)) ? 1 : 0;
 }
 
 int edvr_conv2d_gate_supported(const edvr_conv2d_desc *d) {

@@ -291,9 +291,25 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
     F4_BARRIER_T();
 
     int par = 0;  // stage the consumers read during the current step
+    // abs_sum epilogue (edvr_conv2d_desc.abs_sum): every staging thread sums |y| of the elements it stores, over the items of one
+    // image; when the walk enters another image (a workgroup's items cover one or two) and at the end, the wave folds its 64 sums
+    // and adds one value to abs_sum[image] - a few thousand atomics per launch.
+    float asum = 0.f;
+    int asum_img = -1;
+    auto asum_flush = [&]() {
+      float s = asum;
+#pragma unroll
+      for (int sh = 32; sh > 0; sh >>= 1) s += __shfl_xor(s, sh);
+      if (lane == 0 && asum_img >= 0 && s != 0.f) atomicAdd(d.abs_sum + asum_img, s);
+      asum = 0.f;
+    };
     for (int item = item_first; item < item_end; item += xcd_wgs) {
       int e_co_blk, e_img, e_ty0, e_tx0;
       decode(item, e_co_blk, e_img, e_ty0, e_tx0);
+      if (d.abs_sum && e_img != asum_img) {
+        asum_flush();
+        asum_img = e_img;
+      }
 #pragma unroll 1
       for (int k = 0; k < n_chunks; ++k) {
         // the region holds chunk k + 1 (chunk 0 of the next item at the end): patches -> registers, request chunk k + 2,
@@ -408,6 +424,11 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
                 }
             }
           } else if (V) {
+            if (d.abs_sum && co < d.abs_sum_channels) {  // (channels below act_from: Y is the conv output + bias here)
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                if (i < rows_in) asum += (fabsf(Y[i][0]) + fabsf(Y[i][1])) + (fabsf(Y[i][2]) + fabsf(Y[i][3]));
+            }
             if (gt) {
 #pragma unroll
               for (int i = 0; i < 4; ++i)
@@ -435,6 +456,7 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
               for (int jj = 0; jj < 4; ++jj) {
                 if (ox + jj < d.w) {
                   float o = Y[i][jj];
+                  if (d.abs_sum && co < d.abs_sum_channels) asum += fabsf(o);
                   if (gt) o *= gt[off + jj] > 0.f ? a.ys : a.ys_gs;
                   else if (r1) o = __builtin_fmaf(o, a.ys, r1[off + jj] + (r2 ? r2[off + jj] : 0.f));
                   if (shuffle)
@@ -454,6 +476,7 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
       else if (vec) column_pass(std::true_type{}, std::false_type{});
       else column_pass(std::false_type{}, std::false_type{});
     }
+    if (d.abs_sum) asum_flush();
   } else {
     // =========================================================================================== consumers
     const int q = wave - 4, wm = q & 1, row = q >> 1;

@@ -24,8 +24,10 @@ def _needs_grad(*ts):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
 
 
-def conv(m, x, *, x2=None, x2_map=None, act=ACT_NONE, act_from=0, res1=None, res2=None, out_mode=OUT_NCHW, y_scale=1.0):
-    """y_scale * act(conv(cat(x, x2)) + bias) + res1 + res2 with the parameters of nn.Conv2d `m`."""
+def conv(m, x, *, x2=None, x2_map=None, act=ACT_NONE, act_from=0, res1=None, res2=None, out_mode=OUT_NCHW, y_scale=1.0,
+         abs_sum_channels=0):
+    """y_scale * act(conv(cat(x, x2)) + bias) + res1 + res2 with the parameters of nn.Conv2d `m`.
+    abs_sum_channels > 0 (no-grad calls only): returns (y, per-image sums of |y[:, :abs_sum_channels]|), ops.conv2d."""
     ks, stride = _conv_geometry(m)
     if x.dim() != 4:
         raise ValueError(f'expected a 4-D input, got {tuple(x.shape)}')
@@ -35,6 +37,7 @@ def conv(m, x, *, x2=None, x2_map=None, act=ACT_NONE, act_from=0, res1=None, res
     ops.require_gpu(x, x2, m.weight)
     if _needs_grad(x, x2, m.weight, m.bias, res1, res2):
         from . import autograd as ag
+        assert abs_sum_channels == 0
         return ag.conv(m, x, x2, x2_map, act, act_from, res1, res2, out_mode, ks, stride, y_scale)
     wpk = ops.pack_conv_weight(m.weight)
     # the F(4x4,3x3) Winograd weights let the C side pick that kernel where it is the fastest (2.25 instead of 4 multiplies per
@@ -44,7 +47,18 @@ def conv(m, x, *, x2=None, x2_map=None, act=ACT_NONE, act_from=0, res1=None, res
                                                       and m.out_channels >= 48) else None
     bias = m.bias.detach() if m.bias is not None else None
     return ops.conv2d(x, wpk, bias, m.out_channels, ks, x2=x2, x2_map=x2_map, stride=stride, act=act, act_from=act_from,
-                      res1=res1, res2=res2, out_mode=out_mode, y_scale=y_scale, wpk_f4=wf4)
+                      res1=res1, res2=res2, out_mode=out_mode, y_scale=y_scale, wpk_f4=wf4, abs_sum_channels=abs_sum_channels)
+
+
+def offset_mask_conv_stats(conv_offset, feat):
+    """offset_mask_conv + the per-image sums of |offset| that DCNv2Pack's `> 50` check needs (arch_util.py:248-253) -> (om, sums).
+    Without gradients the sums come out of the conv's own epilogue (no second pass over the offsets) where the layer runs on the
+    F(4x4) kernel; the training path and small layers use the separate reduction kernel."""
+    co = conv_offset.out_channels
+    if _needs_grad(feat, conv_offset.weight, conv_offset.bias):
+        om = offset_mask_conv(conv_offset, feat)
+        return om, ops.abs_sum_per_image(om.detach()[:, :2 * co // 3])
+    return conv(conv_offset, feat, act=ACT_SIGMOID, act_from=2 * co // 3, abs_sum_channels=2 * co // 3)
 
 
 def offset_mask_conv(conv_offset, feat):

@@ -149,7 +149,7 @@ F4_TRAINING = os.environ.get('EDVR_WINOGRAD_F4_TRAIN', '1') != '0'  # autograd.p
 
 
 def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NONE, act_from=0, res1=None, res2=None,
-           out_mode=OUT_NCHW, out=None, algo=None, gate=None, gate_slope=0.0, y_scale=1.0, wpk_f4=None):
+           out_mode=OUT_NCHW, out=None, algo=None, gate=None, gate_slope=0.0, y_scale=1.0, wpk_f4=None, abs_sum_channels=0):
     """y = y_scale * act(conv(cat(x1, x2)) + bias) + res1 + res2 on the fp32 MFMA kernel.
     algo: CONV_AUTO (default; module-level CONV_ALGO overrides it, used by tests), CONV_DIRECT, CONV_WINOGRAD or CONV_WINOGRAD_F4.
     wpk_f4: pack_conv_weight(w, f4=True) - allows the F(4x4,3x3) Winograd kernel (inference; ~1e-6 relative rounding error).
@@ -158,6 +158,8 @@ def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NON
     gate (n, co, ho, wo): y *= gate > 0 ? 1 : gate_slope - the backward of a ReLU / LeakyReLU fused into the data-gradient conv
     (3x3 kernels; in the Winograd kernel's epilogue where that kernel applies, else in the direct kernel's).
     y_scale: ResidualBlockNoBN's res_scale (arch_util.py:95), 3x3 kernels only.
+    abs_sum_channels > 0: returns (y, sums) with sums[i] = sum |y[i, :abs_sum_channels]| - in the conv's own epilogue where the
+    launch runs on the F(4x4) kernel (edvr_conv2d_desc.abs_sum), by the separate abs_sum kernel otherwise.
     """
     require_gpu(x1, x2, wpk, bias, res1, res2)
     L = _lib.lib()
@@ -204,6 +206,10 @@ def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NON
         require_gpu(wpk_f4)
         d.wpk_f4 = _ptr(wpk_f4)
     d.algo = CONV_ALGO if algo is None else algo
+    sums = None
+    if abs_sum_channels > 0 and out_mode == OUT_NCHW and L.edvr_conv2d_abs_sum_supported(ctypes.byref(d)):
+        sums = torch.zeros(n, dtype=torch.float32, device=x1.device)
+        d.abs_sum, d.abs_sum_channels = _ptr(sums), int(abs_sum_channels)
     name, flops, nbytes, executed = 'conv2d', 0.0, 0.0, None
     if LAUNCH_HOOK is not None:  # measurement only (bench.py): brackets the launch with events on this stream
         buf = ctypes.create_string_buffer(96)
@@ -217,6 +223,8 @@ def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NON
         nbytes = 4.0 * (n * (c1 + d.c2) * h * w + n * co * ho * wo * (1 + (res1 is not None) + (res2 is not None) + (gate is not None))
                         + co * (c1 + d.c2) * ks * ks)
     _run(name, lambda: _lib.check(L.edvr_conv2d_f32(ctypes.byref(d), _stream()), 'edvr_conv2d_f32'), flops, nbytes, executed)
+    if abs_sum_channels > 0:
+        return out, (sums if sums is not None else abs_sum_per_image(out[:, :abs_sum_channels]))
     return out
 
 

@@ -118,6 +118,12 @@ typedef struct edvr_conv2d_desc {
                            * rounding error ~1e-6 of the output scale instead of ~2e-7) under EDVR_CONV_AUTO where that kernel is the
                            * fastest; NULL keeps the F(2x2) / direct choice.  edvr_amd's inference AND training paths (forward and
                            * data-gradient convs; the weight gradient stays in the F(2x2) domain) pass it by default. */
+  float *abs_sum;         /* optional (n): abs_sum[i] += sum |y[i, c, :, :]| over the output channels c < abs_sum_channels, added with
+                           * atomics in the epilogue (the caller zeroes the array; summation order is not deterministic).  This is the
+                           * statistic behind DCNv2Pack's "Offset abs mean is ..., larger than 50" check (arch_util.py:248-253) taken
+                           * where conv_offset's output is still in registers instead of re-reading it (edvr_abs_sum_f32).  Only the
+                           * F(4x4) kernel has this epilogue: ask edvr_conv2d_abs_sum_supported; EDVR_ERR_UNSUPPORTED otherwise. */
+  int abs_sum_channels;
 } edvr_conv2d_desc;
 
 size_t edvr_conv2d_packed_weight_elems(int co, int ci, int ks);
@@ -137,6 +143,8 @@ int edvr_conv2d_f32(const edvr_conv2d_desc *d, edvr_stream_t stream);
  * kernel - correct, slower).  Callers that fuse an activation backward into a data-gradient conv ask first and keep the
  * two-launch form otherwise.  Pointers of `d` need not be set. */
 int edvr_conv2d_gate_supported(const edvr_conv2d_desc *d);
+/* 1 if edvr_conv2d_f32 would run `d` on a kernel whose epilogue takes `abs_sum` (the F(4x4) Winograd kernel), else 0. */
+int edvr_conv2d_abs_sum_supported(const edvr_conv2d_desc *d);
 /* Name of the kernel template instantiation edvr_conv2d_f32 would launch for `d` (as rocprofv3 prints it),
  * written to buf; returns 0 or EDVR_ERR_*.  Measurement aid only. */
 int edvr_conv2d_kernel_name(const edvr_conv2d_desc *d, char *buf, size_t buf_len);

@@ -158,3 +158,26 @@ def test_f4_packed_weights_match_the_oracle_layout(gpu, flip):
     want = W.pack_operand_order(wt, transpose_flip=flip)
     assert got.shape == want.shape
     assert (got - want).abs().max().item() < 2e-7 * want.abs().max().item()
+
+
+@pytest.mark.parametrize('shape', [(3, 64, 20, 64, 216), (2, 32, 9, 68, 216), (5, 128, 45, 80, 216), (1, 32, 12, 36, 96)])
+def test_f4_abs_sum_epilogue(gpu, shape):
+    """edvr_conv2d_desc.abs_sum: per-image sums of |y| over the first channels (conv_offset's offsets: bias added, no activation
+    below act_from), accumulated in the F(4x4) kernel's epilogue - vector rows, ragged blocks, blocks below the image, several
+    images per workgroup walk - against the plain reduction of the output; and the fallback to the separate kernel."""
+    from edvr_amd import ops
+    n, c, h, w, co = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(n, c, h, w, generator=g).to(gpu)
+    wt = (torch.randn(co, c, 3, 3, generator=g) * 0.1).to(gpu)
+    b = torch.randn(co, generator=g).to(gpu)
+    wpk, wf4 = ops.pack_conv_weight(wt), ops.pack_conv_weight(wt, f4=True)
+    nch = 2 * co // 3
+    kw = dict(act=ops.ACT_SIGMOID, act_from=nch)
+    y, sums = ops.conv2d(x, wpk, b, co, 3, wpk_f4=wf4, algo=ops.CONV_WINOGRAD_F4, abs_sum_channels=nch, **kw)
+    y0 = ops.conv2d(x, wpk, b, co, 3, wpk_f4=wf4, algo=ops.CONV_WINOGRAD_F4, **kw)
+    assert torch.equal(y, y0)  # the extra epilogue does not touch the output
+    want = y0[:, :nch].double().abs().sum((1, 2, 3))
+    assert ((sums.double() - want).abs() / want).max().item() < 1e-5
+    y2, sums2 = ops.conv2d(x, wpk, b, co, 3, algo=ops.CONV_DIRECT, abs_sum_channels=nch, **kw)  # no such epilogue: separate kernel
+    assert ((sums2.double() - y2[:, :nch].double().abs().sum((1, 2, 3))).abs() / want).max().item() < 1e-5

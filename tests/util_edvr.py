@@ -55,7 +55,7 @@ class DecisionRecorder:
     def __enter__(self):
         from edvr_amd import autograd as ag, functional as F_
         self._F, self._ag = F_, ag
-        self._saved = (F_.conv, F_.dcn_from_packed, F_.pool_maxavg, F_.offset_mask_conv, ag.ResBlockFn.forward)
+        self._saved = (F_.conv, F_.dcn_from_packed, F_.pool_maxavg, F_.offset_mask_conv_stats, ag.ResBlockFn.forward)
         conv, dcn, pool, omc, rbf = self._saved
         rec = self
 
@@ -80,9 +80,9 @@ class DecisionRecorder:
             return pool(t)
 
         def omc_w(m, f):
-            om = omc(m, f)
+            om, sums = omc(m, f)
             rec.oms.append(om.detach().cpu())
-            return om
+            return om, sums
 
         def rbf_w(ctx, x, w1, b1, w2, b2, res_scale=1.0):  # fused residual block: the hidden ReLU output is only in ctx
             y = rbf(ctx, x, w1, b1, w2, b2, res_scale)
@@ -90,7 +90,7 @@ class DecisionRecorder:
             return y
 
         self._resblock_h = []
-        F_.conv, F_.dcn_from_packed, F_.pool_maxavg, F_.offset_mask_conv = conv_w, dcn_w, pool_w, omc_w
+        F_.conv, F_.dcn_from_packed, F_.pool_maxavg, F_.offset_mask_conv_stats = conv_w, dcn_w, pool_w, omc_w
         ag.ResBlockFn.forward = staticmethod(rbf_w)
         self._net_params = None
         return self
@@ -104,7 +104,7 @@ class DecisionRecorder:
 
     def __exit__(self, *exc):
         F_, ag = self._F, self._ag
-        F_.conv, F_.dcn_from_packed, F_.pool_maxavg, F_.offset_mask_conv = self._saved[:4]
+        F_.conv, F_.dcn_from_packed, F_.pool_maxavg, F_.offset_mask_conv_stats = self._saved[:4]
         ag.ResBlockFn.forward = staticmethod(self._saved[4])
         return False
 
