@@ -35,6 +35,8 @@ PROTOTYPES = {
     'edvr_conv2d_pack_weight_f32': (i32, [vp, vp, i32, i32, i32, i32, vp]),
     'edvr_conv2d_packed_weight_f4_elems': (sz, [i32, i32]),
     'edvr_conv2d_pack_weight_f4_f32': (i32, [vp, vp, i32, i32, i32, vp]),
+    'edvr_pack_job_bytes': (sz, []),
+    'edvr_conv2d_pack_weights_multi': (i32, [vp, i32, i32, vp]),
     'edvr_conv2d_f32': (i32, [ctypes.POINTER(ConvDesc), vp]),
     'edvr_conv2d_gate_supported': (i32, [ctypes.POINTER(ConvDesc)]),
     'edvr_conv2d_abs_sum_supported': (i32, [ctypes.POINTER(ConvDesc)]),

@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "pack.h"
 
 namespace edvr {
 
@@ -486,39 +487,11 @@ __global__ void winograd_weight_kernel(const float *__restrict__ w, float *__res
   const int64_t total = (int64_t)cip * cop;
   if (wpk) {
     const int64_t dtotal = (int64_t)cip * 9 * cop32;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < dtotal; i += (int64_t)gridDim.x * blockDim.x) {
-      const int o = (int)(i % cop32), t = (int)((i / cop32) % 9), c = (int)(i / ((int64_t)cop32 * 9));
-      float v = 0.f;
-      if (o < co && c < ci) v = transpose_flip ? w[((int64_t)c * co + o) * 9 + (8 - t)] : w[((int64_t)o * ci + c) * 9 + t];
-      wpk[i] = v;
-    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < dtotal; i += (int64_t)gridDim.x * blockDim.x)
+      pack_direct_elem(w, wpk, i, co, ci, 9, cop32, transpose_flip);  // pack.h
   }
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int o = (int)(i % cop), c = (int)(i / cop);
-    float g[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      float v = 0.f;
-      if (o < co && c < ci) v = transpose_flip ? w[((int64_t)c * co + o) * 9 + (8 - t)] : w[((int64_t)o * ci + c) * 9 + t];
-      g[t] = v;
-    }
-    float tmp[12];
-#pragma unroll
-    for (int jx = 0; jx < 3; ++jx) {  // G g
-      tmp[0 * 3 + jx] = g[0 * 3 + jx];
-      tmp[1 * 3 + jx] = 0.5f * (g[0 * 3 + jx] + g[1 * 3 + jx] + g[2 * 3 + jx]);
-      tmp[2 * 3 + jx] = 0.5f * (g[0 * 3 + jx] - g[1 * 3 + jx] + g[2 * 3 + jx]);
-      tmp[3 * 3 + jx] = g[2 * 3 + jx];
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {  // (G g) G^T
-      float *dst = U + ((int64_t)c * 16 + r * 4) * cop + o;
-      dst[0 * (int64_t)cop] = tmp[r * 3 + 0];
-      dst[1 * (int64_t)cop] = 0.5f * (tmp[r * 3 + 0] + tmp[r * 3 + 1] + tmp[r * 3 + 2]);
-      dst[2 * (int64_t)cop] = 0.5f * (tmp[r * 3 + 0] - tmp[r * 3 + 1] + tmp[r * 3 + 2]);
-      dst[3 * (int64_t)cop] = tmp[r * 3 + 2];
-    }
-  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    pack_u2_elem(w, U, i, co, ci, cop, transpose_flip);
 }
 
 bool winograd_eligible(const edvr_conv2d_desc &d) {

@@ -33,6 +33,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "pack.h"
 
 namespace edvr {
 
@@ -630,45 +631,8 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
 __global__ void winograd_f4_weight_kernel(const float *__restrict__ w, float *__restrict__ U, int co, int ci, int cop, int cip,
                                           int transpose_flip) {
   const int64_t total = (int64_t)cip * cop;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int o = (int)(i % cop), c = (int)(i / cop);
-    float g[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      float v = 0.f;
-      if (o < co && c < ci) v = transpose_flip ? w[((int64_t)c * co + o) * 9 + (8 - t)] : w[((int64_t)o * ci + c) * 9 + t];
-      g[t] = v;
-    }
-    // rows of G: (1/4, 0, 0), (-1/6, -1/6, -1/6), (-1/6, 1/6, -1/6), (1/24, 1/12, 1/6), (1/24, -1/12, 1/6), (0, 0, 1)
-    auto G6 = [](float g0, float g1, float g2, float *o6) {
-      const float e = (g0 + g2) * (-1.f / 6.f), f = g1 * (-1.f / 6.f);
-      const float p = g0 * (1.f / 24.f) + g2 * (1.f / 6.f), q2 = g1 * (1.f / 12.f);
-      o6[0] = g0 * 0.25f;
-      o6[1] = e + f;
-      o6[2] = e - f;
-      o6[3] = p + q2;
-      o6[4] = p - q2;
-      o6[5] = g2;
-    };
-    float tmp[6][3];  // G g
-#pragma unroll
-    for (int jx = 0; jx < 3; ++jx) {
-      float col[6];
-      G6(g[0 * 3 + jx], g[1 * 3 + jx], g[2 * 3 + jx], col);
-#pragma unroll
-      for (int r = 0; r < 6; ++r) tmp[r][jx] = col[r];
-    }
-    const int64_t blk0 = ((int64_t)(o >> 6) * (cip >> 1) + (c >> 1)) * 12 + ((o >> 5) & 1);
-    const int ln = (c & 1) * 32 + (o & 31);
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {  // (G g) G^T
-      float u[6];
-      G6(tmp[r][0], tmp[r][1], tmp[r][2], u);
-      float *blk = U + (blk0 + 2 * r) * 384;
-      *reinterpret_cast<f32x4 *>(blk + ln * 4) = f32x4{u[0], u[1], u[2], u[3]};
-      *reinterpret_cast<f32x2 *>(blk + 256 + ln * 2) = f32x2{u[4], u[5]};
-    }
-  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    pack_f4_elem(w, U, i, co, ci, cop, cip, transpose_flip);  // pack.h
 }
 
 bool winograd_f4_enabled() {

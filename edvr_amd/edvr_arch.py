@@ -21,6 +21,7 @@ What differs is how the graph is executed:
   * TSA temporal attention (t dot-products + sigmoid + broadcast multiply, :171-184) is one
     bandwidth-bound kernel; max+avg pooling and their concat are one kernel.
 """
+import torch
 from torch import nn
 
 from . import functional as F_
@@ -198,6 +199,7 @@ class EDVR(nn.Module):
         self.lrelu = nn.LeakyReLU(negative_slope=0.1, inplace=True)
         self.taps = None  # set to a dict to collect intermediates (parity tests)
         self._pending_offset_stats = []  # (pinned host tensor, copy-done event, per-layer records) of earlier no-grad forwards
+        self._conv_weights = None         # conv weight Parameters (collected at the first training forward)
 
     def forward(self, x):
         b, t, c, h, w = x.shape
@@ -208,6 +210,11 @@ class EDVR(nn.Module):
         x = x.contiguous()
         ctr = self.center_frame_idx
         self.check_offsets(wait=False)  # offset statistics of earlier forwards whose copy has landed: no synchronisation
+        if torch.is_grad_enabled() and x.is_cuda:
+            # training: the optimizer has rewritten every weight - all packed layouts of all conv layers in one launch (ops.py)
+            if self._conv_weights is None:
+                self._conv_weights = [m.weight for m in self.modules() if isinstance(m, nn.Conv2d)]
+            F_.ops.prepack_conv_weights(self._conv_weights)
         frames = x.view(b * t, c, h, w)
         if self.with_predeblur:
             f1 = F_.conv(self.conv_1x1, self.predeblur(frames))

@@ -124,6 +124,70 @@ def pack_conv_weight(weight, transpose_flip=False, f4=False):
     return out
 
 
+_PACK_TABLES = {}  # job signature -> (device table, total blocks): the table of a training iteration never changes
+
+
+def prepack_conv_weights(weights):
+    """Fill the packed-weight cache for a whole network in ONE launch (edvr_conv2d_pack_weights_multi): every (weight, orientation)
+    the training step will ask pack_conv_weight / f4_weight for whose cached copy is stale - after an optimizer step: all of them,
+    ~480 separate ~5 us launches otherwise.  `weights`: iterable of conv weight Parameters (3x3 or 1x1).  Purely an optimisation:
+    whatever is not packed here is packed lazily, one launch per request, as before.  Packed buffers are rewritten in place (the
+    launch is ordered behind their last readers on the current stream), so the job table is built and uploaded once."""
+    import numpy as np
+    L = _lib.lib()
+    jobs, sig, filled = [], [], []
+    for w in weights:
+        if not w.is_cuda or w.dtype != torch.float32 or w.dim() != 4 or w.shape[2] != w.shape[3] or w.shape[2] not in (1, 3) or not w.is_contiguous():
+            continue
+        wid, ver, k = id(w), w._version, w.shape[2]
+        ent = _PACKED.get(wid)
+        if ent is None or ent[0]() is not w:
+            ent = (weakref.ref(w, lambda _r, wid=wid: _PACKED.pop(wid, None)), {})
+            _PACKED[wid] = ent
+        for flip in (False, True):
+            co, ci = (w.shape[1], w.shape[0]) if flip else (w.shape[0], w.shape[1])
+            want_f4 = F4_TRAINING and k == 3 and ci >= 32 and co >= 48  # = f4_weight()
+            outs = []
+            for f4 in ((False, True) if want_f4 else (False,)):
+                hit = ent[1].get((flip, f4))
+                if hit is not None and hit[0] == ver and hit[2] == w.data_ptr():
+                    outs.append(None)  # current
+                    continue
+                n = L.edvr_conv2d_packed_weight_f4_elems(co, ci) if f4 else L.edvr_conv2d_packed_weight_elems(co, ci, k)
+                buf = hit[1] if (hit is not None and hit[1].numel() == n and hit[1].device == w.device) else \
+                    torch.empty(n, dtype=torch.float32, device=w.device)
+                outs.append(buf)
+                filled.append((ent, (flip, f4), ver, buf, w.data_ptr()))
+            wpk = outs[0]
+            wf4 = outs[1] if want_f4 else None
+            if wpk is None and wf4 is None:
+                continue
+            work = max((wpk.numel() if wpk is not None else 0), (wf4.numel() // 36 if wf4 is not None else 0))
+            jobs.append((w.data_ptr(), wpk.data_ptr() if wpk is not None else 0, wf4.data_ptr() if wf4 is not None else 0, co, ci, k,
+                         int(flip), max(1, min(64, (work + 255) // 256))))
+    if not jobs:
+        return 0
+    key = tuple(jobs)  # (device pointers inside: unique per device)
+    tab = _PACK_TABLES.get(key)
+    if tab is None:
+        rec = np.zeros(len(jobs), dtype=np.dtype([('w', '<u8'), ('wpk', '<u8'), ('f4', '<u8'), ('co', '<i4'), ('ci', '<i4'), ('ks', '<i4'),
+                                                  ('flip', '<i4'), ('first', '<i4'), ('nb', '<i4'), ('pad', '<i4', (4,))]))
+        assert rec.dtype.itemsize == L.edvr_pack_job_bytes()
+        first = 0
+        for i, (pw, pk, pf, co, ci, k, flip, nb) in enumerate(jobs):
+            rec[i] = (pw, pk, pf, co, ci, k, flip, first, nb, (0, 0, 0, 0))
+            first += nb
+        dev = filled[0][3].device
+        tab = (torch.from_numpy(rec.view(np.uint8).copy()).to(dev), first)
+        if len(_PACK_TABLES) > 8:
+            _PACK_TABLES.clear()
+        _PACK_TABLES[key] = tab
+    _lib.check(L.edvr_conv2d_pack_weights_multi(_ptr(tab[0]), len(jobs), tab[1], _stream()), 'edvr_conv2d_pack_weights_multi')
+    for ent, k2, ver, buf, ptr in filled:
+        ent[1][k2] = (ver, buf, ptr)
+    return len(jobs)
+
+
 def f4_weight(weight, ks, transpose_flip=False):
     """The F(4x4,3x3) packing of a 3x3 weight for the training path, or None when that path is off / the layer too small."""
     if not F4_TRAINING or ks != 3:

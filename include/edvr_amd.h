@@ -137,6 +137,14 @@ int edvr_conv2d_pack_weight_f32(const float *w, float *wpk, int co, int ci, int 
  * transpose_flip as in edvr_conv2d_pack_weight_f32 (data-gradient kernel). */
 size_t edvr_conv2d_packed_weight_f4_elems(int co, int ci);
 int edvr_conv2d_pack_weight_f4_f32(const float *w, float *wpk_f4, int co, int ci, int transpose_flip, edvr_stream_t stream);
+/* Many weights in ONE launch (the training path repacks every conv weight after each optimizer step: ~480 tiny launches per
+ * iteration otherwise).  `jobs`: DEVICE array of n_jobs records of edvr_pack_job_bytes() = 64 bytes { const float *w; float *wpk;
+ * float *wpk_f4; int32 co, ci, ks, transpose_flip; int32 first_block, n_blocks; 16 bytes padding }: wpk / wpk_f4 as the two
+ * functions above fill them (either may be NULL), transpose_flip as above; job j owns the workgroups [first_block, first_block +
+ * n_blocks) of the launch (ascending, contiguous from 0; any n_blocks >= 1 - 256 elements per workgroup and pass), total_blocks =
+ * their sum.  Results are bit-identical to the per-tensor functions. */
+size_t edvr_pack_job_bytes(void);
+int edvr_conv2d_pack_weights_multi(const void *jobs, int n_jobs, int total_blocks, edvr_stream_t stream);
 int edvr_conv2d_f32(const edvr_conv2d_desc *d, edvr_stream_t stream);
 /* 1 if `d` with a `gate` (and no residuals) would run in a Winograd kernel's fused epilogue (that kernel applies under d->algo,
  * the sizes and the EDVR_CONV_WINOGRAD environment switch), else 0 (edvr_conv2d_f32 still accepts the gate on the direct

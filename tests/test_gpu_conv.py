@@ -109,3 +109,31 @@ def test_transpose_flip_pack_is_data_gradient(gpu):
     wpk = ops.pack_conv_weight(wt.float().to(gpu), transpose_flip=True)
     dx = ops.conv2d(dy.float().to(gpu), wpk, None, 24, 3)
     assert _rel(dx, x.grad) < RTOL
+
+
+def test_multi_tensor_packing_is_bit_identical(gpu):
+    """ops.prepack_conv_weights (one edvr_conv2d_pack_weights_multi launch for a whole network's weights, the training path)
+    against the per-tensor packing functions: every layout, both orientations, 1x1 / 3x3, channel counts that need padding -
+    and the cache bookkeeping (nothing to do on a second call, only the touched weight after an in-place update)."""
+    from edvr_amd import ops
+    g = torch.Generator().manual_seed(77)
+    shapes = [(128, 128, 3), (64, 3, 3), (3, 64, 3), (216, 128, 3), (70, 20, 3), (64, 640, 1), (48, 96, 1), (128, 256, 3)]
+    ws = [torch.nn.Parameter((torch.randn(co, ci, k, k, generator=g) * 0.1).to(gpu)) for co, ci, k in shapes]
+    want = {}
+    for i, w in enumerate(ws):
+        for flip in (False, True):
+            want[(i, flip, False)] = ops.pack_conv_weight(w, transpose_flip=flip).clone()
+            f4 = ops.f4_weight(w, w.shape[2], transpose_flip=flip)
+            if f4 is not None:
+                want[(i, flip, True)] = f4.clone()
+    ops.invalidate_packed_weights()
+    n_jobs = ops.prepack_conv_weights(ws)
+    assert n_jobs == 2 * len(ws)
+    for (i, flip, f4), ref in want.items():
+        got = ops.pack_conv_weight(ws[i], transpose_flip=flip, f4=f4)  # a cache hit now: the buffer the multi launch filled
+        assert torch.equal(got, ref), (shapes[i], flip, f4)
+    assert ops.prepack_conv_weights(ws) == 0
+    with torch.no_grad():
+        ws[3].mul_(2.0)  # in-place update: the version moves, as after an optimizer step
+    assert ops.prepack_conv_weights(ws) == 2
+    assert torch.equal(ops.pack_conv_weight(ws[3], f4=True), 2.0 * want[(3, False, True)])
