@@ -212,6 +212,20 @@ F4_TRAINING = os.environ.get('EDVR_WINOGRAD_F4_TRAIN', '1') != '0'  # autograd.p
 #                                                                   the gradient parity tests hold at their 1e-5 bounds)
 
 
+def set_f4(inference=None, training=None):
+    """Switch the F(4x4,3x3) Winograd kernel on / off at run time for the no-grad path (`inference`) and for the forward / data-gradient
+    convs of the training path (`training`); None leaves a setting alone.  Returns the previous (inference, training) pair.  The
+    environment variables EDVR_WINOGRAD_F4 / EDVR_WINOGRAD_F4_TRAIN only give the initial values.  (F(4x4) rounds at ~1e-6 of the
+    output scale, F(2x2) at ~2e-7.)"""
+    global F4_INFERENCE, F4_TRAINING
+    prev = (F4_INFERENCE, F4_TRAINING)
+    if inference is not None:
+        F4_INFERENCE = bool(inference)
+    if training is not None:
+        F4_TRAINING = bool(training)
+    return prev
+
+
 def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NONE, act_from=0, res1=None, res2=None,
            out_mode=OUT_NCHW, out=None, algo=None, gate=None, gate_slope=0.0, y_scale=1.0, wpk_f4=None, abs_sum_channels=0):
     """y = y_scale * act(conv(cat(x1, x2)) + bias) + res1 + res2 on the fp32 MFMA kernel.

@@ -25,6 +25,9 @@ def train(args, log=print):
     from edvr_amd.data import REDSDeviceLoader, VideoTestClips
     from edvr_amd.optim import (CosineAnnealingRestartLR, load_network, make_optimizer, resume_training, save_network,
                                 save_training_state, tsa_freeze_schedule)
+    if getattr(args, "no_f4", False):  # forward / data-gradient convs on F(2x2) / direct kernels only (~2e-7 instead of ~1e-6 relative rounding, slower)
+        from edvr_amd import ops
+        ops.set_f4(training=False)
     rank, world = D.get_dist_info() if torch.distributed.is_initialized() else D.init_dist()
     device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)))
     torch.cuda.set_device(device)
@@ -111,6 +114,7 @@ def main():
     ap.add_argument('--val-gt')
     ap.add_argument('--val-lq')
     ap.add_argument('--val-partition', default='REDS4')
+    ap.add_argument('--no-f4', action='store_true', help='keep the F(4x4,3x3) Winograd kernel out of the training path (edvr_amd.ops.set_f4)')
     ap.add_argument('--num-feat', type=int, default=128)              # EDVR-L (options/train/EDVR/train_EDVR_L_x4_SR_REDS_*.yml)
     ap.add_argument('--num-reconstruct-block', type=int, default=40)
     ap.add_argument('--num-frame', type=int, default=5)
