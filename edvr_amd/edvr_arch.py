@@ -200,6 +200,7 @@ class EDVR(nn.Module):
         self.taps = None  # set to a dict to collect intermediates (parity tests)
         self._pending_offset_stats = []  # (pinned host tensor, copy-done event, per-layer records) of earlier no-grad forwards
         self._conv_weights = None         # conv weight Parameters (collected at the first training forward)
+        self._captured_offset_stats = None
 
     def forward(self, x):
         b, t, c, h, w = x.shape
@@ -267,6 +268,9 @@ class EDVR(nn.Module):
         import torch
         sums = torch.stack([e[0] for e in sink]).view(len(sink), b, t).sum(1)  # (layers, t), on the device
         recs = [(per_img * b, module) for _, per_img, module in sink]
+        if torch.cuda.is_current_stream_capturing():  # hipGraph capture (edvr_amd/graphs.py): the sums are outputs of the graph,
+            self._captured_offset_stats = (sums, recs)  # read back on demand by GraphedEDVR.check_offsets
+            return
         if torch.is_grad_enabled():
             self._examine_offsets(sums.cpu(), recs)
             return
