@@ -526,6 +526,8 @@ def main():
                                        else f'clip-sharded x{world}, no data-path collective'),
                        'world_size': world, 'backend': 'RCCL (torch.distributed nccl)' if world > 1 else 'single process'},
         }
+        from edvr_amd.build import source_hash
+        result['csrc_sha16'] = source_hash()  # the kernel sources this line was measured on (ties profiles/*.json to the tree)
         if args.mode == 'train':
             result['iters_per_sec'] = round(args.steps / elapsed, 4)
             result['optimizer'] = ('edvr_amd.optim.FusedAdam (one HIP launch for all tensors; arithmetic of torch.optim.Adam)'
