@@ -365,7 +365,7 @@ int edvr_conv2d_wgrad_f32(const float *x1, const float *x2, const float *dz, flo
                                    dz_img_stride, wsplits, dbias != nullptr, stream);
     if (rc) return rc;
     const int64_t total = (int64_t)co * ci * 9;  // the bias gradient rides on the same two launches (its partials follow dW's)
-    return reduce_partials_launch(a.ws, dw, total, 2 * wsplits, accumulate, stream, dbias ? a.ws + 2 * wsplits * total : nullptr, dbias, co,
+    return reduce_partials_launch(a.ws, dw, total, wsplits, accumulate, stream, dbias ? a.ws + (int64_t)wsplits * total : nullptr, dbias, co,
                                   wsplits);
   }
   dim3 grid(cdiv(ci, 32 * (4 / mw)), cdiv(co, 32 * mw), a.splits);

@@ -13,7 +13,8 @@
 // 64 co x 64 ci block), ph = transform rows {2ph, 2ph+1} = 8 accumulator tiles; per chunk of 8 tiles (one k-chunk) the Z
 // and V slabs are staged in LDS (double-buffered, 132 KB) by a rotating-register pipeline; all global reads are buffer
 // loads whose hardware range check supplies the zero padding.  The tile axis is split over workgroups (deterministic
-// split-K); each wave writes the G-transformed partial of its two rows, wgrad_reduce_kernel sums 2 * splits partials.
+// split-K); the two ph waves of a quadrant combine their rows through LDS, one G-transformed partial per split is written and
+// wgrad_reduce_kernel sums `splits` of them.
 #include <cstdlib>
 #include <type_traits>
 
@@ -26,7 +27,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct WinoWgradArgs {
   const float *x1, *x2, *dz;
-  float *ws;  // [2 * splits][co][ci][9], then (want_db) [splits][co] bias-gradient partials
+  float *ws;  // [splits][co][ci][9], then (want_db) [splits][co] bias-gradient partials
   int want_db;
   int c1, c2, n, h, w, co;
   int64_t x1_img_stride, x2_img_stride, dz_img_stride;
@@ -278,33 +279,53 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
     s += __shfl_xor(s, 4, 64);
-    if (t == 0 && valid_co) (a.ws + (int64_t)2 * a.splits * a.co * ci_total * 9)[(int64_t)split * a.co + co_s] = s;
+    if (t == 0 && valid_co) (a.ws + (int64_t)a.splits * a.co * ci_total * 9)[(int64_t)split * a.co + co_s] = s;
   }
 
-  // ---- epilogue: this wave's share of dW = G^T dU G.  Row pass t[rr][jx] = (dU G)[2 ph + rr][jx], then the two rows
-  //      weighted by G[2 ph + rr][i]; the sibling wave's rows and the other splits are added by wgrad_reduce_kernel.
-  //      G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
-  const float g0[3] = {ph ? 0.5f : 1.f, ph ? -0.5f : 0.f, ph ? 0.5f : 0.f};  // G[2 ph][.]
-  const float g1[3] = {ph ? 0.f : 0.5f, ph ? 0.f : 0.5f, ph ? 1.f : 0.5f};   // G[2 ph + 1][.]
-  float *out = a.ws + (int64_t)(2 * split + ph) * a.co * ci_total * 9;
+  // ---- epilogue: dW = G^T dU G of this split.  Row pass t[rr][jx] = (dU G)[2 ph + rr][jx] in every wave; the ph = 1
+  //      wave of a quadrant hands its two rows to its ph = 0 sibling through LDS (the slabs are dead after the last
+  //      barrier: 4 waves x 64 lanes x 96 floats = 96 KB, lane-contiguous so the exchange is conflict-free), and the
+  //      ph = 0 wave applies G^T over all four rows and writes ONE partial per split; wgrad_reduce_kernel sums `splits`
+  //      of them.  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+  float tr[16][2][3];
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const float u0 = acc[rr * 4 + 0][r], u1 = acc[rr * 4 + 1][r], u2 = acc[rr * 4 + 2][r], u3 = acc[rr * 4 + 3][r];
+      tr[r][rr][0] = u0 + 0.5f * (u1 + u2);
+      tr[r][rr][1] = 0.5f * (u1 - u2);
+      tr[r][rr][2] = 0.5f * (u1 + u2) + u3;
+    }
+  float *xch = smem + quad * (96 * 64) + lane;  // [quad][r * 6 + rr * 3 + jx][lane]
+  if (ph) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int q = 0; q < 6; ++q) xch[(r * 6 + q) * 64] = tr[r][q / 3][q % 3];
+  }
+  __syncthreads();
+  if (ph) return;
+  float *out = a.ws + (int64_t)split * a.co * ci_total * 9;
   const int ci_o = ci_blk + wn * 32 + j;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int co_o = co_blk + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-    float tr[2][3];
+    float t2[3], t3[3];
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      const float u0 = acc[rr * 4 + 0][r], u1 = acc[rr * 4 + 1][r], u2 = acc[rr * 4 + 2][r], u3 = acc[rr * 4 + 3][r];
-      tr[rr][0] = u0 + 0.5f * (u1 + u2);
-      tr[rr][1] = 0.5f * (u1 - u2);
-      tr[rr][2] = 0.5f * (u1 + u2) + u3;
+    for (int jx = 0; jx < 3; ++jx) {
+      t2[jx] = xch[(r * 6 + jx) * 64];
+      t3[jx] = xch[(r * 6 + 3 + jx) * 64];
     }
     if (co_o < a.co && ci_o < ci_total) {
       float *dst = out + ((int64_t)co_o * ci_total + ci_o) * 9;
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int jx = 0; jx < 3; ++jx) dst[i * 3 + jx] = g0[i] * tr[0][jx] + g1[i] * tr[1][jx];
+      for (int jx = 0; jx < 3; ++jx) {
+        const float m = 0.5f * (tr[r][1][jx] + t2[jx]), d = 0.5f * (tr[r][1][jx] - t2[jx]);
+        dst[0 + jx] = tr[r][0][jx] + m;
+        dst[3 + jx] = d;
+        dst[6 + jx] = m + t3[jx];
+      }
     }
   }
 }
@@ -350,7 +371,7 @@ bool winograd_wgrad_plan(int n, int c1, int c2, int h, int w, int co, int ks, in
 }
 
 size_t winograd_wgrad_ws_bytes(int co, int ci, int splits) {
-  return ((size_t)2 * splits * co * ci * 9 + (size_t)splits * co) * sizeof(float);  // dW partial pairs + bias-gradient partials
+  return ((size_t)splits * co * ci * 9 + (size_t)splits * co) * sizeof(float);  // dW partials + bias-gradient partials
 }
 
 int winograd_wgrad_launch(const float *x1, const float *x2, const float *dz, float *ws, int c1, int c2, int n, int h, int w, int co,
