@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libedvr_amd.so')
 OBJDIR = os.path.join(HERE, 'build')
-SOURCES = ['api.hip', 'pack.hip', 'conv2d.hip', 'dcn.hip', 'dcn_any.hip', 'elementwise.hip', 'wgrad.hip', 'backward.hip', 'dcn_fused.hip', 'winograd.hip', 'winograd_f4.hip', 'winograd_wgrad.hip', 'optim.hip', 'metrics.hip', 'conv_small.hip', 'conv1x1.hip', 'data.hip']
+SOURCES = ['api.hip', 'pack.hip', 'conv2d.hip', 'dcn.hip', 'dcn_any.hip', 'elementwise.hip', 'wgrad.hip', 'backward.hip', 'dcn_fused.hip', 'dcn_bwd_fused.hip', 'winograd.hip', 'winograd_f4.hip', 'winograd_wgrad.hip', 'optim.hip', 'metrics.hip', 'conv_small.hip', 'conv1x1.hip', 'data.hip']
 LINK = []  # no library dependencies beyond the HIP runtime: every kernel of the path is in csrc/
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-ffp-contract=fast']
 
@@ -29,7 +29,7 @@ def _hipcc():
 
 
 def _deps():
-    return [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'pack.h'), os.path.join(HERE, '..', 'include', 'edvr_amd.h')]
+    return [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'pack.h'), os.path.join(CSRC, 'dcn_tap.h'), os.path.join(HERE, '..', 'include', 'edvr_amd.h')]
 
 
 def _stale(target, sources):

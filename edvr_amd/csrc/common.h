@@ -94,6 +94,12 @@ int dcn_fused_pack(const float *weight, float *wpk, int Co, int C, hipStream_t s
 int dcn_fused_forward(const float *x, const float *offset, const float *mask, const float *wpk, const float *bias, float *y, int B, int C,
                       int H, int W, int Co, int dg, int64_t off_bs, int64_t msk_bs, int act, int halo, hipStream_t stream);
 
+// dcn_bwd_fused.hip: DCNv2 backward (dX, dOffset, dMask, forward columns) for the EDVR signature without the dcol buffer
+bool dcn_bwd_fused_supported(const DcnShape &s);
+size_t dcn_bwd_fused_wbk_elems(int dg);  // floats of the re-ordered W^T the kernel streams (workspace)
+int dcn_bwd_fused_launch(const DcnShape &s, const float *x, const float *offset, const float *mask, const float *weight, const float *dy,
+                         float *wbk, float *col, float *dx, float *doffset, float *dmask, hipStream_t stream);
+
 // XCD-aware workgroup order.  The dispatcher deals consecutive workgroups round-robin to the 8 XCDs (workgroup L runs on
 // XCD L % 8), each with its own 4 MB L2, so spatially adjacent tiles - which share 128-byte lines and halo rows - land on
 // eight different L2s and each re-fetches the shared lines from the fabric.  xcd_remap gives XCD x one contiguous range of

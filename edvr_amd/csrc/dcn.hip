@@ -31,6 +31,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "dcn_tap.h"
 
 namespace edvr {
 
@@ -39,49 +40,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __global__ void fill_kernel(float *__restrict__ p, float v, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
 }
-
-struct Tap {
-  float w00, w01, w10, w11;  // bilinear corner weights, 0 where the corner is outside the image
-  int o00, o01, o10, o11;    // clamped element offsets inside one channel plane
-  float lh, lw;
-  bool ok00, ok01, ok10, ok11;  // corner inside the image AND tap valid
-  int h0, w0;                   // unclamped integer coordinates of corner 00
-};
-
-__device__ __forceinline__ Tap resolve_tap(float h, float w, int H, int W) {
-  Tap t;
-  const bool valid = (h > -1.f) && (w > -1.f) && (h < (float)H) && (w < (float)W);
-  const float fh = floorf(h), fw = floorf(w);
-  const int h0 = (int)fh, w0 = (int)fw, h1 = h0 + 1, w1 = w0 + 1;
-  t.h0 = h0;
-  t.w0 = w0;
-  t.lh = h - fh;
-  t.lw = w - fw;
-  const float hh = 1.f - t.lh, hw = 1.f - t.lw;
-  const bool r0 = valid && h0 >= 0, r1 = valid && h1 <= H - 1;
-  const bool c0 = w0 >= 0, c1 = w1 <= W - 1;
-  t.ok00 = r0 && c0;
-  t.ok01 = r0 && c1;
-  t.ok10 = r1 && c0;
-  t.ok11 = r1 && c1;
-  t.w00 = t.ok00 ? hh * hw : 0.f;
-  t.w01 = t.ok01 ? hh * t.lw : 0.f;
-  t.w10 = t.ok10 ? t.lh * hw : 0.f;
-  t.w11 = t.ok11 ? t.lh * t.lw : 0.f;
-  const int ch0 = min(max(h0, 0), H - 1), ch1 = min(max(h1, 0), H - 1);
-  const int cw0 = min(max(w0, 0), W - 1), cw1 = min(max(w1, 0), W - 1);
-  t.o00 = ch0 * W + cw0;
-  t.o01 = ch0 * W + cw1;
-  t.o10 = ch1 * W + cw0;
-  t.o11 = ch1 * W + cw1;
-  return t;
-}
-
-// Neighbour exchange inside a wave (DPP wave shifts, no LDS): lane i reads lane i+1 / lane i-1; lanes without a neighbour get 0.
-__device__ __forceinline__ int lane_next_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false); }
-__device__ __forceinline__ int lane_prev_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
-__device__ __forceinline__ float lane_prev_f(float v) { return __int_as_float(lane_prev_i(__float_as_int(v))); }
-__device__ __forceinline__ float lane_next_f(float v) { return __int_as_float(lane_next_i(__float_as_int(v))); }
 
 // In a smooth offset field the right-hand corners (01, 11) of pixel p are the left-hand corners (00, 10) of pixel p+1,
 // i.e. of the next lane.  merge_right() decides, once per (pixel, tap), whether this lane hands its 01 / 11 contributions
@@ -715,7 +673,7 @@ static BwdWs bwd_ws(const DcnShape &s) {
   w.col = 0;
   size_t off = align_up((size_t)s.B * s.C * K * P * 4, 256);
   w.wpk = off;
-  off += align_up(edvr_conv2d_packed_weight_elems((int)(cig * K), cog, 1) * 4 * s.groups, 256);
+  off += align_up(std::max(edvr_conv2d_packed_weight_elems((int)(cig * K), cog, 1) * s.groups, dcn_bwd_fused_wbk_elems(s.dg)) * 4, 256);
   w.gemm = off;
   off += align_up(std::max(gemm_nt_ws_elems_b(cog, (int)(cig * K), (int64_t)P, s.B), (size_t)s.B * s.Co * cig * K) * 4, 256);
   w.total = off;
@@ -818,58 +776,69 @@ int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, c
   float *wpk = reinterpret_cast<float *>(static_cast<char *>(ws) + wsz.wpk);
   float *gws = reinterpret_cast<float *>(static_cast<char *>(ws) + wsz.gemm);
   const int cig = C / groups, cog = Co / groups;
-  // 1. dcol[b, g] (cig*K x P) = W[g]^T (cig*K x cog) dY[b, g] (cog x P): a 1x1 convolution of dY with cog -> cig*K channels, on the
-  //    streaming-GEMM kernel of conv1x1.hip (B operand = dY straight from global memory, W slab in LDS)
-  const size_t wpk_g = edvr_conv2d_packed_weight_elems(cig * K, cog, 1);
-  for (int g = 0; g < groups; ++g) {
-    const float *wg = weight + (size_t)g * cog * cig * K;
-    const float *wuse = wg;
-    if ((cog % 32) != 0 || ((cig * K) % 32) != 0) {  // W (cog x cig*K, row-major) is already the packed layout when aligned
-      rc = edvr_conv2d_pack_weight_f32(wg, wpk + g * wpk_g, cig * K, cog, 1, 1, stream_);
-      if (rc) return rc;
-      wuse = wpk + g * wpk_g;
+  if (scatter_hint == EDVR_DCN_SCATTER_STRIP && dcn_bwd_fused_supported(s)) {
+    // 1 + 2 in one kernel: the dcol slice of a (group, tap pair) is consumed in the registers the matrix core left it in.  Its dX
+    // route is built for sub-pixel offsets, the same layers the strip hint marks (6.4 vs 8.6 ms at sigma 0.3, 13.2 vs 16.6 at 0.5)
+    if (hipMemsetAsync(dx, 0, (size_t)B * C * H * W * sizeof(float), stream) != hipSuccess) {
+      set_error("dcnv2_bwd: hipMemsetAsync failed");
+      return EDVR_ERR_LAUNCH;
     }
-    edvr_conv2d_desc d = {};
-    d.x1 = dy + (int64_t)g * cog * P;
-    d.c1 = cog;
-    d.x1_img_stride = (int64_t)Co * P;
-    d.n = B; d.h = s.Ho; d.w = s.Wo;
-    d.wpk = wuse;
-    d.co = cig * K; d.ks = 1; d.stride = 1;
-    d.y = col + (int64_t)g * cig * K * P;
-    d.y_img_stride = (int64_t)C * K * P;
-    rc = conv2d_launch(d, stream);
+    rc = dcn_bwd_fused_launch(s, x, offset, mask, weight, dy, wpk, col, dx, doffset, dmask, stream);
+    if (rc) return rc;
+  } else {
+    // 1. dcol[b, g] (cig*K x P) = W[g]^T (cig*K x cog) dY[b, g] (cog x P): a 1x1 convolution of dY with cog -> cig*K channels, on the
+    //    streaming-GEMM kernel of conv1x1.hip (B operand = dY straight from global memory, W slab in LDS)
+    const size_t wpk_g = edvr_conv2d_packed_weight_elems(cig * K, cog, 1);
+    for (int g = 0; g < groups; ++g) {
+      const float *wg = weight + (size_t)g * cog * cig * K;
+      const float *wuse = wg;
+      if ((cog % 32) != 0 || ((cig * K) % 32) != 0) {  // W (cog x cig*K, row-major) is already the packed layout when aligned
+        rc = edvr_conv2d_pack_weight_f32(wg, wpk + g * wpk_g, cig * K, cog, 1, 1, stream_);
+        if (rc) return rc;
+        wuse = wpk + g * wpk_g;
+      }
+      edvr_conv2d_desc d = {};
+      d.x1 = dy + (int64_t)g * cog * P;
+      d.c1 = cog;
+      d.x1_img_stride = (int64_t)Co * P;
+      d.n = B; d.h = s.Ho; d.w = s.Wo;
+      d.wpk = wuse;
+      d.co = cig * K; d.ks = 1; d.stride = 1;
+      d.y = col + (int64_t)g * cig * K * P;
+      d.y_img_stride = (int64_t)C * K * P;
+      rc = conv2d_launch(d, stream);
+      if (rc) return rc;
+    }
+    // 2. dOffset, dMask, dX (+ forward columns in place)
+    if (hipMemsetAsync(dx, 0, (size_t)B * C * H * W * sizeof(float), stream) != hipSuccess) {
+      set_error("dcnv2_bwd: hipMemsetAsync failed");
+      return EDVR_ERR_LAUNCH;
+    }
+    static const bool use_tile = []() {
+      const char *e = getenv("EDVR_DCN_BWD_TILE");  // "0": never use the LDS-window kernel (A/B)
+      return !(e && e[0] == '0');
+    }();
+    const bool edvr_sig = kh == 3 && kw == 3 && s.stride == 1 && s.pad == 1 && s.dil == 1 && s.stride_w == 1 && s.pad_w == 1 && s.dil_w == 1;
+    if (scatter_hint == EDVR_DCN_SCATTER_STRIP && edvr_sig && dg * cdiv(W, 64) <= 65535) {
+      // dX by the register-ring kernel (reads dcol before the next kernel rewrites it), then dOffset / dMask / columns without dX
+      hipLaunchKernelGGL(dcn_bwd_dx_strip_kernel, dim3(dg * cdiv(W, 64), B), dim3(256), 0, stream, offset, mask, col, dx, s);
+      const int64_t total = (int64_t)B * dg * K * P;
+      hipLaunchKernelGGL(dcn_bwd_coord_kernel<false>, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 1 << 20)), dim3(256), 0, stream,
+                         x, offset, mask, col, static_cast<float *>(nullptr), doffset, dmask, s);
+      rc = check_launch("dcn_bwd_dx_strip_kernel + dcn_bwd_coord_kernel");
+    } else if (use_tile && scatter_hint != EDVR_DCN_SCATTER_DEVICE && scatter_hint != EDVR_DCN_SCATTER_STRIP && edvr_sig && C / dg <= 16) {
+      const int tiles_x = cdiv(s.Wo, 32), tiles_y = cdiv(s.Ho, 8);
+      hipLaunchKernelGGL((dcn_bwd_coord_tile_kernel<3>), dim3(tiles_x * tiles_y, dg, B), dim3(256), 0, stream, x, offset, mask, col, dx,
+                         doffset, dmask, s, tiles_x);
+      rc = check_launch("dcn_bwd_coord_tile_kernel");
+    } else {
+      const int64_t total = (int64_t)B * dg * K * P;
+      hipLaunchKernelGGL(dcn_bwd_coord_kernel<true>, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 1 << 20)), dim3(256), 0, stream, x,
+                         offset, mask, col, dx, doffset, dmask, s);
+      rc = check_launch("dcn_bwd_coord_kernel");
+    }
     if (rc) return rc;
   }
-  // 2. dOffset, dMask, dX (+ forward columns in place)
-  if (hipMemsetAsync(dx, 0, (size_t)B * C * H * W * sizeof(float), stream) != hipSuccess) {
-    set_error("dcnv2_bwd: hipMemsetAsync failed");
-    return EDVR_ERR_LAUNCH;
-  }
-  static const bool use_tile = []() {
-    const char *e = getenv("EDVR_DCN_BWD_TILE");  // "0": never use the LDS-window kernel (A/B)
-    return !(e && e[0] == '0');
-  }();
-  const bool edvr_sig = kh == 3 && kw == 3 && s.stride == 1 && s.pad == 1 && s.dil == 1 && s.stride_w == 1 && s.pad_w == 1 && s.dil_w == 1;
-  if (scatter_hint == EDVR_DCN_SCATTER_STRIP && edvr_sig && dg * cdiv(W, 64) <= 65535) {
-    // dX by the register-ring kernel (reads dcol before the next kernel rewrites it), then dOffset / dMask / columns without dX
-    hipLaunchKernelGGL(dcn_bwd_dx_strip_kernel, dim3(dg * cdiv(W, 64), B), dim3(256), 0, stream, offset, mask, col, dx, s);
-    const int64_t total = (int64_t)B * dg * K * P;
-    hipLaunchKernelGGL(dcn_bwd_coord_kernel<false>, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 1 << 20)), dim3(256), 0, stream,
-                       x, offset, mask, col, static_cast<float *>(nullptr), doffset, dmask, s);
-    rc = check_launch("dcn_bwd_dx_strip_kernel + dcn_bwd_coord_kernel");
-  } else if (use_tile && scatter_hint != EDVR_DCN_SCATTER_DEVICE && scatter_hint != EDVR_DCN_SCATTER_STRIP && edvr_sig && C / dg <= 16) {
-    const int tiles_x = cdiv(s.Wo, 32), tiles_y = cdiv(s.Ho, 8);
-    hipLaunchKernelGGL((dcn_bwd_coord_tile_kernel<3>), dim3(tiles_x * tiles_y, dg, B), dim3(256), 0, stream, x, offset, mask, col, dx,
-                       doffset, dmask, s, tiles_x);
-    rc = check_launch("dcn_bwd_coord_tile_kernel");
-  } else {
-    const int64_t total = (int64_t)B * dg * K * P;
-    hipLaunchKernelGGL(dcn_bwd_coord_kernel<true>, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 1 << 20)), dim3(256), 0, stream, x,
-                       offset, mask, col, dx, doffset, dmask, s);
-    rc = check_launch("dcn_bwd_coord_kernel");
-  }
-  if (rc) return rc;
   // 3. dW[g] = sum_{b,p} dY[b, g] col[b, g]^T ; db = sum dY
   for (int g = 0; g < groups; ++g) {
     rc = gemm_nt_batched(dy + (int64_t)g * cog * P, col + (int64_t)g * cig * K * P, dweight + (size_t)g * cog * cig * K, cog, cig * K, P,

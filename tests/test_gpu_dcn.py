@@ -46,6 +46,13 @@ CASES = [
     (1, 16, 1, 5, 16, 3, 1, 1, 1, 1, 4, 0.6, {}),                   # one row
     (1, 32, 12, 150, 32, 3, 1, 1, 1, 1, 8, 0.4, {}),                # wider than a wave: three 64-column strips, ragged last one
     (1, 16, 6, 128, 16, 3, 1, 1, 1, 1, 4, 1.2, {}),                 # two full strips, many taps outside the sub-pixel window
+    # 16 channels per deformable group, Co <= 128: the backward without the dcol buffer (dcn_bwd_fused.hip) for 'lds' / 'strip'
+    (2, 128, 17, 45, 128, 3, 1, 1, 1, 1, 8, 5.0, {}),               # ragged tiles, many cells beyond the LDS window (slow path)
+    (1, 128, 9, 33, 63, 3, 1, 1, 1, 1, 8, 0.7, {}),                 # odd output-channel count (zero rows of the dY tile)
+    (1, 128, 12, 12, 64, 3, 1, 1, 1, 1, 8, 2.0, {'integer': True}),
+    (1, 128, 12, 12, 64, 3, 1, 1, 1, 1, 8, 2.0, {'half': True}),
+    (1, 128, 12, 16, 64, 3, 1, 1, 1, 1, 8, 16.0, {}),               # mostly out of bounds
+    (3, 32, 16, 40, 32, 3, 1, 1, 1, 1, 2, 1.0, {}),                 # two groups, three images
 ]
 
 
