@@ -65,6 +65,10 @@ __global__ void dcn_bwd_fused_pack_kernel(const float *__restrict__ w, float *__
 __global__ __launch_bounds__(512) void dcn_bwd_fused_kernel(const DcnBwdFusedArgs a) {
   constexpr int TH = BF_TH, TW = BF_TW, IH = BF_IH, IW = BF_IW, CHS = BF_CHS, CPG = BF_CPG, NS = BF_NS, LS = BF_LS, SLAB = BF_SLAB;
   constexpr int PC = BF_PC, PCH = BF_PCH, PW = BF_PW;
+#ifndef BF_CG
+#define BF_CG 2
+#endif
+  constexpr int CG = BF_CG;  // channels whose accumulator updates share one LDS round trip per column pass (2: 6.23 ms, 4: 6.37, 8: 6.98 - registers)
   constexpr int RSRC_FLAGS = 0x00020000;
   constexpr int OOB = (int)0x80000000;
   typedef __attribute__((address_space(3))) void lvoid;
@@ -111,15 +115,19 @@ __global__ __launch_bounds__(512) void dcn_bwd_fused_kernel(const DcnBwdFusedArg
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
   };
 
-  // ---- dY tile of this wave's pixel row, register-resident: dyr[s] = dY[co = 2 s + half][pixel j] (the MFMA B operand of k-step s);
-  //      rows past Co fall outside the resource and read 0
+  // ---- dY tile of this wave's pixel row: dyr[s] = dY[co = 2 s + half][pixel j] (the MFMA B operand of k-step s); rows past Co fall
+  //      outside the resource and read 0.  BF_DY_STREAM: re-read (L2) at the top of every step instead of register-resident, so
+  //      that the consumer phase has the 64 registers for its own loads in flight.
+  const __amdgpu_buffer_rsrc_t dy_rsrc = rsrc_of(a.dy + (int64_t)img * a.Co * P, a.Co * P * 4);
+  const int dy_voff = pix_ok ? (half * P + p) * 4 : OOB;
   float dyr[NS];
-  {
-    const __amdgpu_buffer_rsrc_t dy_rsrc = rsrc_of(a.dy + (int64_t)img * a.Co * P, a.Co * P * 4);
-    const int voff = pix_ok ? (half * P + p) * 4 : OOB;
+  auto load_dy = [&]() {
 #pragma unroll
-    for (int s = 0; s < NS; ++s) dyr[s] = bload(dy_rsrc, voff, 2 * s * P * 4);
-  }
+    for (int s = 0; s < NS; ++s) dyr[s] = bload(dy_rsrc, dy_voff, 2 * s * P * 4);
+  };
+#ifndef BF_DY_STREAM
+  load_dy();
+#endif
 
   // ---- x window of one deformable group -> LDS (as dcn_fused.hip: positions outside the image fail the range check -> 0)
   constexpr int NXK = (CHS + 511) / 512;
@@ -165,8 +173,6 @@ __global__ __launch_bounds__(512) void dcn_bwd_fused_kernel(const DcnBwdFusedArg
     fw = bload(off_rsrc, v2, (g * 18 + 1) * P * 4);
     fm = bload(msk_rsrc, v1, g * 9 * P * 4);
   };
-  float o_h, o_w, o_m;
-  fetch_tap(0, 0, o_h, o_w, o_m);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // slab 0 (this wave's pieces) before the first barrier
 
   const int n_steps = a.dg * BF_TP;
@@ -176,13 +182,16 @@ __global__ __launch_bounds__(512) void dcn_bwd_fused_kernel(const DcnBwdFusedArg
   auto step = [&](auto TPC, int g) {
     constexpr int TP = decltype(TPC)::value;
     const int i = g * BF_TP + TP;
+#ifdef BF_DY_STREAM
+    load_dy();
+#endif
     // LDS-only barrier: slab i is in LDS (every wave waited for its own pieces after the MFMAs of the step before), nobody reads
     // slab i - 1 or updates accumulator rows of the step before any more
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const float *slab = wsl + (i & 1) * SLAB;
     if (i + 1 < n_steps) dma_w(wsl + ((i + 1) & 1) * SLAB, i + 1);
-    float n_h = 0.f, n_w = 0.f, n_m = 0.f;
-    if (i + 1 < n_steps) fetch_tap(TP == BF_TP - 1 ? g + 1 : g, TP == BF_TP - 1 ? 0 : TP + 1, n_h, n_w, n_m);
+    float o_h, o_w, o_m;  // offsets / mask of the lane's tap: requested here, landed by the end of the MFMAs
+    fetch_tap(g, TP, o_h, o_w, o_m);
 
     // ---- 1. dcol rows of (g, the two taps of the step) for this wave's 32 pixels: 64 k-steps over the output channels
     f32x16 acc;
@@ -249,14 +258,14 @@ __global__ __launch_bounds__(512) void dcn_bwd_fused_kernel(const DcnBwdFusedArg
 #ifdef BF_EXP_NOCONS /* ablation (wrong results): the consumer of the accumulators is skipped */
     for (int r = 0; r < 16; ++r) s_m += acc[r];
 #pragma unroll
-    for (int c4 = 0; c4 < 0; c4 += 4) {
+    for (int c4 = 0; c4 < 0; c4 += CG) {
 #else
 #pragma unroll
-    for (int c4 = 0; c4 < CPG; c4 += 4) {
+    for (int c4 = 0; c4 < CPG; c4 += CG) {
 #endif
-      float tt[4];
+      float tt[CG];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < CG; ++u) {
         const int c = c4 + u;
         const float *cell = xs + c * CHS + xaddr;
         const float a00 = cell[0], a01 = cell[1], a10 = cell[IW], a11 = cell[IW + 1];
@@ -272,23 +281,23 @@ __global__ __launch_bounds__(512) void dcn_bwd_fused_kernel(const DcnBwdFusedArg
       }
 #ifndef BF_EXP_NOSCAT /* ablation (wrong dX): no accumulator updates */
       if constexpr (TP < 3) {
-        float r0[4], r1[4], gift[4];
+        float r0[CG], r1[CG], gift[CG];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < CG; ++u) {
           r0[u] = tt[u] * wk0;
           r1[u] = tt[u] * wk1;
           gift[u] = __shfl_xor(tt[u] * wgift, 32, 64);
         }
 #pragma unroll
         for (int b = 0; b < 3; ++b) {  // column passes: separate instructions, in order (neighbouring lanes overlap across passes)
-          float o0[4], o1[4];
+          float o0[CG], o1[CG];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < CG; ++u) {
             o0[u] = pk0[(c4 + u) * PCH + b];
             o1[u] = pk1[(c4 + u) * PCH + b];
           }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < CG; ++u) {
             pk0[(c4 + u) * PCH + b] = o0[u] + r0[u] * cx[b];
             pk1[(c4 + u) * PCH + b] = o1[u] + r1[u] * cx[b] + gift[u] * pcx[b];
           }
@@ -303,13 +312,13 @@ __global__ __launch_bounds__(512) void dcn_bwd_fused_kernel(const DcnBwdFusedArg
           if (half == hs) {
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
-              float o[4][3];
+              float o[CG][3];
 #pragma unroll
-              for (int u = 0; u < 4; ++u)
+              for (int u = 0; u < CG; ++u)
 #pragma unroll
                 for (int r = 0; r < 3; ++r) o[u][r] = pun[(c4 + u) * PCH + r * PC + b];
 #pragma unroll
-              for (int u = 0; u < 4; ++u) {
+              for (int u = 0; u < CG; ++u) {
                 const float tc = tt[u] * cx[b];
                 pun[(c4 + u) * PCH + 0 * PC + b] = o[u][0] + tc * rym;
                 pun[(c4 + u) * PCH + 1 * PC + b] = o[u][1] + tc * ry0;
@@ -323,6 +332,7 @@ __global__ __launch_bounds__(512) void dcn_bwd_fused_kernel(const DcnBwdFusedArg
       }
 #endif
     }
+#ifndef BF_EXP_NOSLOW /* ablation (wrong results beyond sub-pixel offsets): no cold paths */
     if (__any(mid)) {  // inside the window but not sub-pixel: dX by device atomics (four per channel, nothing waits for them)
       if (mid) {
         const bool r0 = fhi >= 0, r1 = fhi + 1 <= a.H - 1, c0 = fwi >= 0, c1 = fwi + 1 <= a.W - 1;  // corners inside the image (.cu:481-491)
@@ -366,10 +376,10 @@ __global__ __launch_bounds__(512) void dcn_bwd_fused_kernel(const DcnBwdFusedArg
         }
       }
     }
+#endif
     bstore(s_m, dmsk_rsrc, v1, g * 9 * P * 4);
     bstore(s_y * o_m, doff_rsrc, v2, g * 18 * P * 4);
     bstore(s_x * o_m, doff_rsrc, v2, (g * 18 + 1) * P * 4);
-    o_h = n_h; o_w = n_w; o_m = n_m;
   };
 
   for (int g = 0; g < a.dg; ++g) {
