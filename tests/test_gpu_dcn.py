@@ -123,6 +123,42 @@ def test_autograd_function_and_strided_offset_views(gpu):
         assert _rel(a.grad, r.grad) < BWD_RTOL
 
 
+@pytest.mark.parametrize('sigma', [0.3, 1.5])
+def test_backward_without_dcol_buffer_writes_strided_gradient_slices(gpu, sigma):
+    """The training path's call: offsets / masks are channel slices of conv_offset's output, d(offset) / d(mask) are written into
+    slices of ONE gradient buffer (image strides != plane count x plane size), scatter hint STRIP -> csrc/dcn_bwd_fused.hip
+    (16 channels per deformable group).  Against the CPU oracle and against the staged path (hint DEVICE) on the same inputs."""
+    from edvr_amd import ops
+    from oracle import dcn_oracle as O
+    g = torch.Generator().manual_seed(11)
+    B, C, H, W = 3, 128, 19, 40
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) * 0.1
+    om = torch.randn(B, 216, H, W, generator=g) * sigma
+    om[:, 144:] = torch.sigmoid(om[:, 144:])
+    dy = torch.randn(B, C, H, W, generator=g)
+    ref = O.c_backward(x.double(), om[:, :144].double(), om[:, 144:].double(), w.double(), dy.double(), True, 1, 1, 1, 1, 8)
+    xg, omg, wg, dyg = (t.to(gpu) for t in (x, om, w, dy))
+    outs = {}
+    for name, hint in (('fused', ops.DCN_SCATTER_STRIP), ('staged', ops.DCN_SCATTER_DEVICE)):
+        dom = torch.full_like(omg, float('nan'))
+        dx, _, _, dw, db = ops.dcnv2_backward(xg, omg[:, :144], omg[:, 144:], wg, dyg, True, 1, 1, 1, 1, 8, doffset=dom[:, :144],
+                                              dmask=dom[:, 144:], scatter_hint=hint)
+        torch.cuda.synchronize()
+        assert torch.isfinite(dom).all(), 'every plane of both slices is written'
+        outs[name] = (dx, dom[:, :144], dom[:, 144:], dw, db)
+    ref32 = O.c_backward(x, om[:, :144], om[:, 144:], w, dy, True, 1, 1, 1, 1, 8)
+    for name in outs:
+        for what, a, r, r32 in zip(('dx', 'doffset', 'dmask', 'dweight', 'dbias'), outs[name], ref, ref32):
+            if what == 'doffset':  # (fp32 floor flips, as in the test above)
+                flip = (r32.double() - r).abs() > 1e-3 * r.abs().max()
+                assert flip.sum().item() <= 2
+                a, r = a.double().cpu().masked_fill(flip, 0.), r.masked_fill(flip, 0.)
+            assert _rel(a, r) < BWD_RTOL, (name, what)
+    for a, b_ in zip(outs['fused'][1:3], outs['staged'][1:3]):  # same arithmetic per (pixel, tap): no summation-order freedom
+        assert (a - b_).abs().max().item() <= 2e-5 * b_.abs().max().item()
+
+
 def test_cpu_tensor_is_refused():
     """Same behaviour as the reference op (deform_conv.py:133-134): no CPU path."""
     from edvr_amd import modulated_deform_conv
