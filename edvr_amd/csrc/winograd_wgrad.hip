@@ -24,6 +24,7 @@ namespace edvr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct WinoWgradArgs {
   const float *x1, *x2, *dz;
@@ -90,6 +91,19 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
   };
   __amdgpu_buffer_rsrc_t x_rsrc = uniform_rsrc(a.x1), z_rsrc = x_rsrc;
   bool rowok[4], colok[4], tile_ok;
+#ifndef WW_ROW128
+#define WW_ROW128 1
+#endif
+#if WW_ROW128
+  // One 16-byte load per patch row (4 instead of 12 vector-memory instructions per chunk, each touching 8-16 cache lines).  A row
+  // of the first tile of an image row starts one element LEFT of the image row - for the first row of the tensor that is outside
+  // the allocation - so these loads go through a resource that covers exactly this block's image (base = its first element,
+  // num_records = its bytes): a dword outside it is range-checked to zero without touching memory, a negative offset included
+  // (it wraps to a huge unsigned one).  The two border columns are then masked in registers.
+  __amdgpu_buffer_rsrc_t xrow_rsrc = x_rsrc;
+  int win_off = 0;  // byte offset of the chunk's window origin from the image's first element (may be negative)
+  const int x_img_bytes = (use_x2 ? a.c2 : a.c1) * hw * 4;
+#endif
   auto geometry = [&]() {  // resources and validity masks of chunk q = (img, ty, xc)
     const bool in_range = q < a.total_chunks;
     const float *xi;
@@ -100,7 +114,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
       xi = a.x1 + (int64_t)img * a.x1_img_stride;
     }
     // window origin = halo pixel (2 ty - 1, 16 xc - 1): may lie outside the image, those elements are masked below
+#if WW_ROW128
+    {
+      const uint64_t pv = reinterpret_cast<uint64_t>(xi);
+      const uint64_t pu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pv >> 32)) << 32) |
+                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pv);
+      xrow_rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(pu), (short)0, x_img_bytes, RSRC_FLAGS);
+      win_off = __builtin_amdgcn_readfirstlane(((2 * ty - 1) * a.w + 16 * xc - 1) * 4);
+    }
+#else
     x_rsrc = uniform_rsrc(xi + ((int64_t)(2 * ty - 1) * a.w + 16 * xc - 1));
+#endif
     z_rsrc = uniform_rsrc(a.dz + (int64_t)img * a.dz_img_stride + ((int64_t)2 * ty * a.w + 16 * xc));
     const int gx = 16 * xc + 2 * t - 1;
 #pragma unroll
@@ -128,6 +152,23 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
   // Column c of the patch for chunk q (the geometry() state).  Columns 1 and 2 of a row are an 8-byte aligned pair (even x,
   // even w and h), both valid or both invalid: one 64-bit load, issued once both columns have been consumed (c == 2).
   auto load_col = [&](int c) {
+#if WW_ROW128 && !defined(WW_EXP_NOLOAD)
+    // (row mode: `c` is the patch ROW - the transform below runs row-wise first, so a row is free as soon as its own pass is done)
+    // The lanes whose column 0 lies left of the image (first tile of an image row) load columns 1..4 instead and move them up one
+    // place: their offset stays >= 0 (a negative one would have to rely on how the range check wraps); at the right border and
+    // at the end of the image the per-component range check of multi-dword buffer loads returns 0 for the dwords past num_records.
+    {
+      const int r = c;
+      const bool shl = !colok[0];
+      const int off = rel[r * 4] + win_off + (shl ? 4 : 0);
+      const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrow_rsrc, (rowok[r] && colok[1]) ? off : OOB, 0, 0));
+      pr[r * 4 + 0] = shl ? 0.f : v[0];
+      pr[r * 4 + 1] = shl ? v[0] : v[1];
+      pr[r * 4 + 2] = shl ? v[1] : v[2];
+      pr[r * 4 + 3] = colok[3] ? (shl ? v[2] : v[3]) : 0.f;
+    }
+    return;
+#endif
     if (c == 1) return;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -153,15 +194,35 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
     dy[S][1] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(z_rsrc, tile_ok ? dz_rel + a.w * 4 : OOB, 0, 0));
   };
   auto transform_col = [&](int c) {
+#if WW_ROW128 && !defined(WW_EXP_NOLOAD)
+    // row mode: (d B) of patch row c first - tt[4 c + j]; commit_v_row applies B^T down the columns
+    const float d0 = pr[c * 4 + 0], d1 = pr[c * 4 + 1], d2 = pr[c * 4 + 2], d3 = pr[c * 4 + 3];
+    tt[c * 4 + 0] = d0 - d2;
+    tt[c * 4 + 1] = d1 + d2;
+    tt[c * 4 + 2] = d2 - d1;
+    tt[c * 4 + 3] = d1 - d3;
+#else
     const float d0 = pr[0 * 4 + c], d1 = pr[1 * 4 + c], d2 = pr[2 * 4 + c], d3 = pr[3 * 4 + c];
     tt[0 * 4 + c] = d0 - d2;
     tt[1 * 4 + c] = d1 + d2;
     tt[2 * 4 + c] = d2 - d1;
     tt[3 * 4 + c] = d1 - d3;
+#endif
   };
-  auto commit_v_row = [&](float *Vs, int r) {  // positions xi = 4r .. 4r+3 of (B^T d) B
-    const float *s = tt + r * 4;
+  auto commit_v_row = [&](float *Vs, int r) {  // positions xi = 4r .. 4r+3 of B^T d B
     float *dst = Vs + t * TS + (r * 4) * 64 + chl;
+#if WW_ROW128 && !defined(WW_EXP_NOLOAD)
+    // row r of B^T (d B): B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]] down the rows of tt
+    const float *ra = tt + (r == 0 ? 0 : r == 1 ? 1 : r == 2 ? 2 : 1) * 4, *rb = tt + (r == 0 ? 2 : r == 1 ? 2 : r == 2 ? 1 : 3) * 4;
+#ifdef WW_EXP_NOCOMMIT
+    if (ra[0] == 12345.f)  /* ablation only */
+#endif
+    {
+#pragma unroll
+      for (int jx = 0; jx < 4; ++jx) dst[jx * 64] = r == 1 ? ra[jx] + rb[jx] : ra[jx] - rb[jx];
+    }
+#else
+    const float *s = tt + r * 4;
 #ifdef WW_EXP_NOCOMMIT
     if (s[0] == 12345.f)  /* ablation only */
 #endif
@@ -171,6 +232,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
       dst[2 * 64] = s[2] - s[1];
       dst[3 * 64] = s[1] - s[3];
     }
+#endif
   };
   float bvalid = 1.f;  // 0 once the chunk being committed lies beyond this split's range (its dY must not be counted)
   auto commit_z_row = [&](float *Zs, auto SET, int r) {  // row r of A dY A^T, A = [[1,0],[1,1],[1,-1],[0,-1]]
