@@ -67,11 +67,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
   const int ci_s = ci_blk + chl, co_s = co_blk + chl;
   const bool valid_ci = ci_s < (use_x2 || a.c2 == 0 ? ci_total : a.c1), valid_co = co_s < a.co;
   const int ci_in = use_x2 ? ci_s - a.c1 : ci_s;
-  int rel[16];  // byte offset of patch element (r, c) of tile t from the chunk's window origin (top-left halo pixel)
+  int rel[4];  // byte offset of patch row r (its column 0) of tile t from the chunk's window origin (top-left halo pixel)
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) rel[r * 4 + c] = (ci_in * hw + r * a.w + c + 2 * t) * 4;
+  for (int r = 0; r < 4; ++r) rel[r] = (ci_in * hw + r * a.w + 2 * t) * 4;
   const int dz_rel = (co_s * hw + 2 * t) * 4;
 
   // ---- geometry of the chunk being LOADED (wave-uniform; advanced branch-free once per iteration)
@@ -89,43 +87,41 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pv);
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(pu), (short)0, 0x7fffffff, RSRC_FLAGS);
   };
-  __amdgpu_buffer_rsrc_t x_rsrc = uniform_rsrc(a.x1), z_rsrc = x_rsrc;
+  // One 16-byte load per patch row (4 vector-memory instructions per chunk, each touching 8-16 cache lines; the first version of
+  // this kernel issued b32 + b64 + b32 per row).  A row of the first tile of an image row starts one element LEFT of the image
+  // row - for the first row of the tensor that is outside the allocation - so the loads go through a resource that covers exactly
+  // this block's image (base = its first element, num_records = its bytes): a dword past its end is range-checked to zero
+  // without touching memory (multi-dword buffer loads are checked per component).  The resources change with the IMAGE only (a
+  // scalar branch once per 64 chunks on the 64 x 64 training layers); the chunk's position inside the image is a byte offset
+  // added to the lane offsets (rebuilding both resources per chunk was most of the 11 % the chunk geometry cost).
+  __amdgpu_buffer_rsrc_t xrow_rsrc = uniform_rsrc(a.x1), z_rsrc = xrow_rsrc;
   bool rowok[4], colok[4], tile_ok;
-#ifndef WW_ROW128
-#define WW_ROW128 1
-#endif
-#if WW_ROW128
-  // One 16-byte load per patch row (4 instead of 12 vector-memory instructions per chunk, each touching 8-16 cache lines).  A row
-  // of the first tile of an image row starts one element LEFT of the image row - for the first row of the tensor that is outside
-  // the allocation - so these loads go through a resource that covers exactly this block's image (base = its first element,
-  // num_records = its bytes): a dword outside it is range-checked to zero without touching memory, a negative offset included
-  // (it wraps to a huge unsigned one).  The two border columns are then masked in registers.
-  __amdgpu_buffer_rsrc_t xrow_rsrc = x_rsrc;
-  int win_off = 0;  // byte offset of the chunk's window origin from the image's first element (may be negative)
-  const int x_img_bytes = (use_x2 ? a.c2 : a.c1) * hw * 4;
-#endif
-  auto geometry = [&]() {  // resources and validity masks of chunk q = (img, ty, xc)
+  int win_off = 0;  // byte offset of the chunk's window origin (halo pixel (2 ty - 1, 16 xc - 1)) from the image's first element: may be negative
+  int z_off = 0;    // byte offset of the chunk's first dY pixel (2 ty, 16 xc) from the image's first element
+  int rsrc_img = -1;
+  const int x_img_bytes = (use_x2 ? a.c2 : a.c1) * hw * 4, z_img_bytes = a.co * hw * 4;
+  auto exact_rsrc = [&](const float *p, int bytes) {
+    const uint64_t pv = reinterpret_cast<uint64_t>(p);
+    const uint64_t pu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pv >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pv);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(pu), (short)0, bytes, RSRC_FLAGS);
+  };
+  auto geometry = [&]() {  // resources, offsets and validity masks of chunk q = (img, ty, xc)
     const bool in_range = q < a.total_chunks;
-    const float *xi;
-    if (use_x2) {
-      const int i2 = a.x2_div > 0 ? (img / a.x2_div) * a.x2_mul + a.x2_add : img;
-      xi = a.x2 + (int64_t)i2 * a.x2_img_stride;
-    } else {
-      xi = a.x1 + (int64_t)img * a.x1_img_stride;
+    if (img != rsrc_img) {  // wave-uniform
+      rsrc_img = img;
+      const float *xi;
+      if (use_x2) {
+        const int i2 = a.x2_div > 0 ? (img / a.x2_div) * a.x2_mul + a.x2_add : img;
+        xi = a.x2 + (int64_t)i2 * a.x2_img_stride;
+      } else {
+        xi = a.x1 + (int64_t)img * a.x1_img_stride;
+      }
+      xrow_rsrc = exact_rsrc(xi, x_img_bytes);
+      z_rsrc = exact_rsrc(a.dz + (int64_t)img * a.dz_img_stride, z_img_bytes);
     }
-    // window origin = halo pixel (2 ty - 1, 16 xc - 1): may lie outside the image, those elements are masked below
-#if WW_ROW128
-    {
-      const uint64_t pv = reinterpret_cast<uint64_t>(xi);
-      const uint64_t pu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pv >> 32)) << 32) |
-                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pv);
-      xrow_rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(pu), (short)0, x_img_bytes, RSRC_FLAGS);
-      win_off = __builtin_amdgcn_readfirstlane(((2 * ty - 1) * a.w + 16 * xc - 1) * 4);
-    }
-#else
-    x_rsrc = uniform_rsrc(xi + ((int64_t)(2 * ty - 1) * a.w + 16 * xc - 1));
-#endif
-    z_rsrc = uniform_rsrc(a.dz + (int64_t)img * a.dz_img_stride + ((int64_t)2 * ty * a.w + 16 * xc));
+    win_off = ((2 * ty - 1) * a.w + 16 * xc - 1) * 4;
+    z_off = (2 * ty * a.w + 16 * xc) * 4;
     const int gx = 16 * xc + 2 * t - 1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) rowok[r] = in_range && (unsigned)(2 * ty - 1 + r) < (unsigned)a.h;
@@ -151,68 +147,38 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
   float bsum = 0.f;  // bias gradient: sum of this thread's dY tiles (the values are in registers anyway)
   // Column c of the patch for chunk q (the geometry() state).  Columns 1 and 2 of a row are an 8-byte aligned pair (even x,
   // even w and h), both valid or both invalid: one 64-bit load, issued once both columns have been consumed (c == 2).
-  auto load_col = [&](int c) {
-#if WW_ROW128 && !defined(WW_EXP_NOLOAD)
-    // (row mode: `c` is the patch ROW - the transform below runs row-wise first, so a row is free as soon as its own pass is done)
-    // The lanes whose column 0 lies left of the image (first tile of an image row) load columns 1..4 instead and move them up one
-    // place: their offset stays >= 0 (a negative one would have to rely on how the range check wraps); at the right border and
-    // at the end of the image the per-component range check of multi-dword buffer loads returns 0 for the dwords past num_records.
-    {
-      const int r = c;
-      const bool shl = !colok[0];
-      const int off = rel[r * 4] + win_off + (shl ? 4 : 0);
-      const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrow_rsrc, (rowok[r] && colok[1]) ? off : OOB, 0, 0));
-      pr[r * 4 + 0] = shl ? 0.f : v[0];
-      pr[r * 4 + 1] = shl ? v[0] : v[1];
-      pr[r * 4 + 2] = shl ? v[1] : v[2];
-      pr[r * 4 + 3] = colok[3] ? (shl ? v[2] : v[3]) : 0.f;
-    }
-    return;
-#endif
-    if (c == 1) return;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
+  // Row r of the patch for chunk q (the geometry() state).  The lanes whose column 0 lies left of the image (first tile of an image
+  // row) load columns 1..4 instead and move them up one place: their offset stays >= 0 (a negative one would have to rely on how
+  // the range check wraps); at the right border and at the end of the image the dwords past num_records come back as 0.
+  auto load_row = [&](int r) {
 #ifdef WW_EXP_NOLOAD
-      if (c == 2) pr[r * 4 + 1] = (rowok[r] && colok[1]) ? 1.f : 0.f;
-      pr[r * 4 + c] = (rowok[r] && colok[c]) ? 1.f : 0.f;  /* ablation only */
+#pragma unroll
+    for (int c = 0; c < 4; ++c) pr[r * 4 + c] = (rowok[r] && colok[c]) ? 1.f : 0.f;  /* ablation only */
 #else
-      if (c == 2) {
-        const f32x2 v = __builtin_bit_cast(
-            f32x2, __builtin_amdgcn_raw_buffer_load_b64(x_rsrc, (rowok[r] && colok[1]) ? rel[r * 4 + 1] : OOB, 0, 0));
-        pr[r * 4 + 1] = v[0];
-        pr[r * 4 + 2] = v[1];
-      } else {
-        pr[r * 4 + c] = __builtin_bit_cast(
-            float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (rowok[r] && colok[c]) ? rel[r * 4 + c] : OOB, 0, 0));
-      }
+    const bool shl = !colok[0];
+    const int off = rel[r] + win_off + (shl ? 4 : 0);
+    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrow_rsrc, (rowok[r] && colok[1]) ? off : OOB, 0, 0));
+    pr[r * 4 + 0] = shl ? 0.f : v[0];
+    pr[r * 4 + 1] = shl ? v[0] : v[1];
+    pr[r * 4 + 2] = shl ? v[1] : v[2];
+    pr[r * 4 + 3] = colok[3] ? (shl ? v[2] : v[3]) : 0.f;
 #endif
-    }
   };
   auto load_dy = [&](auto SET) {
     constexpr int S = decltype(SET)::value;
-    dy[S][0] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(z_rsrc, tile_ok ? dz_rel : OOB, 0, 0));
-    dy[S][1] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(z_rsrc, tile_ok ? dz_rel + a.w * 4 : OOB, 0, 0));
+    dy[S][0] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(z_rsrc, tile_ok ? dz_rel + z_off : OOB, 0, 0));
+    dy[S][1] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(z_rsrc, tile_ok ? dz_rel + z_off + a.w * 4 : OOB, 0, 0));
   };
-  auto transform_col = [&](int c) {
-#if WW_ROW128 && !defined(WW_EXP_NOLOAD)
-    // row mode: (d B) of patch row c first - tt[4 c + j]; commit_v_row applies B^T down the columns
-    const float d0 = pr[c * 4 + 0], d1 = pr[c * 4 + 1], d2 = pr[c * 4 + 2], d3 = pr[c * 4 + 3];
-    tt[c * 4 + 0] = d0 - d2;
-    tt[c * 4 + 1] = d1 + d2;
-    tt[c * 4 + 2] = d2 - d1;
-    tt[c * 4 + 3] = d1 - d3;
-#else
-    const float d0 = pr[0 * 4 + c], d1 = pr[1 * 4 + c], d2 = pr[2 * 4 + c], d3 = pr[3 * 4 + c];
-    tt[0 * 4 + c] = d0 - d2;
-    tt[1 * 4 + c] = d1 + d2;
-    tt[2 * 4 + c] = d2 - d1;
-    tt[3 * 4 + c] = d1 - d3;
-#endif
+  auto transform_row = [&](int r) {  // (d B) of patch row r; commit_v_row applies B^T down the columns.  Row-wise first, so that a
+                                     // row's registers are free - and re-requested - right after its own pass
+    const float d0 = pr[r * 4 + 0], d1 = pr[r * 4 + 1], d2 = pr[r * 4 + 2], d3 = pr[r * 4 + 3];
+    tt[r * 4 + 0] = d0 - d2;
+    tt[r * 4 + 1] = d1 + d2;
+    tt[r * 4 + 2] = d2 - d1;
+    tt[r * 4 + 3] = d1 - d3;
   };
-  auto commit_v_row = [&](float *Vs, int r) {  // positions xi = 4r .. 4r+3 of B^T d B
+  auto commit_v_row = [&](float *Vs, int r) {  // positions xi = 4r .. 4r+3 of B^T (d B): B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]
     float *dst = Vs + t * TS + (r * 4) * 64 + chl;
-#if WW_ROW128 && !defined(WW_EXP_NOLOAD)
-    // row r of B^T (d B): B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]] down the rows of tt
     const float *ra = tt + (r == 0 ? 0 : r == 1 ? 1 : r == 2 ? 2 : 1) * 4, *rb = tt + (r == 0 ? 2 : r == 1 ? 2 : r == 2 ? 1 : 3) * 4;
 #ifdef WW_EXP_NOCOMMIT
     if (ra[0] == 12345.f)  /* ablation only */
@@ -221,18 +187,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
 #pragma unroll
       for (int jx = 0; jx < 4; ++jx) dst[jx * 64] = r == 1 ? ra[jx] + rb[jx] : ra[jx] - rb[jx];
     }
-#else
-    const float *s = tt + r * 4;
-#ifdef WW_EXP_NOCOMMIT
-    if (s[0] == 12345.f)  /* ablation only */
-#endif
-    {
-      dst[0 * 64] = s[0] - s[2];
-      dst[1 * 64] = s[1] + s[2];
-      dst[2 * 64] = s[2] - s[1];
-      dst[3 * 64] = s[1] - s[3];
-    }
-#endif
   };
   float bvalid = 1.f;  // 0 once the chunk being committed lies beyond this split's range (its dY must not be counted)
   auto commit_z_row = [&](float *Zs, auto SET, int r) {  // row r of A dY A^T, A = [[1,0],[1,1],[1,-1],[0,-1]]
@@ -281,8 +235,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
       for (int i = 0; i < 4; ++i) acc[x0 + i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][i], acc[x0 + i], 0, 0, 0);
       if (g == 0) load_dy(PAR);  // set P held chunk k, consumed an iteration ago
       if (g < 4) {
-        transform_col(g);
-        load_col(g);
+        transform_row(g);
+        load_row(g);
       } else {
         commit_v_row(Vd, g - 4);
         commit_z_row(Zd, Other{}, g - 4);
@@ -306,9 +260,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
   geometry();
   load_dy(S0{});
 #pragma unroll
-  for (int c = 0; c < 4; ++c) load_col(c);
+  for (int c = 0; c < 4; ++c) load_row(c);
 #pragma unroll
-  for (int c = 0; c < 4; ++c) transform_col(c);
+  for (int c = 0; c < 4; ++c) transform_row(c);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     commit_v_row(smem + SLAB, r);
@@ -318,7 +272,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
   geometry();
   load_dy(S1{});
 #pragma unroll
-  for (int c = 0; c < 4; ++c) load_col(c);
+  for (int c = 0; c < 4; ++c) load_row(c);
   advance();
   geometry();  // chunk q0 + 2: loaded by the first iteration (each iteration prepares the next one's geometry at its end)
 #pragma unroll
