@@ -36,7 +36,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
-constexpr int BF_TH = 8, BF_TW = 32, BF_IH = BF_TH + 6, BF_IW = BF_TW + 6, BF_CHS = BF_IH * BF_IW;  // x window: the tile + 3 on every side
+#ifndef BF_TH_ROWS
+#define BF_TH_ROWS 8
+#endif
+constexpr int BF_TH = BF_TH_ROWS, BF_NT = 64 * BF_TH, BF_TW = 32, BF_IH = BF_TH + 6, BF_IW = BF_TW + 6, BF_CHS = BF_IH * BF_IW;  // x window: the tile + 3 on every side
 constexpr int BF_CPG = 16, BF_NS = 64, BF_LS = BF_NS + 4, BF_SLAB = 32 * 2 * BF_LS, BF_TP = 5;  // slab: [row 32][co parity 2][co pair 64 + 4 pad]
 constexpr int BF_PR = 5, BF_PC = BF_TW + 4, BF_PCH = BF_PR * BF_PC, BF_PW = BF_CPG * BF_PCH;  // private dX rows: [wave][channel][5][36]
 // tap of (step tp, half-wave): pairs with equal tj and ti = 0 / 1 first, then (6, 7), then 8 alone (9 = no tap)
@@ -62,7 +65,7 @@ __global__ void dcn_bwd_fused_pack_kernel(const float *__restrict__ w, float *__
   }
 }
 
-__global__ __launch_bounds__(512) void dcn_bwd_fused_kernel(const DcnBwdFusedArgs a) {
+__global__ __launch_bounds__(BF_NT) void dcn_bwd_fused_kernel(const DcnBwdFusedArgs a) {
   constexpr int TH = BF_TH, TW = BF_TW, IH = BF_IH, IW = BF_IW, CHS = BF_CHS, CPG = BF_CPG, NS = BF_NS, LS = BF_LS, SLAB = BF_SLAB;
   constexpr int PC = BF_PC, PCH = BF_PCH, PW = BF_PW;
 #ifndef BF_CG
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(512) void dcn_bwd_fused_kernel(const DcnBwdFusedArg
   typedef __attribute__((address_space(1))) void gvoid;
   // three separate objects: the compiler may then move x-window reads across private-accumulator writes (151 KB in all)
   __shared__ __attribute__((aligned(16))) float xs[CPG * CHS];
-  __shared__ __attribute__((aligned(16))) float priv[8 * PW];
+  __shared__ __attribute__((aligned(16))) float priv[TH * PW];
   __shared__ __attribute__((aligned(16))) float wsl[2 * SLAB];
 
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, j = lane & 31;
@@ -115,26 +118,26 @@ __global__ __launch_bounds__(512) void dcn_bwd_fused_kernel(const DcnBwdFusedArg
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
   };
 
-  // ---- dY tile of this wave's pixel row: dyr[s] = dY[co = 2 s + half][pixel j] (the MFMA B operand of k-step s); rows past Co fall
-  //      outside the resource and read 0.  BF_DY_STREAM: re-read (L2) at the top of every step instead of register-resident, so
+  // ---- dY tile of this wave's pixel row: dyr[s] = dY[co = 2 s + half][pixel j] (the MFMA B operand of k-step s); rows past Co carry
+  //      the out-of-range LANE offset (not left to the range check of lane + scalar offset) and read 0.  BF_DY_STREAM: re-read (L2) at the top of every step instead of register-resident, so
   //      that the consumer phase has the 64 registers for its own loads in flight.
   const __amdgpu_buffer_rsrc_t dy_rsrc = rsrc_of(a.dy + (int64_t)img * a.Co * P, a.Co * P * 4);
   const int dy_voff = pix_ok ? (half * P + p) * 4 : OOB;
   float dyr[NS];
   auto load_dy = [&]() {
 #pragma unroll
-    for (int s = 0; s < NS; ++s) dyr[s] = bload(dy_rsrc, dy_voff, 2 * s * P * 4);
+    for (int s = 0; s < NS; ++s) dyr[s] = bload(dy_rsrc, 2 * s + half < a.Co ? dy_voff : OOB, 2 * s * P * 4);
   };
 #ifndef BF_DY_STREAM
   load_dy();
 #endif
 
   // ---- x window of one deformable group -> LDS (as dcn_fused.hip: positions outside the image fail the range check -> 0)
-  constexpr int NXK = (CHS + 511) / 512;
+  constexpr int NT = BF_NT, NXK = (CHS + NT - 1) / NT;
   int xoff[NXK];
 #pragma unroll
   for (int k = 0; k < NXK; ++k) {
-    const int q = tid + k * 512;
+    const int q = tid + k * NT;
     const int iy = q / IW, ix = q - iy * IW;
     const int gy = wy0 + iy, gx = wx0 + ix;
     xoff[k] = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (gy * a.W + gx) * 4 : OOB;
@@ -142,24 +145,24 @@ __global__ __launch_bounds__(512) void dcn_bwd_fused_kernel(const DcnBwdFusedArg
   auto dma_x = [&](int g) {
 #pragma unroll
     for (int k = 0; k < NXK; ++k)
-      if (tid + k * 512 < CHS) {  // the lanes past the end are masked off (LDS-DMA writes active lanes only)
+      if (tid + k * NT < CHS) {  // the lanes past the end are masked off (LDS-DMA writes active lanes only)
 #pragma unroll
         for (int ch = 0; ch < CPG; ++ch)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lvoid *)(xs + ch * CHS + k * 512 + wave * 64), 4, xoff[k], (g * CPG + ch) * P * 4, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lvoid *)(xs + ch * CHS + k * NT + wave * 64), 4, xoff[k], (g * CPG + ch) * P * 4, 0, 0);
       }
   };
   // ---- W^T slab of (group, step) i -> LDS buffer: a linear copy of 17 KB in 16-byte pieces
   auto dma_w = [&](float *dst, int i) {
     constexpr int TOTAL = SLAB / 4;  // float4 pieces
     const float *src = a.wbk + (int64_t)i * SLAB;
-    for (int q0 = wave * 64; q0 < TOTAL; q0 += 512)
+    for (int q0 = wave * 64; q0 < TOTAL; q0 += NT)
       if (q0 + lane < TOTAL) __builtin_amdgcn_global_load_lds((gvoid *)(src + (q0 + lane) * 4), (lvoid *)(dst + q0 * 4), 16, 0, 0);
   };
 
-  for (int i = tid; i < 8 * PW; i += 512) priv[i] = 0.f;
+  for (int i = tid; i < TH * PW; i += NT) priv[i] = 0.f;
   dma_w(wsl, 0);
   dma_x(0);
-  // offsets / mask of the lane's tap, fetched one step ahead
+  // offsets / mask of the lane's tap of a step: requested at the top of the step, used after its MFMAs
   auto tap_voff = [&](int tp, int &v1, int &v2) {  // lane offsets of (tap plane, pixel) in 9-plane and 18-plane groups
     const int t = half ? bf_tap(tp, 1) : bf_tap(tp, 0);
     const bool on = pix_ok && t < 9;
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(512) void dcn_bwd_fused_kernel(const DcnBwdFusedArg
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], dyr[s + 3], acc, 0, 0, 0);
     }
 
-    // everything this wave has in flight - its pieces of slab i + 1, the next taps, at a group's first step its pieces of the x
+    // everything this wave has in flight - its pieces of slab i + 1, its taps, at a group's first step its pieces of the x
     // window - was requested before the 64 MFMAs: waiting HERE, and not at the barrier, keeps the column stores of the consumer
     // below (whose completion nothing depends on) out of every wait
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -392,13 +395,13 @@ __global__ __launch_bounds__(512) void dcn_bwd_fused_kernel(const DcnBwdFusedArg
     // with one global atomic per touched element inside the image, clear them, fetch the next x window
     __syncthreads();
     float *gg = dx_img + (int64_t)g * CPG * P;
-    for (int q = tid; q < CPG * (TH + 4) * PC; q += 512) {
+    for (int q = tid; q < CPG * (TH + 4) * PC; q += NT) {
       const int cc = q / ((TH + 4) * PC), rem = q - cc * ((TH + 4) * PC), R = rem / PC, col = rem - R * PC;
       float v = 0.f;
 #pragma unroll
       for (int r = 0; r < BF_PR; ++r) {
         const int wv = R - r;
-        if (wv >= 0 && wv < 8) {
+        if (wv >= 0 && wv < TH) {
           float *e = priv + wv * PW + cc * PCH + r * PC + col;
           v += *e;
           *e = 0.f;
@@ -436,7 +439,7 @@ int dcn_bwd_fused_launch(const DcnShape &s, const float *x, const float *offset,
   a.tiles_x = cdiv(s.W, BF_TW);
   a.tiles_y = cdiv(s.H, BF_TH);
   a.off_bs = s.off_bs; a.msk_bs = s.msk_bs; a.doff_bs = s.doff_bs; a.dmsk_bs = s.dmsk_bs;
-  hipLaunchKernelGGL(dcn_bwd_fused_kernel, dim3(a.tiles_x * a.tiles_y, 1, s.B), dim3(512), 0, stream, a);
+  hipLaunchKernelGGL(dcn_bwd_fused_kernel, dim3(a.tiles_x * a.tiles_y, 1, s.B), dim3(BF_NT), 0, stream, a);
   return check_launch("dcn_bwd_fused_kernel");
 }
 
