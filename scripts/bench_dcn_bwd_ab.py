@@ -14,13 +14,16 @@ sigma = float(sys.argv[1]) if len(sys.argv) > 1 else 0.3
 dev = torch.device('cuda:0')
 g = torch.Generator(device=dev).manual_seed(0)
 print('EDVR_DCN_BWD_FUSED =', os.environ.get('EDVR_DCN_BWD_FUSED', '(unset: fused)'), ' sigma =', sigma)
+only = os.environ.get('BENCH_ONLY')  # e.g. 'L1': that layer only, strip hint only (for counter collection)
 for name, (B, C, H, W) in {'L1 160x128x64x64': (160, 128, 64, 64), 'L2 160x128x32x32': (160, 128, 32, 32), 'L3 160x128x16x16': (160, 128, 16, 16)}.items():
+    if only and not name.startswith(only):
+        continue
     x = torch.randn(B, C, H, W, device=dev, generator=g)
     w = torch.randn(C, C, 3, 3, device=dev, generator=g) * 0.05
     off = torch.randn(B, 144, H, W, device=dev, generator=g) * sigma
     m = torch.rand(B, 72, H, W, device=dev, generator=g)
     dy = torch.randn(B, C, H, W, device=dev, generator=g)
-    for hint_name, hint in (('strip', ops.DCN_SCATTER_STRIP), ('lds', ops.DCN_SCATTER_LDS)):
+    for hint_name, hint in (('strip', ops.DCN_SCATTER_STRIP), ('lds', ops.DCN_SCATTER_LDS))[:1 if only else 2]:
         for _ in range(3):
             ops.dcnv2_backward(x, off, m, w, dy, True, 1, 1, 1, 1, 8, scatter_hint=hint)
         torch.cuda.synchronize()
