@@ -102,6 +102,33 @@ def test_dcn_backward_adjoint_at_full_size(gpu, data):
     assert abs((dm.double() * m.double()).sum().item() - lhs) / abs(lhs) < 1e-4  # also linear in the mask
 
 
+@pytest.mark.parametrize('sigma', [0.3, 0.8])
+def test_dcn_backward_without_dcol_buffer_at_the_training_launch_shape(gpu, sigma):
+    """BASELINE configs[3]: 32 clips x 5 frames of 64 x 64 crops in ONE DCN backward launch (160 x 128 x 64 x 64, the shape
+    csrc/dcn_bwd_fused.hip is timed on).  The fused kernel (scatter hint STRIP) against the staged path (hint DEVICE: dcol buffer,
+    device atomics) on the same inputs, and the adjoint identities <dy, dcn(x)> == <dx, x> == <dW, W> == <dmask, mask>."""
+    from edvr_amd import ops
+    g = torch.Generator(device=gpu).manual_seed(31)
+    n, c, h, w_ = 160, 128, 64, 64
+    x = torch.randn(n, c, h, w_, device=gpu, generator=g)
+    wt = torch.randn(c, c, 3, 3, device=gpu, generator=g) * 0.03
+    off = torch.randn(n, 144, h, w_, device=gpu, generator=g) * sigma
+    m = torch.rand(n, 72, h, w_, device=gpu, generator=g)
+    dy = torch.randn(n, c, h, w_, device=gpu, generator=g)
+    out = ops.dcnv2_forward(x, off, m, wt, None, 1, 1, 1, 1, 8)
+    lhs = (dy.double() * out.double()).sum().item()
+    fused = ops.dcnv2_backward(x, off, m, wt, dy, True, 1, 1, 1, 1, 8, scatter_hint=ops.DCN_SCATTER_STRIP)
+    staged = ops.dcnv2_backward(x, off, m, wt, dy, True, 1, 1, 1, 1, 8, scatter_hint=ops.DCN_SCATTER_DEVICE)
+    torch.cuda.synchronize()
+    for name, a, b, tol in zip(('dx', 'doffset', 'dmask', 'dweight', 'dbias'), fused, staged, (2e-5, 2e-5, 2e-5, 1e-4, 1e-5)):
+        assert torch.isfinite(a).all(), name
+        assert _rel(a, b) < tol, name  # (dx, dW: different summation orders; doffset / dmask: the same arithmetic per tap)
+    dx, _, dm, dw, _ = fused
+    assert abs((dx.double() * x.double()).sum().item() - lhs) / abs(lhs) < 1e-4
+    assert abs((dw.double() * wt.double()).sum().item() - lhs) / abs(lhs) < 1e-4
+    assert abs((dm.double() * m.double()).sum().item() - lhs) / abs(lhs) < 1e-4
+
+
 def test_edvr_l_full_size_forward_is_finite_and_batch_consistent(gpu):
     """EDVR-L at the bench shape: clips are independent, so a 2-clip batch equals the two 1-clip runs."""
     from util_edvr import randomize_offsets
