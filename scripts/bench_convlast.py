@@ -8,3 +8,9 @@ x = torch.randn(4, 64, 720, 1280, device=dev); w = torch.randn(3, 64, 3, 3, devi
 wpk = ops.pack_conv_weight(w)
 for _ in range(8): ops.conv2d(x, wpk, b, 3, 3)
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20): ops.conv2d(x, wpk, b, 3, 3)
+e1.record()
+torch.cuda.synchronize()
+print(f'conv_last 4x64x720x1280 -> 3: {e0.elapsed_time(e1) / 20:.3f} ms per launch')
