@@ -16,13 +16,39 @@ Semantics kept from deform_conv_cuda.cpp (the callers rely on them):
     as the reference's coord kernels do;
   * `columns` / `ones` / `im2col_step` are scratch / blocking arguments of the reference's implementation: accepted, unused (the
     workspace is the explicit, grow-only one of edvr_amd.ops);
-  * launches go to the current stream under the tensors' device; no host synchronisation;
+  * launches go to the current stream under the tensors' device; no host synchronisation (the DCNv2 forward leaves the mean
+    |offset| of its call in pinned memory behind an event; the backward of the same offsets reads it if it has arrived and
+    passes it on as the scatter hint of include/edvr_amd.h - the strategy of dX, never its value);
   * contiguity of input / weight is required like deform_conv_cuda.cpp:497-498, kernel sizes are checked against the weight like
     :507-512; CPU tensors are refused ("not implemented on CPU", deform_conv_ext.cpp:66,85,103,123,145).
 """
 import torch
 
 from .. import ops
+
+
+_OFFSET_STATS = {}  # offset.data_ptr() -> (pinned per-image sums of |offset|, event, numel): forward -> backward of the same call
+
+
+def _note_offsets(offset):
+    if offset.dtype != torch.float32 or offset.dim() != 4:
+        return
+    if len(_OFFSET_STATS) > 256:  # forwards whose backward never came (inference through the training entry point)
+        _OFFSET_STATS.clear()
+    sums = ops.abs_sum_per_image(offset)
+    host = torch.empty(sums.shape, dtype=sums.dtype, pin_memory=True)
+    host.copy_(sums, non_blocking=True)
+    done = torch.cuda.Event()
+    done.record()
+    _OFFSET_STATS[offset.data_ptr()] = (host, done, offset.numel())
+
+
+def _scatter_hint(offset):
+    rec = _OFFSET_STATS.pop(offset.data_ptr(), None)
+    if rec is None or not rec[1].query():  # unknown, or still on its way: the default strategy
+        return ops.DCN_SCATTER_AUTO
+    from ..functional import scatter_hint_from_absmean
+    return scatter_hint_from_absmean(float(rec[0].sum()) / rec[2])
 
 
 def _check(input, weight, kh, kw, group):
@@ -44,6 +70,7 @@ def modulated_deform_conv_forward(input, weight, bias, ones, offset, mask, outpu
     y = ops.dcnv2_forward(input, offset, mask, weight, bias if with_bias else None, (stride_h, stride_w), (pad_h, pad_w),
                           (dilation_h, dilation_w), group, deformable_group)
     output.view_as(y).copy_(y)
+    _note_offsets(offset)
 
 
 def modulated_deform_conv_backward(input, weight, bias, ones, offset, mask, columns, grad_input, grad_weight, grad_bias, grad_offset,
@@ -51,7 +78,8 @@ def modulated_deform_conv_backward(input, weight, bias, ones, offset, mask, colu
                                    group, deformable_group, with_bias):
     _check(input, weight, kernel_h, kernel_w, group)
     dx, doff, dmsk, dw, db = ops.dcnv2_backward(input, offset, mask, weight, grad_output, bool(with_bias), (stride_h, stride_w),
-                                                (pad_h, pad_w), (dilation_h, dilation_w), group, deformable_group)
+                                                (pad_h, pad_w), (dilation_h, dilation_w), group, deformable_group,
+                                                scatter_hint=_scatter_hint(offset))
     grad_input.view_as(dx).add_(dx)
     grad_weight.add_(dw)
     if with_bias:

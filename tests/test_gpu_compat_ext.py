@@ -64,6 +64,53 @@ def test_modulated_deform_conv_ext_call_sites(gpu, case):
     assert (out[5] is None) == (not with_bias)
 
 
+def test_ext_backward_takes_its_dx_strategy_from_the_forward_of_the_same_offsets(gpu):
+    """The FFI has no argument for the scatter hint: the forward notes the mean |offset| of its call (pinned memory + event), the
+    backward of the same offset tensor picks it up - sub-pixel offsets on a 16-channels-per-group layer then run the kernel
+    without the dcol buffer.  Results against the oracle either way; the statistic is consumed exactly once."""
+    from edvr_amd import ops
+    from edvr_amd.compat import deform_conv_ext as ext
+    from oracle import dcn_oracle as O
+    g = torch.Generator().manual_seed(77)
+    B, C, H, W, dg = 2, 128, 16, 40, 8
+    x = torch.randn(B, C, H, W, generator=g)
+    off = torch.randn(B, dg * 18, H, W, generator=g) * 0.3
+    m = torch.rand(B, dg * 9, H, W, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) * 0.1
+    b = torch.randn(C, generator=g)
+    dy = torch.randn(B, C, H, W, generator=g)
+    cfg = (1, 1, 1, 1, dg)
+    ref_y = O.c_forward(x.double(), off.double(), m.double(), w.double(), b.double(), *cfg)
+    ref_g = O.c_backward(x.double(), off.double(), m.double(), w.double(), dy.double(), True, *cfg)
+    dev = [t.to(gpu) for t in (x, off, m, w)]
+    seen = []
+    orig = ops.dcnv2_backward
+
+    def spy(*a, **kw):
+        seen.append(kw.get('scatter_hint'))
+        return orig(*a, **kw)
+
+    ops.dcnv2_backward = spy
+    try:
+        ext._OFFSET_STATS.clear()
+        # (the reference's Function runs forward and backward in separate calls: the statistic has long arrived by then)
+        out_y = torch.empty(B, C, H, W, device=gpu)
+        ext.modulated_deform_conv_forward(dev[0], dev[3], b.to(gpu), dev[0].new_empty(0), dev[1], dev[2], out_y, dev[0].new_empty(0),
+                                          3, 3, 1, 1, 1, 1, 1, 1, 1, dg, True)
+        torch.cuda.synchronize()
+        assert dev[1].data_ptr() in ext._OFFSET_STATS
+        grads = [torch.zeros_like(t) for t in (dev[0], dev[3], b.to(gpu), dev[1], dev[2])]
+        ext.modulated_deform_conv_backward(dev[0], dev[3], b.to(gpu), dev[0].new_empty(0), dev[1], dev[2], dev[0].new_empty(0), grads[0],
+                                           grads[1], grads[2], grads[3], grads[4], dy.to(gpu), 3, 3, 1, 1, 1, 1, 1, 1, 1, dg, True)
+        torch.cuda.synchronize()
+    finally:
+        ops.dcnv2_backward = orig
+    assert seen == [ops.DCN_SCATTER_STRIP] and not ext._OFFSET_STATS
+    assert _rel(out_y, ref_y) < 2e-5
+    for name, a, r in zip(('dx', 'dweight', 'dbias', 'doffset', 'dmask'), grads, (ref_g[0], ref_g[3], ref_g[4], ref_g[1], ref_g[2])):
+        assert _rel(a, r) < 1e-4, name
+
+
 def test_ext_accumulates_where_the_reference_does(gpu):
     """grad_input / grad_weight / grad_bias are accumulated into (atomicAdd / addmm_ beta 1 in the reference), grad_offset and
     grad_mask overwritten: buffers that are NOT zero on entry keep their contents in the first three, lose them in the others."""
