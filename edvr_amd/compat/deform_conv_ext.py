@@ -27,7 +27,7 @@ import torch
 from .. import ops
 
 
-_OFFSET_STATS = {}  # offset.data_ptr() -> (pinned per-image sums of |offset|, event, numel): forward -> backward of the same call
+_OFFSET_STATS = {}  # offset.data_ptr() -> ops.note_abs_mean record: forward -> backward of the same call
 
 
 def _note_offsets(offset):
@@ -35,20 +35,15 @@ def _note_offsets(offset):
         return
     if len(_OFFSET_STATS) > 256:  # forwards whose backward never came (inference through the training entry point)
         _OFFSET_STATS.clear()
-    sums = ops.abs_sum_per_image(offset)
-    host = torch.empty(sums.shape, dtype=sums.dtype, pin_memory=True)
-    host.copy_(sums, non_blocking=True)
-    done = torch.cuda.Event()
-    done.record()
-    _OFFSET_STATS[offset.data_ptr()] = (host, done, offset.numel())
+    _OFFSET_STATS[offset.data_ptr()] = ops.note_abs_mean(offset)
 
 
 def _scatter_hint(offset):
-    rec = _OFFSET_STATS.pop(offset.data_ptr(), None)
-    if rec is None or not rec[1].query():  # unknown, or still on its way: the default strategy
+    absmean = ops.abs_mean_if_ready(_OFFSET_STATS.pop(offset.data_ptr(), None))
+    if absmean is None:  # unknown, or still on its way: the default strategy
         return ops.DCN_SCATTER_AUTO
     from ..functional import scatter_hint_from_absmean
-    return scatter_hint_from_absmean(float(rec[0].sum()) / rec[2])
+    return scatter_hint_from_absmean(absmean)
 
 
 def _check(input, weight, kh, kw, group):

@@ -33,8 +33,11 @@ class ModulatedDeformConvFunction(Function):
         ctx.with_bias = bias is not None
         ctx.act = act
         out = ops.dcnv2_forward(input, offset, mask, weight, bias, *ctx.cfg, act=act)
+        ctx.offset_stat = None
         if weight.requires_grad or mask.requires_grad or offset.requires_grad or input.requires_grad:
             ctx.save_for_backward(input, offset, mask, weight, out if act != ops.ACT_NONE else None)
+            if offset.dtype == torch.float32:  # mean |offset| of this call, on its way to the host while the graph above runs:
+                ctx.offset_stat = ops.note_abs_mean(offset)  # the backward's dX strategy (performance only, never waited for)
         return out
 
     @staticmethod
@@ -45,7 +48,10 @@ class ModulatedDeformConvFunction(Function):
         input, offset, mask, weight, out = ctx.saved_tensors
         if ctx.act != ops.ACT_NONE:
             grad_output = ops.act_backward(grad_output, out, ctx.act)
-        dx, doff, dmsk, dw, db = ops.dcnv2_backward(input, offset, mask, weight, grad_output, ctx.with_bias, *ctx.cfg)
+        from .functional import scatter_hint_from_absmean
+        absmean = ops.abs_mean_if_ready(ctx.offset_stat)
+        hint = scatter_hint_from_absmean(absmean) if absmean is not None else ops.DCN_SCATTER_AUTO
+        dx, doff, dmsk, dw, db = ops.dcnv2_backward(input, offset, mask, weight, grad_output, ctx.with_bias, *ctx.cfg, scatter_hint=hint)
         return dx, doff, dmsk, dw, db, None, None, None, None, None, None
 
 

@@ -659,6 +659,24 @@ def charbonnier(pred, target, eps=1e-12, want_grad=True, grad_scale=1.0):
     return loss, dpred
 
 
+def note_abs_mean(x):
+    """Start computing mean |x| of a (n, c, h, w) float32 tensor without waiting for it: per-image sums -> pinned memory behind an
+    event.  `abs_mean_if_ready` returns the value once it has arrived (None before) - how a backward picks up the offset statistic
+    of its own forward without a host synchronisation."""
+    sums = abs_sum_per_image(x)
+    host = torch.empty(sums.shape, dtype=sums.dtype, pin_memory=True)
+    host.copy_(sums, non_blocking=True)
+    done = torch.cuda.Event()
+    done.record()
+    return host, done, x.numel()
+
+
+def abs_mean_if_ready(rec):
+    if rec is None or not rec[1].query():
+        return None
+    return float(rec[0].sum()) / rec[2]
+
+
 def abs_sum_per_image(x):
     """sum |x[i]| per image of a (n, c, h, w) tensor (image-strided views allowed)."""
     require_gpu(x)
