@@ -19,7 +19,15 @@ Objects in the line besides the contract's fields (everything below runs OUTSIDE
   target_4k           BASELINE.json north_star's target workload - EDVR-L x4, 5 frames, 720x1280 -> 2880x5120, 1 clip per GPU -
                       timed the same way (barrier + synchronize, max over ranks), with its F(4x4) roofline fraction and parity
                       (max rel err, dPSNR) against the stock-PyTorch-ROCm arm on the same clip.
-  train               BASELINE.json's second headline (training iters/sec) on the cfg4 per-GPU shape, run on ALL ranks (DDP).
+  train               BASELINE.json's second headline (training iters/sec) on the cfg4 per-GPU shape, run on ALL ranks (DDP), with
+                      `parity`: the same 2-clip batch and weights through oracle/edvr_oracle.py in stock fp32 torch ops + torch
+                      autograd on this GPU - loss and every parameter gradient compared (the bounds of tests/test_gpu_train.py).
+  trained_like        the headline workload with the offsets a TRAINED EDVR predicts: conv_offset.bias ~ N(0, 4^2) / N(0, 10^2) per
+                      channel (every (group, tap) has its own multi-pixel displacement, mean |offset| ~ 3.2 / 8 px) on top of the
+                      same N(0, 0.02) weights (spatially coherent field): clips/s, the DCN forward's roofline fraction, parity
+                      against the stock-ops arm.  The reference's gather costs the same at any offset (.cu:570-633).
+  configs             one-line results for the other BASELINE.json configs that fit one GPU: [1] EDVR-M batch 4, [2] EDVR-L T7
+                      batch 8 forward and forward+backward+Adam, [4] deblur 720p batch 4.
   parity              the headline workload's output on ONE clip vs the CPU oracle's output on the same clip.
   cpu_baseline        the CPU oracle timed on that clip (median of 3) on this box's host cores.
   stock_rocm_baseline SURVEY 8(d)'s second arm: the same network in stock PyTorch-ROCm ops (MIOpen / rocBLAS) with a pure-torch
@@ -42,7 +50,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
 PEAK_HBM_GBPS = 8000.0        # same guide: HBM3E ~8 TB/s
-PROFILE_ROUND = 'r3'
+PROFILE_ROUND = 'r4'
 
 L5 = dict(num_feat=128, num_frame=5, num_reconstruct_block=40, center_frame_idx=None)
 WORKLOADS = {
@@ -99,15 +107,17 @@ def parse():
     ap.add_argument('--no-train-leg', action='store_true', help='infer mode: skip the training leg (the `train` object)')
     ap.add_argument('--no-batch4', action='store_true', help='headline workload: skip the extra 4-clips-per-GPU measurement')
     ap.add_argument('--no-target-4k', action='store_true', help='headline workload: skip the 720p -> 4K target leg (`target_4k`)')
-    ap.add_argument('--train-steps', type=int, default=5)
+    ap.add_argument('--train-steps', type=int, default=20)
+    ap.add_argument('--no-trained-like', action='store_true', help='headline workload: skip the trained-like-offsets leg')
+    ap.add_argument('--no-configs', action='store_true', help='headline workload: skip the other BASELINE configs (`configs` object)')
     return ap.parse_args()
 
 
-def build_net(cfg, device):
+def build_net(cfg, device, offset_bias_sigma=0.5):
     from edvr_amd import EDVR
     from util_edvr import randomize_offsets
     torch.manual_seed(10)  # options/train/EDVR/*.yml manual_seed: 10
-    return randomize_offsets(EDVR(**cfg['net'])).eval().to(device)
+    return randomize_offsets(EDVR(**cfg['net']), bias_sigma=offset_bias_sigma).eval().to(device)
 
 
 # ------------------------------------------------------------------------------------------------ instrumented pass
@@ -163,8 +173,10 @@ def kernel_table(per, steps, step_seconds):
         row = {'launches_per_step': round(n / steps, 1), 'ms_per_step': round(secs / steps * 1e3, 3),
                'share_of_step': round(secs / steps / step_seconds, 4), 'avg_launch_us': round(secs / n * 1e6, 2)}
         if _is_mfma(name) and flops > 0:
-            ex = executed / secs / 1e12
-            row.update(bound='mfma', tflops_executed=round(ex, 2), frac_of_mfma_peak=round(ex / PEAK_F32_MFMA_TFLOPS, 4))
+            ex, useful = executed / secs / 1e12, _executed(name, flops) / secs / 1e12
+            # frac_of_mfma_peak counts the USEFUL matrix-core flops (no padded tiles / channels); the issued ones are beside it
+            row.update(bound='mfma', tflops_executed=round(useful, 2), frac_of_mfma_peak=round(useful / PEAK_F32_MFMA_TFLOPS, 4),
+                       tflops_incl_padding=round(ex, 2), frac_incl_padding=round(ex / PEAK_F32_MFMA_TFLOPS, 4))
             if name.startswith(WINOGRAD + WINOGRAD_F4):
                 row['tflops_algorithmic'] = round(flops / secs / 1e12, 2)
         else:
@@ -179,7 +191,7 @@ def measured_traffic(workload, kernel):
     (scripts/prof_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate --pmc passes, calibrated on known-size copies as
     MI355X_MICROARCH.md's HBM section prescribes).  PMC collection serialises kernels, so it is not redone inside the timed run;
     the summary records the hash of the kernel sources it was measured on (`csrc_sha16`), compared with the tree's below."""
-    for rnd in (PROFILE_ROUND, 'r2', 'r1'):
+    for rnd in (PROFILE_ROUND, 'r3', 'r2', 'r1'):
         path = os.path.join(ROOT, 'profiles', rnd, f'traffic_{workload}.json')
         if os.path.exists(path):
             rep = json.load(open(path))
@@ -202,19 +214,24 @@ def roofline_object(per, steps, step_seconds, workload, default_batch):
     n, flops, secs, nbytes = per[name][:4]
     executed = per[name][4] if len(per[name]) > 4 else _executed(name, flops)
     ex = executed / secs / 1e12
+    useful = _executed(name, flops) / secs / 1e12
     tr, tr_src = measured_traffic(workload, name) if default_batch else (None, None)
     wino = name.startswith(WINOGRAD)
     f4 = name.startswith(WINOGRAD_F4)
     from edvr_amd.build import source_hash
     return {
-        'bound': 'mfma', 'kernel': name, 'achieved': round(ex, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': round(ex / PEAK_F32_MFMA_TFLOPS, 4),
-        'definition': 'achieved = flops the fp32 matrix cores execute = v_mfma_f32_32x32x2_f32 issues x 4096, tile and channel '
-                      'padding included (edvr_conv2d_executed_flops; rocprofv3 SQ_INSTS_VALU_MFMA_MOPS_F32 counts the same '
-                      'issues, profiles/*/winograd_f4_micro_pmc.json) / HIP-event time of the kernel; frac = achieved / peak',
-        # the same without the padded tiles / channels (algorithmic flops / 4 for F(4x4), / 2.25 for F(2x2)): the useful part
-        'executed_without_padding_tflops': round(_executed(name, flops) / secs / 1e12, 2),
+        'bound': 'mfma', 'kernel': name, 'achieved': round(useful, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+        'frac': round(useful / PEAK_F32_MFMA_TFLOPS, 4),
+        'definition': 'achieved = USEFUL flops the fp32 matrix cores execute (algorithmic flops / 4 for F(4x4), / 2.25 for F(2x2): '
+                      'what the algorithm needs on exactly fitting tiles) / HIP-event time of the kernel; frac = achieved / peak.  '
+                      'The MFMAs issued on padded tiles and channels are NOT counted as achievement: incl_padding_* carries them '
+                      '(v_mfma_f32_32x32x2_f32 issues x 4096 = edvr_conv2d_executed_flops = what rocprofv3 '
+                      'SQ_INSTS_VALU_MFMA_MOPS_F32 counts, profiles/*/winograd_f4_micro_pmc.json)',
+        'executed_without_padding_tflops': round(useful, 2),
+        'incl_padding_tflops': round(ex, 2), 'incl_padding_frac': round(ex / PEAK_F32_MFMA_TFLOPS, 4),
         'padding_overhead': round(executed / max(_executed(name, flops), 1.0) - 1.0, 4),
+        # SURVEY 8(d)'s algorithmic count against the matrix-core peak scaled by the algorithm's multiply saving (4 for F(4x4)):
+        'algorithmic_frac_winograd': round(flops / secs / 1e12 / ((4.0 if f4 else (2.25 if wino else 1.0)) * PEAK_F32_MFMA_TFLOPS), 4),
         'algorithm': 'winograd F(4x4,3x3), fp32: 36 instead of 144 multiplies per 4x4 tile and channel pair' if f4
                      else ('winograd F(2x2,3x3), fp32: 16 instead of 36 multiplies per 2x2 tile and channel pair' if wino
                            else 'direct implicit GEMM, fp32'),
@@ -371,6 +388,127 @@ def timed(step, steps, warmup, dist, device):
     return elapsed
 
 
+def _rel_err(a, ref):
+    return float(((a.double() - ref.double()).abs().max() / ref.double().abs().max().clamp_min(1e-30)).item())
+
+
+def train_parity(cfg, device, clips=2):
+    """Witness of the training half of the metric (sr_model.py:88-112): `clips` clips, same weights, ONE forward + Charbonnier(sum)
+    + backward through this path and through oracle/edvr_oracle.py in stock fp32 torch ops (convs = F.unfold + GEMM, pure-torch
+    DCNv2, torch autograd) on this GPU.  Nothing is shared between the two runs (activation sides, pooling routes, DCN cells are each
+    run's own), so single tensors may differ by a finite jump where a value sits within rounding distance of a kink
+    (tests/test_gpu_train.py): bounded are the loss, the output, the MEDIAN over the parameter tensors and the maximum."""
+    from edvr_amd.autograd import charbonnier_loss
+    from oracle import dcn_oracle, edvr_oracle as EO
+    net = build_net(cfg, device).train()
+    sc = cfg.get('scale', 4)
+    x = torch.rand(clips, *cfg['shape'], generator=torch.Generator().manual_seed(0)).to(device)
+    gt = torch.rand(clips, 3, sc * cfg['shape'][2], sc * cfg['shape'][3], generator=torch.Generator().manual_seed(1)).to(device)
+    out = net(x)
+    loss = charbonnier_loss(out, gt)
+    loss.backward()
+    ours = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in net.state_dict().items()}
+    t0 = time.perf_counter()
+    ref_out = EO.edvr_forward(sd, x, dcn=dcn_oracle.dcnv2_torch, conv_impl='unfold', **oracle_kw(cfg))
+    ref_loss = EO.charbonnier_sum(ref_out, gt)
+    ref_loss.backward()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    errs = sorted((_rel_err(ours[k], sd[k].grad), k) for k in ours if sd[k].grad is not None and sd[k].grad.abs().max() > 0)
+    vals = [e for e, _ in errs]
+    par = dict(against='oracle/edvr_oracle.py in stock PyTorch-ROCm fp32 ops (F.unfold + rocBLAS GEMM convs, pure-torch DCNv2, torch autograd) on '
+                       f'this GPU: {clips} clips of the training shape, same weights, one forward + Charbonnier(sum) + backward, nothing shared',
+               loss_ours=float(loss.item()), loss_stock=float(ref_loss.item()),
+               loss_rel_err=abs(float(loss.item()) - float(ref_loss.item())) / abs(float(ref_loss.item())),
+               output_max_rel_err=_rel_err(out.detach(), ref_out.detach()),
+               grad_tensors=len(vals), grad_rel_err_median=vals[len(vals) // 2], grad_rel_err_p90=vals[int(len(vals) * 0.9)],
+               grad_rel_err_max=vals[-1], worst_tensor=errs[-1][1],
+               tolerance={'loss_rel_err': 1e-5, 'output_max_rel_err': 2e-4, 'grad_rel_err_median': 1e-3, 'grad_rel_err_max': 0.2},
+               witness_seconds=round(dt, 2))
+    par['ok'] = bool(par['loss_rel_err'] < 1e-5 and par['output_max_rel_err'] < 2e-4 and par['grad_rel_err_median'] < 1e-3 and par['grad_rel_err_max'] < 0.2)
+    return par
+
+
+def trained_like_leg(cfg, batch, args, device, rank, world, dist, sigmas=(4.0, 10.0)):
+    """The headline workload with the offsets of a trained model: conv_offset.bias ~ N(0, sigma^2) per channel."""
+    out = {}
+    for sigma in sigmas:
+        net = build_net(cfg, device, offset_bias_sigma=sigma)
+        x = torch.rand(batch, *cfg['shape'], generator=torch.Generator().manual_seed(rank)).to(device)
+
+        def step():
+            with torch.no_grad():
+                return net(x)
+        steps = 5
+        elapsed = timed(step, steps, 3, dist, device)  # (the first forwards also settle the per-layer kernel hints)
+        rec = None
+        if rank == 0:
+            net.check_offsets()
+            dcns = net.pcd_align.dcn_modules()
+            rec = {'value': round(batch * world * steps / elapsed, 4), 'unit': 'clips/s', 'ms_per_step': round(elapsed / steps * 1e3, 3), 'steps': steps,
+                   'clips_per_gpu': batch, 'offset_bias_sigma': sigma,
+                   'mean_abs_offset_px': [round(m.last_offset_absmean, 3) for m in dcns],
+                   'offset_roughness_px': [None if m.last_offset_rough is None else round(m.last_offset_rough, 3) for m in dcns]}
+            if not args.no_roofline:
+                per = instrumented_pass(step, 1)
+                tab = kernel_table(per, 1, elapsed / steps)
+                if 'dcnv2_fwd' in tab:
+                    rec['dcnv2_fwd'] = tab['dcnv2_fwd']
+            if world == 1 and not args.no_stock_baseline:
+                from oracle import dcn_oracle, edvr_oracle as EO
+                try:
+                    x1 = x[:1].contiguous()
+                    sc = cfg.get('scale', 4)
+                    gt = torch.rand(1, 3, sc * cfg['shape'][2], sc * cfg['shape'][3], generator=torch.Generator().manual_seed(1)).to(device)
+                    with torch.no_grad():
+                        ours = net(x1)
+                        ref = EO.edvr_forward(net.state_dict(), x1, dcn=dcn_oracle.dcnv2_torch, conv_impl='unfold', **oracle_kw(cfg))
+                    err = _rel_err(ours, ref)
+                    p_ours, p_ref = EO.psnr(ours, gt), EO.psnr(ref, gt)
+                    rec['parity'] = dict(against='stock PyTorch-ROCm fp32 ops (F.unfold + GEMM convs, pure-torch DCNv2) on this GPU, one clip, same weights',
+                                         max_rel_err=err, d_psnr=round(abs(p_ours - p_ref), 8), tolerance={'max_rel_err': 2e-4, 'd_psnr_db': 1e-3},
+                                         ok=bool(err < 2e-4 and abs(p_ours - p_ref) <= 1e-3))
+                except Exception as e:  # (a witness arm must never take the measurement down)
+                    rec['parity'] = {'error': f'{type(e).__name__}: {str(e)[:200]}'}
+            out[f'bias_sigma_{sigma:g}'] = rec
+        del net, x, step
+        torch.cuda.empty_cache()
+    return out if rank == 0 else None
+
+
+def configs_leg(args, device, rank, world, dist):
+    """The BASELINE.json configs the headline does not cover, one line each, timed like the headline (barrier + synchronize, max
+    over ranks); full-size parity of each: tests/test_gpu_fullsize_parity.py."""
+    out = {}
+    plan = [('configs[1] EDVR-M x4 T5 180x320 batch 4, inference', 'edvr_m_x4_t5_180x320', 'infer', 5),
+            ('configs[2] EDVR-L x4 T7 180x320 batch 8, forward', 'edvr_l_x4_t7_180x320', 'infer', 3),
+            ('configs[2] EDVR-L x4 T7 180x320 batch 8, forward + backward + Adam', 'edvr_l_x4_t7_180x320', 'train', 3),
+            ('configs[4] EDVR-L deblur T5 1280x720 batch 4, inference', 'edvr_l_deblur_t5_720x1280', 'infer', 3)]
+    for label, wl, mode, steps in plan:
+        cfg = WORKLOADS[wl]
+        try:
+            net = build_net(cfg, device)
+            if mode == 'train':
+                step = make_train_step(net, cfg, cfg['batch'], device, rank, 'fused')
+            else:
+                x = torch.rand(cfg['batch'], *cfg['shape'], generator=torch.Generator().manual_seed(rank)).to(device)
+
+                def step(net=net, x=x):
+                    with torch.no_grad():
+                        return net(x)
+            elapsed = timed(step, steps, 2, dist, device)
+            if rank == 0:
+                out[label] = {'clips_per_sec': round(cfg['batch'] * world * steps / elapsed, 3), 'ms_per_step': round(elapsed / steps * 1e3, 2),
+                              'steps': steps, 'clips_per_gpu': cfg['batch'], 'workload': wl}
+        except Exception as e:  # e.g. out of memory on a smaller part: the headline line must survive
+            if rank == 0:
+                out[label] = {'error': f'{type(e).__name__}: {str(e)[:200]}'}
+        net = step = x = None
+        torch.cuda.empty_cache()
+    return out if rank == 0 else None
+
+
 def train_leg(args, device, rank, world, dist):
     """BASELINE.json's second headline: EDVR-L training iterations/sec on the cfg4 per-GPU shape (32 clips of 5 x 64x64 per GPU)."""
     cfg = WORKLOADS['edvr_l_train_t5_64x64']
@@ -388,6 +526,14 @@ def train_leg(args, device, rank, world, dist):
         for key, label in (('conv3x3_winograd_f4_kernel', 'fwd_dgrad_f4'), ('conv3x3_winograd_kernel', 'fwd_dgrad_f2'), ('conv3x3_winograd_wgrad_kernel', 'wgrad')):
             if key in tab:
                 out[f'{label}_mfma_frac'] = tab[key]['frac_of_mfma_peak']
+    if rank == 0 and world == 1 and not args.no_stock_baseline:
+        del step, net
+        step = None
+        torch.cuda.empty_cache()
+        try:
+            out['parity'] = train_parity(cfg, device)
+        except Exception as e:  # (a witness arm must never take the measurement down)
+            out['parity'] = {'error': f'{type(e).__name__}: {str(e)[:300]}'}
     return out, step
 
 
@@ -528,6 +674,7 @@ def main():
         }
         from edvr_amd.build import source_hash
         result['csrc_sha16'] = source_hash()  # the kernel sources this line was measured on (ties profiles/*.json to the tree)
+        result['library'] = _lib.lib().edvr_version().decode()  # (an experiment build says "variant:NAME" here)
         if args.mode == 'train':
             result['iters_per_sec'] = round(args.steps / elapsed, 4)
             result['optimizer'] = ('edvr_amd.optim.FusedAdam (one HIP launch for all tensors; arithmetic of torch.optim.Adam)'
@@ -558,6 +705,18 @@ def main():
         torch.cuda.empty_cache()
         if rank == 0:
             result['target_4k'] = t4k
+    if args.workload == 'edvr_l_x4_t5_180x320' and args.mode == 'infer' and not args.no_trained_like:
+        tl = trained_like_leg(cfg, batch, args, device, rank, world, dist)  # all ranks (barriers inside)
+        if rank == 0:
+            result['trained_like'] = tl
+            for rec in tl.values():
+                rec['vs_headline'] = round(rec['value'] / result['value'], 4)
+    if args.workload == 'edvr_l_x4_t5_180x320' and args.mode == 'infer' and not args.no_configs:
+        net = None  # (the headline network is not needed any more: the remaining legs build their own)
+        torch.cuda.empty_cache()
+        cf = configs_leg(args, device, rank, world, dist)  # all ranks
+        if rank == 0:
+            result['configs'] = cf
     if args.mode == 'infer' and not args.no_train_leg:
         del net, x
         torch.cuda.empty_cache()

@@ -22,7 +22,7 @@ class ConvDesc(ctypes.Structure):
         ('bias', vp), ('co', i32), ('ks', i32), ('stride', i32), ('act', i32), ('act_from', i32), ('res1', vp),
         ('res2', vp), ('res1_img_stride', i64), ('res2_img_stride', i64), ('y', vp), ('y_img_stride', i64),
         ('out_mode', i32), ('algo', i32), ('gate', vp), ('gate_img_stride', i64), ('gate_slope', f32), ('y_scale', f32),
-        ('wpk_f4', vp), ('abs_sum', vp), ('abs_sum_channels', i32),
+        ('wpk_f4', vp), ('abs_sum', vp), ('abs_sum_channels', i32), ('abs_diff', vp),
     ]
 
 
@@ -80,12 +80,14 @@ PROTOTYPES = {
     'edvr_tsa_combine_bwd_f32': (i32, [vp] * 5 + [i64, vp]),
     'edvr_charbonnier_f32': (i32, [vp, vp, vp, vp, i64, f32, f32, vp]),
     'edvr_abs_sum_f32': (i32, [vp, vp, i32, i64, i64, vp]),
+    'edvr_abs_stats_f32': (i32, [vp, vp, i32, i64, i32, i64, vp]),
 }
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
 OUT_NCHW, OUT_PIXEL_SHUFFLE2 = 0, 1
 CONV_AUTO, CONV_DIRECT, CONV_WINOGRAD, CONV_WINOGRAD_F4 = 0, 1, 2, 3
 DTYPE_F32, DTYPE_F64, DTYPE_F16 = 0, 1, 2  # EDVR_DTYPE_*
+DCN_HALO_TAPWIN = 16  # EDVR_DCN_HALO_TAPWIN
 
 _lib = None
 

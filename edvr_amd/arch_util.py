@@ -76,14 +76,15 @@ class DCNv2Pack(ModulatedDeformConvPack):
     """
 
     stats_sink = None
-    last_offset_absmean = None  # mean |offset| of the previous call: picks the fused kernel's halo class (perf hint only)
+    last_offset_absmean = None  # mean |offset| of the previous call and
+    last_offset_rough = None    # its mean |horizontal neighbour difference|: pick the fused kernel's class (perf hints only)
 
     def forward(self, x, feat, act=F_.ACT_NONE):
-        om, sums = F_.offset_mask_conv_stats(self.conv_offset, feat)
+        om, stats = F_.offset_mask_conv_stats(self.conv_offset, feat)
         offset = om.detach()[:, :2 * om.shape[1] // 3]
         if self.stats_sink is not None:
-            self.stats_sink.append((sums, offset[0].numel(), self))
+            self.stats_sink.append((stats, offset[0].numel(), self))
         else:
-            self.last_offset_absmean = float(sums.sum().item()) / offset.numel()
+            self.last_offset_absmean, self.last_offset_rough = F_.ops.offset_stats(stats.cpu(), offset.numel())
             warn_offset_absmean(self.last_offset_absmean)
         return F_.dcn_from_packed(self, x, om, act)

@@ -145,8 +145,8 @@ class DcnFromPackedFn(Function):
     def backward(ctx, dy):
         x, om, weight, out = ctx.saved_tensors
         stride, padding, dilation, groups, dg, act, _, module = ctx.cfg
-        from .functional import scatter_hint_from_absmean
-        scatter = scatter_hint_from_absmean(getattr(module, 'last_offset_absmean', None))  # statistic of THIS forward
+        from .functional import scatter_hint_from_stats
+        scatter = scatter_hint_from_stats(getattr(module, 'last_offset_absmean', None), getattr(module, 'last_offset_rough', None))  # statistics of THIS forward
         if act != ACT_NONE:
             dy = ops.act_backward(dy, out, act)
         split = 2 * om.shape[1] // 3

@@ -27,7 +27,7 @@ import torch
 from .. import ops
 
 
-_OFFSET_STATS = {}  # offset.data_ptr() -> ops.note_abs_mean record: forward -> backward of the same call
+_OFFSET_STATS = {}  # _stat_key(offset) -> ops.note_abs_mean record: forward -> backward of the same call
 
 
 def _note_offsets(offset):
@@ -35,15 +35,20 @@ def _note_offsets(offset):
         return
     if len(_OFFSET_STATS) > 256:  # forwards whose backward never came (inference through the training entry point)
         _OFFSET_STATS.clear()
-    _OFFSET_STATS[offset.data_ptr()] = ops.note_abs_mean(offset)
+    _OFFSET_STATS[_stat_key(offset)] = ops.note_abs_mean(offset)
+
+
+def _stat_key(offset):
+    # (address, version, shape): a different tensor that happens to reuse the address does not pick up this one's statistic
+    return (offset.data_ptr(), offset._version, tuple(offset.shape))
 
 
 def _scatter_hint(offset):
-    absmean = ops.abs_mean_if_ready(_OFFSET_STATS.pop(offset.data_ptr(), None))
-    if absmean is None:  # unknown, or still on its way: the default strategy
+    st = ops.offset_stats_if_ready(_OFFSET_STATS.pop(_stat_key(offset), None))
+    if st is None:  # unknown, or still on its way: the default strategy
         return ops.DCN_SCATTER_AUTO
-    from ..functional import scatter_hint_from_absmean
-    return scatter_hint_from_absmean(absmean)
+    from ..functional import scatter_hint_from_stats
+    return scatter_hint_from_stats(*st)
 
 
 def _check(input, weight, kh, kw, group):

@@ -14,7 +14,16 @@ void set_error(const char *fmt, ...) {
 }  // namespace edvr
 
 extern "C" {
-const char *edvr_version(void) { return "edvr_amd 0.1.0 (gfx950)"; }
+// A library built by scripts/build_variant.sh (kernel A/B experiments; the ablation switches of the kernel sources compute wrong
+// results on purpose) carries its variant name in the version string: tests/conftest.py refuses to run the GPU suite on such a
+// library, and a bench line records the string.
+#ifdef EDVR_VARIANT
+#define EDVR_STR2(x) #x
+#define EDVR_STR(x) EDVR_STR2(x)
+const char *edvr_version(void) { return "edvr_amd 0.4.0 (gfx950) variant:" EDVR_STR(EDVR_VARIANT); }
+#else
+const char *edvr_version(void) { return "edvr_amd 0.4.0 (gfx950)"; }
+#endif
 const char *edvr_last_error(void) { return edvr::g_err; }
 int edvr_check_device(void) {
   int dev = 0;

@@ -94,6 +94,12 @@ int dcn_fused_pack(const float *weight, float *wpk, int Co, int C, hipStream_t s
 int dcn_fused_forward(const float *x, const float *offset, const float *mask, const float *wpk, const float *bias, float *y, int B, int C,
                       int H, int W, int Co, int dg, int64_t off_bs, int64_t msk_bs, int act, int halo, hipStream_t stream);
 
+// dcn_tapwin.hip: the same operator with the staged window following each (group, tap)'s displacement: cost independent of the
+// offset magnitude for spatially smooth fields.  Takes the weights in dcn_fused_pack's layout.
+bool dcn_tapwin_supported(int C, int Co, int H, int W, int kh, int kw, int stride, int pad, int dil, int groups, int dg);
+int dcn_tapwin_forward(const float *x, const float *offset, const float *mask, const float *wpk, const float *bias, float *y, int B, int C,
+                       int H, int W, int Co, int dg, int64_t off_bs, int64_t msk_bs, int act, hipStream_t stream);
+
 // dcn_bwd_fused.hip: DCNv2 backward (dX, dOffset, dMask, forward columns) for the EDVR signature without the dcol buffer
 bool dcn_bwd_fused_supported(const DcnShape &s);
 size_t dcn_bwd_fused_wbk_elems(int dg);  // floats of the re-ordered W^T the kernel streams (workspace)

@@ -372,9 +372,13 @@ int conv2d_launch(const edvr_conv2d_desc &d, hipStream_t stream) {
     set_error("conv2d: gate together with a sigmoid epilogue is not supported");
     return EDVR_ERR_UNSUPPORTED;
   }
-  if (d.abs_sum && (conv_small_eligible(d) || !winograd_f4_eligible(d))) {
-    set_error("conv2d: abs_sum is an epilogue of the F(4x4) Winograd kernel only (ask edvr_conv2d_abs_sum_supported)");
+  if (d.abs_sum && (conv_small_eligible(d) || !winograd_f4_eligible(d) || d.out_mode != EDVR_OUT_NCHW)) {
+    set_error("conv2d: abs_sum is an epilogue of the F(4x4) Winograd kernel's NCHW store only (ask edvr_conv2d_abs_sum_supported)");
     return EDVR_ERR_UNSUPPORTED;
+  }
+  if (d.abs_diff && !d.abs_sum) {
+    set_error("conv2d: abs_diff is accumulated next to abs_sum (set both)");
+    return EDVR_ERR_ARG;
   }
   if (!d.gate && !scaled && conv_small_eligible(d)) return conv_small_launch(d, stream);
   if (winograd_f4_eligible(d)) return winograd_f4_launch(d, stream);
@@ -449,7 +453,7 @@ int edvr_conv2d_executed_flops(const edvr_conv2d_desc *d, double *flops) {
 
 int edvr_conv2d_abs_sum_supported(const edvr_conv2d_desc *d) {
   if (!d) return 0;
-  return (!edvr::conv_small_eligible(*d) && edvr::winograd_f4_eligible(*d)) ? 1 : 0;
+  return (!edvr::conv_small_eligible(*d) && edvr::winograd_f4_eligible(*d) && d->out_mode == EDVR_OUT_NCHW) ? 1 : 0;  // (the PixelShuffle store has no such sum)
 }
 
 int edvr_conv2d_gate_supported(const edvr_conv2d_desc *d) {

@@ -720,6 +720,13 @@ int edvr_dcnv2_fwd_f32(const float *x, const float *offset, const float *mask, c
   if (use_fused(s) && halo_hint >= 0) {
     rc = dcn_fused_pack(weight, wpk, Co, C, stream);
     if (rc) return rc;
+    // EDVR_DCN_HALO_TAPWIN: the window follows each tap's displacement (dcn_tapwin.hip) - needs 16-byte aligned rows; layers it
+    // does not take (odd widths, other group sizes, unaligned views) run the zero-centred halo kernel, R = 7
+    if (halo_hint == EDVR_DCN_HALO_TAPWIN) {
+      if (dcn_tapwin_supported(C, Co, H, W, kh, kw, s.stride, s.pad, s.dil, groups, dg) && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+        return dcn_tapwin_forward(x, offset, mask, wpk, bias, y, B, C, H, W, Co, dg, s.off_bs, s.msk_bs, act, stream);
+      halo_hint = 7;
+    }
     return dcn_fused_forward(x, offset, mask, wpk, bias, y, B, C, H, W, Co, dg, s.off_bs, s.msk_bs, act, halo_hint, stream);
   }
   const int cig = C / groups, cog = Co / groups;

@@ -195,11 +195,15 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ 
   }
 }
 
-__global__ __launch_bounds__(256) void abs_sum_kernel(const float *__restrict__ x, float *__restrict__ out, int64_t per_img,
-                                                      int64_t img_stride, int vec4) {
+// out[img] += sum |x|; rough (optional, vec4 only) [img] += sum |x[i] - x[i + 1]| over the three neighbour pairs inside every aligned
+// group of four elements (rows are multiples of 4 wide there: 3 of every 4 horizontal neighbour pairs, never across a row end)
+template <bool ROUGH>
+__global__ __launch_bounds__(256) void abs_sum_kernel(const float *__restrict__ x, float *__restrict__ out, float *__restrict__ rough,
+                                                      int64_t per_img, int64_t img_stride, int vec4) {
   const int img = blockIdx.y;
   const float *src = x + (int64_t)img * img_stride;
-  float s = 0.f;
+  float s = 0.f, r = 0.f;
+  auto diff4 = [](const float4 &a) { return (fabsf(a.x - a.y) + fabsf(a.y - a.z)) + fabsf(a.z - a.w); };
   if (vec4) {  // 16-byte loads, two in flight per thread (the scalar loop ran at 2.4 TB/s)
     const float4 *s4 = reinterpret_cast<const float4 *>(src);
     const int64_t n4 = per_img >> 2, step = (int64_t)gridDim.x * 256;
@@ -209,21 +213,36 @@ __global__ __launch_bounds__(256) void abs_sum_kernel(const float *__restrict__ 
       const float4 a = s4[i], b = s4[i + step];
       s += (fabsf(a.x) + fabsf(a.y)) + (fabsf(a.z) + fabsf(a.w));
       s2 += (fabsf(b.x) + fabsf(b.y)) + (fabsf(b.z) + fabsf(b.w));
+      if (ROUGH) r += diff4(a) + diff4(b);
     }
     if (i < n4) {
       const float4 a = s4[i];
       s += (fabsf(a.x) + fabsf(a.y)) + (fabsf(a.z) + fabsf(a.w));
+      if (ROUGH) r += diff4(a);
     }
     s += s2;
   } else {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_img; i += (int64_t)gridDim.x * 256) s += fabsf(src[i]);
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-  __shared__ float red[4];
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_down(s, o, 64);
+    if (ROUGH) r += __shfl_down(r, o, 64);
+  }
+  __shared__ float red[8];
+  if ((threadIdx.x & 63) == 0) {
+    red[threadIdx.x >> 6] = s;
+    red[4 + (threadIdx.x >> 6)] = r;
+  }
   __syncthreads();
-  if (threadIdx.x == 0) unsafeAtomicAdd(out + img, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    unsafeAtomicAdd(out + img, red[0] + red[1] + red[2] + red[3]);
+    if (ROUGH) unsafeAtomicAdd(rough + img, red[4] + red[5] + red[6] + red[7]);
+  }
+}
+
+__global__ void fill_f32_kernel(float *p, float v, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = v;
 }
 
 static inline unsigned grid_for(int64_t total) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv64(total, 256), 256 * 16)); }
@@ -307,7 +326,25 @@ int edvr_abs_sum_f32(const float *x, float *out, int n, int64_t per_img, int64_t
   }
   const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv64(per_img, 256 * 8), 512));
   const int vec4 = (per_img & 3) == 0 && (img_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
-  hipLaunchKernelGGL(abs_sum_kernel, dim3(gx, n), dim3(256), 0, as_stream(stream), x, out, per_img, img_stride, vec4);
+  hipLaunchKernelGGL(abs_sum_kernel<false>, dim3(gx, n), dim3(256), 0, as_stream(stream), x, out, static_cast<float *>(nullptr), per_img, img_stride, vec4);
+  return check_launch("abs_sum_kernel");
+}
+
+int edvr_abs_stats_f32(const float *x, float *out, int n, int64_t per_img, int w, int64_t img_stride, edvr_stream_t stream) {
+  using namespace edvr;
+  EDVR_REQUIRE(x && out && n > 0 && per_img > 0 && w > 0 && per_img % w == 0, "abs_stats: bad arguments");
+  if (hipMemsetAsync(out, 0, sizeof(float) * 2 * n, as_stream(stream)) != hipSuccess) {
+    set_error("abs_stats: hipMemsetAsync failed");
+    return EDVR_ERR_LAUNCH;
+  }
+  const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv64(per_img, 256 * 8), 512));
+  const int vec4 = (w & 3) == 0 && (img_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+  if (vec4) {
+    hipLaunchKernelGGL(abs_sum_kernel<true>, dim3(gx, n), dim3(256), 0, as_stream(stream), x, out, out + n, per_img, img_stride, 1);
+  } else {  // rows that are not whole 16-byte groups: the sums only, the differences are reported as unknown (-1)
+    hipLaunchKernelGGL(abs_sum_kernel<false>, dim3(gx, n), dim3(256), 0, as_stream(stream), x, out, static_cast<float *>(nullptr), per_img, img_stride, 0);
+    hipLaunchKernelGGL(fill_f32_kernel, dim3(1), dim3(256), 0, as_stream(stream), out + n, -1.f, n);
+  }
   return check_launch("abs_sum_kernel");
 }
 

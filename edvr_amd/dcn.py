@@ -48,9 +48,9 @@ class ModulatedDeformConvFunction(Function):
         input, offset, mask, weight, out = ctx.saved_tensors
         if ctx.act != ops.ACT_NONE:
             grad_output = ops.act_backward(grad_output, out, ctx.act)
-        from .functional import scatter_hint_from_absmean
-        absmean = ops.abs_mean_if_ready(ctx.offset_stat)
-        hint = scatter_hint_from_absmean(absmean) if absmean is not None else ops.DCN_SCATTER_AUTO
+        from .functional import scatter_hint_from_stats
+        st = ops.offset_stats_if_ready(ctx.offset_stat)  # (EDVR_DCN_HINT_WAIT=1: waits, so the kernel choice is deterministic)
+        hint = scatter_hint_from_stats(*st) if st is not None else ops.DCN_SCATTER_AUTO
         dx, doff, dmsk, dw, db = ops.dcnv2_backward(input, offset, mask, weight, grad_output, ctx.with_bias, *ctx.cfg, scatter_hint=hint)
         return dx, doff, dmsk, dw, db, None, None, None, None, None, None
 

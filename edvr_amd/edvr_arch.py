@@ -198,9 +198,29 @@ class EDVR(nn.Module):
         self.conv_last = _conv3(64, 3)
         self.lrelu = nn.LeakyReLU(negative_slope=0.1, inplace=True)
         self.taps = None  # set to a dict to collect intermediates (parity tests)
-        self._pending_offset_stats = []  # (pinned host tensor, copy-done event, per-layer records) of earlier no-grad forwards
         self._conv_weights = None         # conv weight Parameters (collected at the first training forward)
+        self._conv_meta = None
         self._captured_offset_stats = None
+
+    # Offset statistics of earlier no-grad forwards still on their way to the host: (pinned host tensor, copy-done event, per-layer
+    # records) per forward.  Kept OUTSIDE the module's __dict__ (a torch.cuda.Event can neither be pickled nor deep-copied:
+    # copy.deepcopy(net) for an EMA copy or torch.save(net) right after an eval forward must keep working) in a registry keyed by
+    # the module; a copy starts with an empty queue.
+    _PENDING = __import__('weakref').WeakKeyDictionary()
+
+    @property
+    def _pending_offset_stats(self):
+        q = EDVR._PENDING.get(self)
+        if q is None:
+            q = EDVR._PENDING[self] = []
+        return q
+
+    def train(self, mode=True):
+        """Switching between train() and eval() first evaluates what the forwards so far have queued (one wait for the last copy):
+        the `Offset abs mean ... larger than 50` warning of the final clip of an inference run is then logged at the latest when the
+        caller leaves eval mode - or call check_offsets() right after the last clip."""
+        self.check_offsets(wait=True)
+        return super().train(mode)
 
     def forward(self, x):
         b, t, c, h, w = x.shape
@@ -214,8 +234,12 @@ class EDVR(nn.Module):
         if torch.is_grad_enabled() and x.is_cuda:
             # training: the optimizer has rewritten every weight - all packed layouts of all conv layers in one launch (ops.py)
             if self._conv_weights is None:
-                self._conv_weights = [m.weight for m in self.modules() if isinstance(m, nn.Conv2d)]
-            F_.ops.prepack_conv_weights(self._conv_weights)
+                convs = [m for m in self.modules() if isinstance(m, nn.Conv2d)]
+                self._conv_weights = [m.weight for m in convs]
+                # (F(4x4) forward layout: stride-1 convs only; flipped layouts: not for the convs that read the input frames)
+                first = self.predeblur.conv_first if self.with_predeblur else self.conv_first
+                self._conv_meta = [(m.stride[0] == 1, m is not first) for m in convs]
+            F_.ops.prepack_conv_weights(self._conv_weights, self._conv_meta)
         frames = x.view(b * t, c, h, w)
         if self.with_predeblur:
             f1 = F_.conv(self.conv_1x1, self.predeblur(frames))
@@ -266,7 +290,7 @@ class EDVR(nn.Module):
         if not sink:
             return
         import torch
-        sums = torch.stack([e[0] for e in sink]).view(len(sink), b, t).sum(1)  # (layers, t), on the device
+        sums = torch.stack([e[0] for e in sink]).view(len(sink), 2, b, t).sum(2)  # (layers, {|offset|, roughness}, t), on the device
         recs = [(per_img * b, module) for _, per_img, module in sink]
         if torch.cuda.is_current_stream_capturing():  # hipGraph capture (edvr_amd/graphs.py): the sums are outputs of the graph,
             self._captured_offset_stats = (sums, recs)  # read back on demand by GraphedEDVR.check_offsets
@@ -284,7 +308,10 @@ class EDVR(nn.Module):
 
     def check_offsets(self, wait=True):
         """Evaluate the `Offset abs mean is ..., larger than 50` check of the no-grad forwards issued so far.  wait=False only
-        looks at forwards whose statistics have already arrived on the host (never blocks)."""
+        looks at forwards whose statistics have already arrived on the host (never blocks).  A no-grad forward never waits for the
+        GPU, so its own check is evaluated by the NEXT forward, by train() / eval(), or by this method: call it after the final
+        clip of an inference run (the reference logs inside every call, arch_util.py:248-253).  The per-layer kernel hints
+        (last_offset_absmean / last_offset_rough) are updated at the same moment, i.e. one forward late in a streaming loop."""
         while self._pending_offset_stats:
             host, done, recs = self._pending_offset_stats[0]
             if wait:
@@ -297,7 +324,9 @@ class EDVR(nn.Module):
     @staticmethod
     def _examine_offsets(sums, recs):
         for li, (count, module) in enumerate(recs):
-            per_frame = (sums[li] / count).tolist()
+            per_frame = (sums[li, 0] / count).tolist()
             module.last_offset_absmean = sum(per_frame) / len(per_frame)
+            rough = float(sums[li, 1].sum())
+            module.last_offset_rough = rough / (0.75 * count * len(per_frame)) if rough >= 0 else None
             for v in per_frame:
                 warn_offset_absmean(v)

@@ -51,13 +51,14 @@ def conv(m, x, *, x2=None, x2_map=None, act=ACT_NONE, act_from=0, res1=None, res
 
 
 def offset_mask_conv_stats(conv_offset, feat):
-    """offset_mask_conv + the per-image sums of |offset| that DCNv2Pack's `> 50` check needs (arch_util.py:248-253) -> (om, sums).
-    Without gradients the sums come out of the conv's own epilogue (no second pass over the offsets) where the layer runs on the
-    F(4x4) kernel; the training path and small layers use the separate reduction kernel."""
+    """offset_mask_conv + the per-image statistics of the offsets -> (om, stats (2, n)): row 0 = sums of |offset|, what DCNv2Pack's
+    `> 50` check needs (arch_util.py:248-253), row 1 = sums of horizontal neighbour differences (the field's roughness: which DCN
+    kernel suits it, `halo_hint_from_stats`).  Without gradients they come out of the conv's own epilogue (no second pass over
+    the offsets) where the layer runs on the F(4x4) kernel; the training path and small layers use the separate reduction kernel."""
     co = conv_offset.out_channels
     if _needs_grad(feat, conv_offset.weight, conv_offset.bias):
         om = offset_mask_conv(conv_offset, feat)
-        return om, ops.abs_sum_per_image(om.detach()[:, :2 * co // 3])
+        return om, ops.abs_stats_per_image(om.detach()[:, :2 * co // 3])
     return conv(conv_offset, feat, act=ACT_SIGMOID, act_from=2 * co // 3, abs_sum_channels=2 * co // 3)
 
 
@@ -69,30 +70,55 @@ def offset_mask_conv(conv_offset, feat):
     return conv(conv_offset, feat, act=ACT_SIGMOID, act_from=2 * co // 3)
 
 
-def halo_hint_from_absmean(absmean):
-    """Halo class of the fused DCN kernel from the mean |offset| seen on the PREVIOUS call of the same layer
-    (a performance hint only).  |offset| ~ N(0, s): mean = 0.8 s; R covers ~2.4 s for R = 3 at mean 1."""
-    if absmean is None or absmean < 1.2:
+SMOOTH_ROUGHNESS = 0.45  # mean |offset[x] - offset[x + 1]| below which a field counts as spatially smooth: white noise of sigma 0.4
+#                          (1.13 sigma) leaves the +-1.5 px slack of a shifted window on 1e-4 of the taps; sigma 0.5 on 3e-3, i.e. on some
+#                          lane of every sixth (wave, step)
+TAPWIN_MIN_ABSMEAN = float(__import__('os').environ.get('EDVR_DCN_TAPWIN_MIN_ABSMEAN', '0'))  # smooth fields below this mean |offset| stay on the zero-centred halo kernel
+
+
+def halo_hint_from_stats(absmean, rough):
+    """Kernel class of the fused DCNv2 forward from the statistics of the PREVIOUS call of the same layer (a performance hint only):
+    `absmean` = mean |offset|, `rough` = mean |horizontal neighbour difference| (None = unknown).  A spatially smooth field - what
+    conv_offset produces once trained: per-tap displacements of any size that vary slowly across the image - runs on the kernel whose
+    staged window follows every tap's displacement (csrc/dcn_tapwin.hip: cost independent of the magnitude).  A rough field keeps the
+    zero-centred halo while it is small (|offset| ~ N(0, s): mean = 0.8 s; R covers ~2.4 s for R = 3 at mean 1) and the
+    column-buffer path beyond."""
+    if absmean is None:
+        return 3
+    if rough is not None and rough < SMOOTH_ROUGHNESS and absmean >= TAPWIN_MIN_ABSMEAN:
+        return ops.DCN_HALO_TAPWIN
+    if absmean < 1.2:
         return 3
     return 7 if absmean < 3.0 else -1
 
 
-def scatter_hint_from_absmean(absmean):
-    """How the DCNv2 backward accumulates dx (include/edvr_amd.h EDVR_DCN_SCATTER_*), from the mean |offset| of the layer's
-    latest forward.  Sub-pixel offsets (fresh or lightly trained conv_offset): the register-ring kernel, which needs no scatter
-    for taps with |offset| < 1 (one wave per 64-column strip of a channel plane).  Anything larger goes through the LDS
-    window, whose cost does not depend on the offset field (6x faster than device atomics on a white-noise field)."""
+def halo_hint_from_absmean(absmean):
+    return halo_hint_from_stats(absmean, None)
+
+
+def scatter_hint_from_stats(absmean, rough):
+    """How the DCNv2 backward accumulates dx (include/edvr_amd.h EDVR_DCN_SCATTER_*), from the statistics of the layer's latest forward.
+    Sub-pixel offsets (fresh or lightly trained conv_offset): the kernels that need no scatter for taps with |offset| < 1.  Larger
+    but spatially SMOOTH offsets (a trained conv_offset): device atomics - neighbouring pixels hit neighbouring addresses, so the
+    atomics coalesce in L2 at any displacement, as in the reference's col2im (.cu:688).  Rough fields go through the LDS window,
+    whose cost does not depend on the offset field (6x faster than device atomics on a white-noise field)."""
     if absmean is None:
         return ops.DCN_SCATTER_LDS
     if absmean < 0.4:  # white-noise offsets of sigma 0.5 (|mean| 0.4): 9 % of the taps already leave the sub-pixel window
         return ops.DCN_SCATTER_STRIP
+    if rough is not None and rough < SMOOTH_ROUGHNESS:
+        return ops.DCN_SCATTER_DEVICE
     return ops.DCN_SCATTER_DEVICE if absmean < 0.75 else ops.DCN_SCATTER_LDS
+
+
+def scatter_hint_from_absmean(absmean):
+    return scatter_hint_from_stats(absmean, None)
 
 
 def dcn_from_packed(m, x, om, act=ACT_NONE):
     """Modulated deformable conv of module `m` (weight/bias/geometry) with offsets+masks packed in `om`."""
     cfg = (m.stride, m.padding, m.dilation, m.groups, m.deformable_groups)
-    hint = halo_hint_from_absmean(getattr(m, 'last_offset_absmean', None))
+    hint = halo_hint_from_stats(getattr(m, 'last_offset_absmean', None), getattr(m, 'last_offset_rough', None))
     if _needs_grad(x, om, m.weight, m.bias):
         from . import autograd as ag
         return ag.DcnFromPackedFn.apply(x, om, m.weight, m.bias, (*cfg, act, hint, m))

@@ -11,8 +11,9 @@ of ~170 short kernels (>= 15 us each), which a graph replays as it is.
     out = g(clip)                           # copy into the static input, replay, returns the static output tensor (see `clone`)
     g.check_offsets()                       # the `Offset abs mean ... larger than 50` check of the LAST replay (arch_util.py:248-253)
 
-What a replay freezes: shapes, the packed weights (replays keep using the layouts packed at capture time: call `refresh()` after
-changing parameters - `__call__` checks the parameters' version counters and refuses to replay stale weights), and the per-layer
+What a replay freezes: shapes, the packed weights (replays keep using the layouts packed at capture time - the graph holds those
+buffers and pins them against the training path's in-place re-packing: call `refresh()` after changing parameters - `__call__`
+checks the parameters' version counters and refuses to replay stale weights), and the per-layer
 performance hints (halo class of the fused DCN kernel): results do not depend on them.
 """
 import torch
@@ -25,15 +26,22 @@ class GraphedEDVR:
         self.net, self.clone, self.check_weights = net, clone, check_weights
         self.static_in = example.detach().clone()
         self._stream = torch.cuda.Stream(device=example.device)
+        self._pinned = []
         self._capture(warmup)
+
+    def __del__(self):
+        from . import ops
+        ops.unpin_packed_weights(getattr(self, '_pinned', []))
 
     def _versions(self):
         return sum(p._version for p in self.net.parameters())
 
     def _capture(self, warmup):
+        from . import ops
         net, s = self.net, self._stream
         was_training = net.training
         net.eval()
+        ops.unpin_packed_weights(self._pinned)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s), torch.no_grad():
             for _ in range(max(1, warmup)):  # on the capture stream: its workspace (ops.workspace is per stream) exists before the capture
@@ -43,6 +51,9 @@ class GraphedEDVR:
             with torch.cuda.graph(self.graph, stream=s):
                 self.static_out = net(self.static_in)
         torch.cuda.current_stream().wait_stream(s)
+        # the captured launches read the packed weight layouts of THIS moment: hold them and keep the training path's in-place
+        # re-packing (ops.prepack_conv_weights) off them - a later optimizer step then packs into fresh buffers
+        self._pinned = ops.pin_packed_weights([p for p in net.parameters() if p.dim() == 4])
         self._offset_stats = getattr(net, '_captured_offset_stats', None)
         net._captured_offset_stats = None
         self._ver = self._versions()

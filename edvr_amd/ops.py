@@ -127,16 +127,52 @@ def pack_conv_weight(weight, transpose_flip=False, f4=False):
 _PACK_TABLES = {}  # job signature -> (device table, total blocks): the table of a training iteration never changes
 
 
-def prepack_conv_weights(weights):
+_PINNED_PACKED = set()  # data_ptr()s of packed buffers somebody outside the cache relies on (a captured hipGraph): never rewritten
+
+
+def pin_packed_weights(weights):
+    """Keep the CURRENT packed layouts of `weights` alive and unmodified: returns the list of buffers (hold it as long as they are
+    needed - e.g. a captured hipGraph whose launches read them, edvr_amd/graphs.py) after registering them so that
+    prepack_conv_weights allocates fresh buffers instead of rewriting these.  Release with unpin_packed_weights(list)."""
+    bufs = []
+    for w in weights:
+        ent = _PACKED.get(id(w))
+        if ent is not None and ent[0]() is w:
+            bufs.extend(hit[1] for hit in ent[1].values())
+    _PINNED_PACKED.update(b.data_ptr() for b in bufs)
+    return bufs
+
+
+def unpin_packed_weights(bufs):
+    for b in bufs:
+        _PINNED_PACKED.discard(b.data_ptr())
+
+
+def _sole_owner(hit):
+    """The cache entry `hit` = (version, buffer, pointer) is the only holder of its buffer: no other Python reference, no view, no
+    C++ holder (autograd node, graph), not pinned.  Only then may the buffer be rewritten in place."""
+    import sys
+    return hit[1]._use_count() == 1 and sys.getrefcount(hit[1]) == 2 and hit[1].data_ptr() not in _PINNED_PACKED
+
+
+def prepack_conv_weights(weights, meta=None):
     """Fill the packed-weight cache for a whole network in ONE launch (edvr_conv2d_pack_weights_multi): every (weight, orientation)
     the training step will ask pack_conv_weight / f4_weight for whose cached copy is stale - after an optimizer step: all of them,
-    ~480 separate ~5 us launches otherwise.  `weights`: iterable of conv weight Parameters (3x3 or 1x1).  Purely an optimisation:
-    whatever is not packed here is packed lazily, one launch per request, as before.  Packed buffers are rewritten in place (the
-    launch is ordered behind their last readers on the current stream), so the job table is built and uploaded once."""
+    ~480 separate ~5 us launches otherwise.  `weights`: iterable of conv weight Parameters (3x3 or 1x1); `meta` (optional, same
+    length): (forward_f4, data_gradient) per weight - False skips layouts the autograd path never requests (the F(4x4) forward
+    layout of a stride-2 conv, the flipped layouts of a conv whose input needs no gradient).  Purely an optimisation: whatever is
+    not packed here is packed lazily, one launch per request, as before.
+    A stale buffer is REWRITTEN IN PLACE when the cache is its only owner (`_sole_owner`: nobody else holds the tensor, it is not
+    pinned by a captured graph), so that the job table is built and uploaded once; otherwise a fresh buffer is allocated and the
+    old one stays as it was for whoever holds it.  The rewrite is ordered behind the buffer's readers on the CURRENT stream only:
+    work queued on another stream that still reads a packed layout must be synchronised with by the caller (single-stream
+    assumption of the training loop; GraphedEDVR pins its layouts instead)."""
     import numpy as np
     L = _lib.lib()
     jobs, sig, filled = [], [], []
-    for w in weights:
+    meta = list(meta) if meta is not None else None
+    for wi, w in enumerate(weights):
+        fwd_f4, dgrad = meta[wi] if meta is not None else (True, True)
         if not w.is_cuda or w.dtype != torch.float32 or w.dim() != 4 or w.shape[2] != w.shape[3] or w.shape[2] not in (1, 3) or not w.is_contiguous():
             continue
         wid, ver, k = id(w), w._version, w.shape[2]
@@ -144,9 +180,9 @@ def prepack_conv_weights(weights):
         if ent is None or ent[0]() is not w:
             ent = (weakref.ref(w, lambda _r, wid=wid: _PACKED.pop(wid, None)), {})
             _PACKED[wid] = ent
-        for flip in (False, True):
+        for flip in ((False, True) if dgrad else (False,)):
             co, ci = (w.shape[1], w.shape[0]) if flip else (w.shape[0], w.shape[1])
-            want_f4 = F4_TRAINING and k == 3 and ci >= 32 and co >= 48  # = f4_weight()
+            want_f4 = F4_TRAINING and k == 3 and ci >= 32 and co >= 48 and (flip or fwd_f4)  # = f4_weight()
             outs = []
             for f4 in ((False, True) if want_f4 else (False,)):
                 hit = ent[1].get((flip, f4))
@@ -154,7 +190,7 @@ def prepack_conv_weights(weights):
                     outs.append(None)  # current
                     continue
                 n = L.edvr_conv2d_packed_weight_f4_elems(co, ci) if f4 else L.edvr_conv2d_packed_weight_elems(co, ci, k)
-                buf = hit[1] if (hit is not None and hit[1].numel() == n and hit[1].device == w.device) else \
+                buf = hit[1] if (hit is not None and hit[1].numel() == n and hit[1].device == w.device and _sole_owner(hit)) else \
                     torch.empty(n, dtype=torch.float32, device=w.device)
                 outs.append(buf)
                 filled.append((ent, (flip, f4), ver, buf, w.data_ptr()))
@@ -205,6 +241,7 @@ def invalidate_packed_weights():
 
 # ------------------------------------------------------------------------------------------------ conv
 DCN_SCATTER_AUTO, DCN_SCATTER_DEVICE, DCN_SCATTER_LDS, DCN_SCATTER_STRIP = 0, 1, 2, 3  # include/edvr_amd.h EDVR_DCN_SCATTER_*
+DCN_HALO_TAPWIN = _lib.DCN_HALO_TAPWIN  # halo_hint of dcnv2_forward: per-tap shifted windows (csrc/dcn_tapwin.hip)
 LAUNCH_HOOK = None  # callable(kernel_name, algorithmic_flops, launch_fn, algorithmic_bytes) or None
 CONV_ALGO = CONV_AUTO  # default algorithm request of conv2d(); tests flip it to cover both kernels on every shape
 F4_INFERENCE = os.environ.get('EDVR_WINOGRAD_F4', '1') != '0'  # functional.conv hands the F(4x4,3x3) weights to no-grad convs
@@ -236,8 +273,9 @@ def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NON
     gate (n, co, ho, wo): y *= gate > 0 ? 1 : gate_slope - the backward of a ReLU / LeakyReLU fused into the data-gradient conv
     (3x3 kernels; in the Winograd kernel's epilogue where that kernel applies, else in the direct kernel's).
     y_scale: ResidualBlockNoBN's res_scale (arch_util.py:95), 3x3 kernels only.
-    abs_sum_channels > 0: returns (y, sums) with sums[i] = sum |y[i, :abs_sum_channels]| - in the conv's own epilogue where the
-    launch runs on the F(4x4) kernel (edvr_conv2d_desc.abs_sum), by the separate abs_sum kernel otherwise.
+    abs_sum_channels > 0: returns (y, stats) with stats (2, n) = abs_stats_per_image(y[:, :abs_sum_channels]) (sums of |y| and of the
+    horizontal neighbour differences) - in the conv's own epilogue where the launch runs on the F(4x4) kernel
+    (edvr_conv2d_desc.abs_sum / abs_diff), by the separate reduction kernel otherwise.
     """
     require_gpu(x1, x2, wpk, bias, res1, res2)
     L = _lib.lib()
@@ -285,9 +323,9 @@ def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NON
         d.wpk_f4 = _ptr(wpk_f4)
     d.algo = CONV_ALGO if algo is None else algo
     sums = None
-    if abs_sum_channels > 0 and out_mode == OUT_NCHW and L.edvr_conv2d_abs_sum_supported(ctypes.byref(d)):
-        sums = torch.zeros(n, dtype=torch.float32, device=x1.device)
-        d.abs_sum, d.abs_sum_channels = _ptr(sums), int(abs_sum_channels)
+    if abs_sum_channels > 0 and L.edvr_conv2d_abs_sum_supported(ctypes.byref(d)):
+        sums = torch.zeros(2, n, dtype=torch.float32, device=x1.device)
+        d.abs_sum, d.abs_sum_channels, d.abs_diff = _ptr(sums), int(abs_sum_channels), _ptr(sums[1])
     name, flops, nbytes, executed = 'conv2d', 0.0, 0.0, None
     if LAUNCH_HOOK is not None:  # measurement only (bench.py): brackets the launch with events on this stream
         buf = ctypes.create_string_buffer(96)
@@ -302,7 +340,7 @@ def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NON
                         + co * (c1 + d.c2) * ks * ks)
     _run(name, lambda: _lib.check(L.edvr_conv2d_f32(ctypes.byref(d), _stream()), 'edvr_conv2d_f32'), flops, nbytes, executed)
     if abs_sum_channels > 0:
-        return out, (sums if sums is not None else abs_sum_per_image(out[:, :abs_sum_channels]))
+        return out, (sums if sums is not None else abs_stats_per_image(out[:, :abs_sum_channels]))
     return out
 
 
@@ -355,7 +393,8 @@ def dcnv1_backward(x, offset, weight, dy, stride, pad, dil, groups, dg, scatter_
     ws = workspace(nbytes, x.device)
     _run('dcnv1_bwd', lambda: _lib.check(L.edvr_dcnv1_bwd_f32(_ptr(x), _ptr(offset), _ptr(weight), _ptr(dy), _ptr(dx), _ptr(doff), _ptr(dw), *dims,
                                     _bstride(offset), _bstride(doff), int(scatter_hint), _ptr(ws), nbytes, _stream()),
-                                       'edvr_dcnv1_bwd_f32'), 6.0 * dy.numel() * weight[0].numel(), _nb(x, offset, weight, dy, dx, doff, dw))
+                                       'edvr_dcnv1_bwd_f32'), 4.0 * dy.numel() * weight[0].numel(),  # two GEMMs (dcol, dW)
+                                       _nb(x, offset, weight, dy, dx, doff, dw))
     return dx, doff, dw
 
 
@@ -443,7 +482,7 @@ def dcnv2_backward(x, offset, mask, weight, dy, with_bias, stride, pad, dil, gro
     _run('dcnv2_bwd', lambda: _lib.check(L.edvr_dcnv2_bwd_f32(_ptr(x), _ptr(offset), _ptr(mask), _ptr(weight), _ptr(dy), _ptr(dx), _ptr(doff), _ptr(dmsk),
                                     _ptr(dw), _ptr(db), *dims, _bstride(offset), _bstride(mask), _bstride(doff), _bstride(dmsk),
                                     int(scatter_hint), _ptr(ws), nbytes, _stream()),
-                                       'edvr_dcnv2_bwd_f32'), 6.0 * dy.numel() * weight[0].numel(), _nb(x, offset, mask, weight, dy, dx, doff, dmsk, dw))
+                                       'edvr_dcnv2_bwd_f32'), 4.0 * dy.numel() * weight[0].numel(), _nb(x, offset, mask, weight, dy, dx, doff, dmsk, dw))
     return dx, doff, dmsk, dw, db
 
 
@@ -660,10 +699,12 @@ def charbonnier(pred, target, eps=1e-12, want_grad=True, grad_scale=1.0):
 
 
 def note_abs_mean(x):
-    """Start computing mean |x| of a (n, c, h, w) float32 tensor without waiting for it: per-image sums -> pinned memory behind an
-    event.  `abs_mean_if_ready` returns the value once it has arrived (None before) - how a backward picks up the offset statistic
-    of its own forward without a host synchronisation."""
-    sums = abs_sum_per_image(x)
+    """Start computing the offset statistics (mean |x| and the roughness, `offset_stats`) of a (n, c, h, w) float32 tensor without
+    waiting for them: per-image sums -> pinned memory behind an event.  `abs_mean_if_ready` / `offset_stats_if_ready` return the
+    values once they have arrived (None before) - how a backward picks up the statistic of its own forward without a host
+    synchronisation.  EDVR_DCN_HINT_WAIT=1 makes the pick-up wait for the copy instead (deterministic kernel choice, for
+    bisecting timings or rounding-level differences; costs one host synchronisation per backward)."""
+    sums = abs_stats_per_image(x)
     host = torch.empty(sums.shape, dtype=sums.dtype, pin_memory=True)
     host.copy_(sums, non_blocking=True)
     done = torch.cuda.Event()
@@ -671,10 +712,30 @@ def note_abs_mean(x):
     return host, done, x.numel()
 
 
-def abs_mean_if_ready(rec):
-    if rec is None or not rec[1].query():
+HINT_WAIT = os.environ.get('EDVR_DCN_HINT_WAIT', '0') == '1'
+
+
+def offset_stats_if_ready(rec):
+    """(mean |x|, roughness or None) of a `note_abs_mean` record, or None while the copy has not landed."""
+    if rec is None:
         return None
-    return float(rec[0].sum()) / rec[2]
+    if HINT_WAIT:
+        rec[1].synchronize()
+    elif not rec[1].query():
+        return None
+    return offset_stats(rec[0], rec[2])
+
+
+def abs_mean_if_ready(rec):
+    st = offset_stats_if_ready(rec)
+    return None if st is None else st[0]
+
+
+def offset_stats(stats, count):
+    """(mean |offset|, mean |horizontal neighbour difference| or None) from the (2, n) sums of `abs_stats_per_image` over `count`
+    elements in all.  The difference sum covers 3 of every 4 horizontal pairs (include/edvr_amd.h, abs_diff)."""
+    tot = stats.double().sum(-1).tolist() if stats.dim() == 2 else [float(stats.double().sum()), -1.0]
+    return tot[0] / count, (tot[1] / (0.75 * count) if tot[1] >= 0 else None)
 
 
 def abs_sum_per_image(x):
@@ -685,6 +746,18 @@ def abs_sum_per_image(x):
     out = torch.empty(n, dtype=torch.float32, device=x.device)
     _run('abs_sum', lambda: _lib.check(_lib.lib().edvr_abs_sum_f32(_ptr(x), _ptr(out), n, c * h * w, _img_stride(x), _stream()),
                                        'edvr_abs_sum_f32'), 0, _nb(x))
+    return out
+
+
+def abs_stats_per_image(x):
+    """(2, n): row 0 = sum |x[i]| per image, row 1 = sum |x[i, c, r, col] - x[i, c, r, col + 1]| over 3 of every 4 horizontal
+    neighbour pairs (edvr_abs_stats_f32; -1 where the rows are not whole 16-byte groups) of a (n, c, h, w) tensor."""
+    require_gpu(x)
+    x = _as_planes(x)
+    n, c, h, w = x.shape
+    out = torch.empty(2, n, dtype=torch.float32, device=x.device)
+    _run('abs_sum', lambda: _lib.check(_lib.lib().edvr_abs_stats_f32(_ptr(x), _ptr(out), n, c * h * w, w, _img_stride(x), _stream()),
+                                       'edvr_abs_stats_f32'), 0, _nb(x))
     return out
 
 

@@ -60,6 +60,7 @@ int edvr_check_device(void);
 #define EDVR_ACT_LRELU 2 /* negative slope 0.1 (edvr_arch.py:70,157,248,356) */
 #define EDVR_ACT_SIGMOID 3
 
+#define EDVR_DCN_HALO_TAPWIN 16 /* halo_hint of edvr_dcnv2_fwd_f32 / edvr_dcnv1_fwd_f32: per-tap shifted windows (below) */
 #define EDVR_DCN_SCATTER_AUTO 0
 #define EDVR_DCN_SCATTER_DEVICE 1
 #define EDVR_DCN_SCATTER_LDS 2
@@ -122,8 +123,14 @@ typedef struct edvr_conv2d_desc {
                            * atomics in the epilogue (the caller zeroes the array; summation order is not deterministic).  This is the
                            * statistic behind DCNv2Pack's "Offset abs mean is ..., larger than 50" check (arch_util.py:248-253) taken
                            * where conv_offset's output is still in registers instead of re-reading it (edvr_abs_sum_f32).  Only the
-                           * F(4x4) kernel has this epilogue: ask edvr_conv2d_abs_sum_supported; EDVR_ERR_UNSUPPORTED otherwise. */
+                           * F(4x4) kernel has this epilogue, in its NCHW store only (EDVR_OUT_PIXEL_SHUFFLE2 has none): ask
+                           * edvr_conv2d_abs_sum_supported; EDVR_ERR_UNSUPPORTED otherwise.  The sum is taken over conv + bias (+ the
+                           * activation of channels >= act_from), BEFORE gate, y_scale and the residuals are applied. */
   int abs_sum_channels;
+  float *abs_diff;        /* optional (n), with abs_sum only: abs_diff[i] += sum |y[i, c, r, x] - y[i, c, r, x + 1]| over the same channels
+                           * for the three horizontal neighbour pairs inside every aligned group of four columns (3 of every 4 pairs) -
+                           * the ROUGHNESS of the offset field.  Together with abs_sum it tells which DCN kernel suits the layer:
+                           * a smooth field of any magnitude runs on the per-tap windows (EDVR_DCN_HALO_TAPWIN), a rough one does not. */
 } edvr_conv2d_desc;
 
 size_t edvr_conv2d_packed_weight_elems(int co, int ci, int ks);
@@ -177,7 +184,12 @@ int edvr_conv2d_executed_flops(const edvr_conv2d_desc *d, double *flops);
  * halo_hint: performance hint only (results are identical for every value).  The EDVR signature (3x3, stride 1, pad 1,
  * dil 1, groups 1, (C/dg) % 8 == 0) runs a fused kernel that stages an input halo of R pixels around each tile in LDS
  * and falls back to global gathers for taps that leave it: 0 or 3 -> R = 3 (|offset| mostly < 3), 7 -> R = 7,
- * -1 -> skip the fused kernel (generic column-buffer path; always used for other signatures). */
+ * -1 -> skip the fused kernel (generic column-buffer path; always used for other signatures).
+ * EDVR_DCN_HALO_TAPWIN (16) -> csrc/dcn_tapwin.hip: the walk is (group, tap, channel pair) and the staged window of every
+ * (group, tap) is centred on that tap's displacement over the tile, so the cost does not depend on the offset MAGNITUDE as long as
+ * the field is spatially smooth (+-2 px inside an 8 x 32 pixel tile) - what a trained conv_offset produces, and what the
+ * reference's gather costs at any offset (.cu:570-633).  Needs W % 4 == 0, W >= 32, 8 or 16 channels per deformable group,
+ * dg <= 16 and a 16-byte aligned x; otherwise the R = 7 kernel runs. */
 size_t edvr_dcnv2_fwd_ws_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil,
                                int groups, int dg);
 int edvr_dcnv2_fwd_f32(const float *x, const float *offset, const float *mask, const float *weight,
@@ -270,6 +282,10 @@ int edvr_act_bwd_f32(const float *dy, const float *y, const float *res1, const f
 /* out[i] = sum |x[i, :per_img]| for each of n images (image stride img_stride) - feeds the
  * "offset abs mean > 50" warning of arch_util.py:248-253 without a per-call host sync. */
 int edvr_abs_sum_f32(const float *x, float *out, int n, int64_t per_img, int64_t img_stride, edvr_stream_t stream);
+/* The same sums in out[0 .. n) plus, in out[n .. 2n), sum |x[i, c, r, col] - x[i, c, r, col + 1]| over the three neighbour pairs inside
+ * every aligned group of four columns of the w-wide rows (the roughness statistic of edvr_conv2d_desc.abs_diff; per_img % w == 0).
+ * Rows that are not whole 16-byte groups (w % 4 != 0 or unaligned views): out[n .. 2n) = -1 (unknown). */
+int edvr_abs_stats_f32(const float *x, float *out, int n, int64_t per_img, int w, int64_t img_stride, edvr_stream_t stream);
 
 /* ------------------------------------------------------------------ training: gradients of the fused launches
  * (what autograd runs under SRModel.optimize_parameters, basicsr/models/sr_model.py:88-112) */

@@ -85,10 +85,25 @@ def conv_unfold(x, w, b, stride, pad):
     return out
 
 
+def conv_unfold_autograd(x, w, b, stride, pad):
+    """The same restatement for runs that need gradients (bench.py's training witness on the GPU): F.unfold over the whole batch +
+    one batched GEMM, every op differentiable by torch autograd (fold / GEMM kernels - no MIOpen backward kernels to compile)."""
+    co, ci, kh, kw = w.shape
+    n, _, h, wd = x.shape
+    ho, wo = (h + 2 * pad - kh) // stride + 1, (wd + 2 * pad - kw) // stride + 1
+    cols = x.reshape(n, ci, h * wd) if (kh == 1 and kw == 1 and stride == 1 and pad == 0) else F.unfold(x, (kh, kw), padding=pad, stride=stride)
+    out = torch.matmul(w.reshape(co, ci * kh * kw), cols)
+    if b is not None:
+        out = out + b.view(1, co, 1)
+    return out.view(n, co, ho, wo)
+
+
 def _conv(sd, name, x, stride=1, padding=None):
     w = sd[name + '.weight']
     pad = (w.shape[-1] // 2) if padding is None else padding
-    if _CONV_IMPL == 'unfold' and not torch.is_grad_enabled():
+    if _CONV_IMPL == 'unfold':
+        if torch.is_grad_enabled():
+            return _tag(conv_unfold_autograd(x, w, sd.get(name + '.bias'), stride, pad), name)
         return _tag(conv_unfold(x, w, sd.get(name + '.bias'), stride, pad), name)
     return _tag(F.conv2d(x, w, sd.get(name + '.bias'), stride, pad), name)
 
@@ -215,7 +230,7 @@ def edvr_forward(sd, x, center=None, hr_in=False, with_predeblur=False, with_tsa
                  stats=None, pool_inputs=None, dcn_offsets=None, act_sides=None, follow_stats=None, conv_impl='conv2d'):
     """x: (b, t, 3, h, w) -> (b, 3, 4h, 4w)  [or (b, 3, h, w) when hr_in].
     pool_inputs / dcn_offsets / act_sides: test aids, the discrete decisions of another run (see _follow, _ACT_SIDES).
-    conv_impl: 'conv2d' (F.conv2d) or 'unfold' (conv_unfold: im2col + GEMM, no-grad runs only).
+    conv_impl: 'conv2d' (F.conv2d) or 'unfold' (im2col + GEMM: conv_unfold without gradients, conv_unfold_autograd with).
     follow_stats: a list; receives one record per followed decision point - ('act', layer, flipped elements, elements, largest
     |pre-activation| among the flipped ones relative to the layer's max) or ('value', None, 0, elements, max |followed - own| /
     max |own|) - so that a test can bound how far the followed run strays from this oracle's own forward pass."""

@@ -20,4 +20,6 @@ def gpu():
     from edvr_amd import _lib
     lib = _lib.lib()  # raises loudly if the HIP extension is missing: never fall back
     assert lib.edvr_check_device() == 0, lib.edvr_last_error().decode()
+    ver = lib.edvr_version().decode()
+    assert 'variant:' not in ver, f'{_lib.LIB_PATH} is an experiment build ({ver}): the GPU suite only runs on the product library'
     return torch.device('cuda:0')

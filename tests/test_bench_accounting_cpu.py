@@ -22,21 +22,24 @@ def test_executed_flops_per_algorithm():
     assert b._is_mfma('conv3x3_winograd_f4_kernel') and not b._is_mfma('upsample2x')
 
 
-def test_roofline_fraction_is_executed_over_peak():
+def test_roofline_fraction_is_useful_executed_over_peak():
     b = _bench()
     flops, secs = 4.0 * 157.3e12, 2.0                                       # algorithmic flops of an F(4x4) kernel over 2 s
     per = {'conv3x3_winograd_f4_kernel': [10, flops, secs, 0.0]}
     r = b.roofline_object(per, 1, 4.0, 'no_such_workload', False)
     assert r['kernel'] == 'conv3x3_winograd_f4_kernel' and r['bound'] == 'mfma'
     assert abs(r['frac'] - 0.5) < 1e-3 and r['frac'] <= 1.0                 # executed = algorithmic / 4
-    assert abs(r['algorithmic_over_peak'] - 2.0) < 1e-3
+    assert abs(r['algorithmic_over_peak'] - 2.0) < 1e-3 and abs(r['algorithmic_frac_winograd'] - 0.5) < 1e-3
     assert r['traffic'] is None
-    # with the C side's count of the MFMAs actually issued (2 % padded tiles): the fraction is taken on THAT number
+    # with the C side's count of the MFMAs actually issued (2 % padded tiles): the fraction stays on the USEFUL flops - padded
+    # tiles are not an achievement - and the issued figure is reported beside it
     per = {'conv3x3_winograd_f4_kernel': [10, flops, secs, 0.0, 1.02 * flops / 4.0]}
     r = b.roofline_object(per, 1, 4.0, 'no_such_workload', False)
-    assert abs(r['frac'] - 0.51) < 1e-3 and abs(r['padding_overhead'] - 0.02) < 1e-3
-    assert abs(r['executed_without_padding_tflops'] - 0.5 * 157.3) < 0.1
-    assert 'padding included' in r['definition']
+    assert abs(r['frac'] - 0.5) < 1e-3 and abs(r['incl_padding_frac'] - 0.51) < 1e-3 and abs(r['padding_overhead'] - 0.02) < 1e-3
+    assert abs(r['executed_without_padding_tflops'] - 0.5 * 157.3) < 0.1 and r['achieved'] == r['executed_without_padding_tflops']
+    assert 'NOT counted' in r['definition']
+    tab = b.kernel_table(per, 1, 4.0)['conv3x3_winograd_f4_kernel']
+    assert abs(tab['frac_of_mfma_peak'] - 0.5) < 1e-3 and abs(tab['frac_incl_padding'] - 0.51) < 1e-3
 
 
 def test_executed_flops_of_the_c_side_equal_the_pmc_count():

@@ -181,3 +181,119 @@ def test_fused_kernel_halo_classes_and_generic_path_agree(gpu, sigma):
         assert _rel(y, ref) < FWD_RTOL, hint
     y_act = ops.dcnv2_forward(*dev, 1, 1, 1, 1, 8, act=ops.ACT_LRELU, halo_hint=3)
     assert _rel(y_act, torch.nn.functional.leaky_relu(ref, 0.1)) < FWD_RTOL
+
+
+# ------------------------------------------------------------------------------------------------ per-tap shifted windows
+def _smooth_field(B, dg, H, W, sigma, g, noise=0.15, low=0.5, outliers=0):
+    """What a trained conv_offset produces: a constant per (group, tap, dy | dx) ~ N(0, sigma^2), a low-frequency motion component
+    and a small white residual; `outliers` pixels per plane jump by +-9 px (object boundaries: the kernel's slow path)."""
+    import torch.nn.functional as F
+    bias = torch.randn(1, dg * 18, 1, 1, generator=g) * sigma
+    coarse = torch.randn(B, dg * 18, (H + 15) // 16 + 1, (W + 15) // 16 + 1, generator=g) * low
+    lowf = F.interpolate(coarse, scale_factor=16, mode='bilinear', align_corners=False)[:, :, :H, :W]
+    off = bias + lowf + torch.randn(B, dg * 18, H, W, generator=g) * noise
+    for _ in range(outliers):
+        yy, xx = int(torch.randint(0, H, (1,), generator=g)), int(torch.randint(0, W, (1,), generator=g))
+        off[:, :, yy, xx] += 9.0 * (1 if _ % 2 else -1)
+    return off.contiguous()
+
+
+TAPWIN_CASES = [
+    # B, C, H, W, Co, dg, sigma, outliers, act
+    (2, 128, 21, 64, 128, 8, 4.0, 0, 0),    # EDVR-L geometry, ragged tile rows, multi-pixel smooth field
+    (1, 128, 16, 32, 128, 8, 10.0, 0, 2),   # one tile column: most windows reach beyond the image (zero pieces) + LeakyReLU epilogue
+    (2, 64, 24, 40, 64, 8, 3.0, 4, 0),      # EDVR-M geometry (8 channels per group, two channel tiles), ragged tile columns, outliers
+    (1, 128, 9, 36, 96, 8, 2.0, 3, 0),      # three channel tiles, width % 32 != 0, outliers
+    (1, 128, 40, 100, 40, 8, 6.0, 0, 1),    # tail channel tile (Co % 32 != 0), ReLU
+    (1, 128, 8, 32, 128, 8, 0.0, 0, 0),     # zero offsets, exactly one tile
+    (1, 256, 12, 48, 160, 16, 5.0, 2, 0),   # 16 groups, two launches (128 + 32 output channels)
+    (3, 128, 33, 72, 128, 8, 64.0, 0, 0),   # displacements larger than the image: every window empty or clipped
+]
+
+
+@pytest.mark.parametrize('case', TAPWIN_CASES)
+def test_tap_window_kernel_matches_oracle(gpu, case):
+    """EDVR_DCN_HALO_TAPWIN (csrc/dcn_tapwin.hip): window origins follow each (group, tap)'s displacement.  Against the C oracle in
+    fp64, and against the zero-centred halo kernel on the same inputs (same arithmetic per sample: only the MFMA summation order
+    over channels differs)."""
+    from edvr_amd import ops
+    from oracle import dcn_oracle as O
+    B, C, H, W, Co, dg, sigma, outliers, act = case
+    g = torch.Generator().manual_seed(1000 + TAPWIN_CASES.index(case))
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(Co, C, 3, 3, generator=g) * 0.1
+    b = torch.randn(Co, generator=g)
+    off = _smooth_field(B, dg, H, W, sigma, g, outliers=outliers)
+    m = torch.rand(B, dg * 9, H, W, generator=g)
+    ref = O.c_forward(x.double(), off.double(), m.double(), w.double(), b.double(), 1, 1, 1, 1, dg)
+    if act == 2:
+        ref = torch.nn.functional.leaky_relu(ref, 0.1)
+    elif act == 1:
+        ref = torch.relu(ref)
+    dev = [t.to(gpu) for t in (x, off, m, w, b)]
+    y = ops.dcnv2_forward(*dev, 1, 1, 1, 1, dg, act=act, halo_hint=ops.DCN_HALO_TAPWIN)
+    assert _rel(y, ref) < FWD_RTOL
+    y7 = ops.dcnv2_forward(*dev, 1, 1, 1, 1, dg, act=act, halo_hint=7)
+    assert (y - y7).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize('sigma', [0.5, 3.0, 12.0])
+def test_tap_window_kernel_on_white_noise_offsets(gpu, sigma):
+    """A rough field is the kernel's worst case, not a wrong one: every lane whose cell leaves its window goes through the fix-up
+    pass (global gathers with the full bounds logic).  Same inputs as the halo-class test above."""
+    from edvr_amd import ops
+    from oracle import dcn_oracle as O
+    x, off, m, w, b, _ = _mk(2, 64, 21, 44, 96, 3, 1, 1, 1, 1, 8, sigma, seed=int(sigma * 10))
+    ref = O.c_forward(x.double(), off.double(), m.double(), w.double(), b.double(), 1, 1, 1, 1, 8)
+    y = ops.dcnv2_forward(*(t.to(gpu) for t in (x, off, m, w, b)), 1, 1, 1, 1, 8, halo_hint=ops.DCN_HALO_TAPWIN)
+    assert _rel(y, ref) < FWD_RTOL
+
+
+def test_tap_window_hint_falls_back_where_the_kernel_does_not_apply(gpu):
+    """Widths that are not a multiple of 4, other group sizes and unaligned views run the R = 7 halo kernel under the same hint."""
+    from edvr_amd import ops
+    from oracle import dcn_oracle as O
+    for (C, H, W, dg) in ((64, 14, 45, 8), (48, 10, 36, 8), (64, 12, 20, 8)):
+        x, off, m, w, b, _ = _mk(1, C, H, W, 64, 3, 1, 1, 1, 1, dg, 2.0, seed=C + W)
+        ref = O.c_forward(x.double(), off.double(), m.double(), w.double(), b.double(), 1, 1, 1, 1, dg)
+        y = ops.dcnv2_forward(*(t.to(gpu) for t in (x, off, m, w, b)), 1, 1, 1, 1, dg, halo_hint=ops.DCN_HALO_TAPWIN)
+        assert _rel(y, ref) < FWD_RTOL, (C, H, W, dg)
+    # a view whose storage offset is not 16-byte aligned
+    x, off, m, w, b, _ = _mk(1, 64, 12, 36, 64, 3, 1, 1, 1, 1, 8, 2.0, seed=5)
+    buf = torch.zeros(x.numel() + 1, device=gpu)
+    xv = buf[1:].view(x.shape)
+    xv.copy_(x)
+    ref = O.c_forward(x.double(), off.double(), m.double(), w.double(), b.double(), 1, 1, 1, 1, 8)
+    y = ops.dcnv2_forward(xv, *(t.to(gpu) for t in (off, m, w, b)), 1, 1, 1, 1, 8, halo_hint=ops.DCN_HALO_TAPWIN)
+    assert _rel(y, ref) < FWD_RTOL
+
+
+def test_offset_statistics_kernels(gpu):
+    """edvr_abs_stats_f32 and the F(4x4) conv epilogue (abs_sum + abs_diff) against torch, and the hints derived from them."""
+    from edvr_amd import functional as F_, ops
+    g = torch.Generator().manual_seed(21)
+    t = torch.randn(3, 10, 12, 40, generator=g)
+    st = ops.abs_stats_per_image(t.to(gpu)).cpu()
+    want_sum = t.double().abs().sum((1, 2, 3))
+    t4 = t.double().view(3, 10, 12, 10, 4)
+    want_diff = (t4[..., 1:] - t4[..., :-1]).abs().sum((1, 2, 3, 4))
+    assert _rel(st[0], want_sum) < 1e-5 and _rel(st[1], want_diff) < 1e-5
+    absmean, rough = ops.offset_stats(st, t.numel())
+    assert abs(absmean - t.abs().mean().item()) < 1e-4 and abs(rough - (t[..., 1:] - t[..., :-1]).abs().mean().item()) < 0.02
+    odd = torch.randn(2, 3, 5, 7, generator=g)  # rows that are not whole 16-byte groups: sums only, roughness unknown
+    st = ops.abs_stats_per_image(odd.to(gpu)).cpu()
+    assert _rel(st[0], odd.double().abs().sum((1, 2, 3))) < 1e-5 and (st[1] == -1).all()
+    assert ops.offset_stats(st, odd.numel())[1] is None
+    # the conv epilogue: conv_offset-shaped layer on the F(4x4) kernel
+    m = torch.nn.Conv2d(64, 216, 3, 1, 1)
+    x = torch.randn(2, 64, 16, 64, generator=g)
+    ref = m(x)[:, :144].double()
+    with torch.no_grad():
+        om, stats = F_.offset_mask_conv_stats(m.to(gpu), x.to(gpu))
+    r4 = ref.view(2, 144, 16, 16, 4)
+    assert _rel(stats[0], ref.abs().sum((1, 2, 3))) < 1e-4
+    assert _rel(stats[1], (r4[..., 1:] - r4[..., :-1]).abs().sum((1, 2, 3, 4))) < 1e-4
+    assert F_.halo_hint_from_stats(3.0, 0.1) == ops.DCN_HALO_TAPWIN and F_.halo_hint_from_stats(3.0, 2.0) == -1
+    assert F_.halo_hint_from_stats(0.4, None) == 3 and F_.halo_hint_from_stats(None, None) == 3
+    assert F_.scatter_hint_from_stats(3.0, 0.1) == ops.DCN_SCATTER_DEVICE and F_.scatter_hint_from_stats(3.0, 2.0) == ops.DCN_SCATTER_LDS
+    assert F_.scatter_hint_from_stats(0.2, 0.1) == ops.DCN_SCATTER_STRIP

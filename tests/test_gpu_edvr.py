@@ -148,8 +148,36 @@ def test_offset_check_is_lazy_in_inference_and_eager_in_training(gpu, caplog):
         assert len([r for r in caplog.records if 'larger than 50' in r.getMessage()]) == 2 * n_inf
         net.check_offsets()
         caplog.clear()
-        net.train()
+        net.train()  # (train() / eval() also flush whatever is pending: nothing here)
         net(xg).sum().backward()  # grad mode: evaluated inside the forward (the backward's scatter strategy needs it)
         assert not net._pending_offset_stats
         assert len([r for r in caplog.records if 'larger than 50' in r.getMessage()]) == n_inf
     assert torch.isfinite(out).all()
+
+
+def test_pending_offset_statistics_do_not_live_in_the_module(gpu, caplog):
+    """The queue of not-yet-examined offset statistics (pinned tensors + torch.cuda.Event objects, which can be neither pickled nor
+    deep-copied) is kept outside the module: an EMA copy or torch.save(net) right after an eval forward works, the copy starts with
+    an empty queue, and train() / eval() flush the queue - the final clip's `larger than 50` warning is not lost."""
+    import copy
+    import io
+    import logging
+    net, x, _ = build('M_T5')
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if n.endswith('cas_dcnpack.conv_offset.bias'):
+                p.fill_(80.0)
+    net = net.to(gpu).eval()
+    with caplog.at_level(logging.WARNING, logger='basicsr'):
+        with torch.no_grad():
+            net(x.to(gpu))
+        assert len(net._pending_offset_stats) == 1 and '_pending_offset_stats' not in net.__dict__
+        ema = copy.deepcopy(net)
+        assert not ema._pending_offset_stats and len(net._pending_offset_stats) == 1
+        torch.save(net, io.BytesIO())
+        assert not [r for r in caplog.records if 'larger than 50' in r.getMessage()]
+        net.train()  # flushes: the warning of the last (only) clip appears
+        assert not net._pending_offset_stats
+        assert len([r for r in caplog.records if 'larger than 50' in r.getMessage()]) == x.shape[1]
+        cas = net.pcd_align.cas_dcnpack
+        assert cas.last_offset_absmean > 50 and cas.last_offset_rough is not None and cas.last_offset_rough < 0.45

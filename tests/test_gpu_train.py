@@ -335,6 +335,18 @@ def test_charbonnier(gpu):
 
 @pytest.mark.parametrize('name', ['M_T5', 'L_deblur_hr', 'M_noTSA', 'L_T7'])
 def test_edvr_parameter_gradients_match_oracle(gpu, name, conv_algo):
+    _followed_gradient_check(gpu, name)
+
+
+def test_edvr_l_full_depth_parameter_gradients_match_oracle(gpu):
+    """BASELINE configs[3] at its real depth and crop size - EDVR-L as trained (128 features, 40 reconstruction blocks, 5 frames,
+    64x64 LR crop, one clip) - on the default kernel selection (F(4x4) forward / data gradient, Winograd-domain weight gradient,
+    fused DCN backward): every parameter gradient against the fp64 CPU oracle following the HIP run's discrete decisions, same
+    bounds as the small stand-ins above."""
+    _followed_gradient_check(gpu, 'L_full_T5')
+
+
+def _followed_gradient_check(gpu, name):
     """Whole network: d(Charbonnier sum)/d(every parameter), HIP fp32 vs oracle autograd fp64.
     The bound is calibrated per tensor against the fp32 noise floor of the oracle itself (same algorithm in fp32 on the
     CPU vs fp64): ours must be within max(1e-3, 4 x that floor) of the fp64 truth, relative to max|grad|.
@@ -406,7 +418,7 @@ def test_edvr_parameter_gradients_match_oracle(gpu, name, conv_algo):
           f'{within}/{len(ours_all)} tensors within max(1e-3, 4 x floor)')
 
 
-@pytest.mark.parametrize('name', ['M_T5', 'L_T7'])
+@pytest.mark.parametrize('name', ['M_T5', 'L_T7', 'L_full_T5'])
 def test_edvr_parameter_gradients_unfollowed(gpu, name):
     """The same comparison with NOTHING shared: the fp64 oracle takes its own activation sides, pooling routes and DCN cells.
     A handful of elements may then sit on different sides of a kink in the two runs and shift individual tensors by a finite
@@ -429,3 +441,65 @@ def test_edvr_parameter_gradients_unfollowed(gpu, name):
     print(f'{name} unfollowed: median {median:.1e}, 90th percentile {p90:.1e}, max {errs[-1]:.1e} over {len(errs)} tensors')
     assert median < 1e-3, (median, p90, errs[-1])
     assert errs[-1] < 0.2, errs[-1]
+
+
+def test_training_trajectory_matches_oracle_adam(gpu):
+    """Ten optimizer steps, not one (sr_model.py:88-112 in a loop): the HIP network + edvr_amd.optim.FusedAdam against the fp64 CPU
+    oracle + torch.optim.Adam from identical weights on identical batches (two alternating batches of two clips, EDVR-M with 4
+    reconstruction blocks, the reference's lr 4e-4 / betas (0.9, 0.99), both dcn_lr_mul groups).  What only a trajectory catches:
+    state that outlives an iteration - the packed-weight cache (ops.prepack_conv_weights rewrites its buffers in place after every
+    step), the per-layer kernel hints, FusedAdam's multi-tensor table and moments.  A forward pass on stale weights leaves the loss
+    curve by >= 1e-3 in the first iterations and turns the sign-like Adam updates of most elements around.
+    Bounds: every loss within 1e-4 relative; per tensor, 99.9 % of the final weights within 1e-4 of max |w| (Adam divides by
+    sqrt(v): an element whose gradient is at fp32 noise level moves by +-lr per step whichever sign the noise has - a 1e-5 fraction of
+    the elements), none further than the 2 * lr * steps Adam can move two copies apart."""
+    from edvr_amd import EDVR
+    from edvr_amd.autograd import charbonnier_loss
+    from edvr_amd.optim import FusedAdam
+    from oracle import dcn_oracle as O, edvr_oracle as EO
+    from util_edvr import randomize_offsets
+    kwargs = dict(num_feat=64, num_frame=5, num_reconstruct_block=4, center_frame_idx=2)
+    steps, lr = 10, 4e-4
+    torch.manual_seed(10)
+    net = randomize_offsets(EDVR(**kwargs)).train()
+    g = torch.Generator().manual_seed(7)
+    batches = [(torch.rand(2, 5, 3, 32, 32, generator=g), torch.rand(2, 3, 128, 128, generator=g)) for _ in range(2)]
+    # oracle arm
+    sd = {k: v.detach().double().clone().requires_grad_() for k, v in net.state_dict().items()}
+    opt64 = torch.optim.Adam(list(sd.values()), lr=lr, betas=(0.9, 0.99))
+    loss64 = []
+    for it in range(steps):
+        x, gt = batches[it % 2]
+        opt64.zero_grad()
+        l = EO.charbonnier_sum(EO.edvr_forward(sd, x.double(), dcn=O.dcnv2_c, **oracle_kwargs(kwargs)), gt.double())
+        l.backward()
+        opt64.step()
+        loss64.append(l.item())
+    assert abs(loss64[2] - loss64[0]) / loss64[0] > 1e-3, 'the test needs a loss that moves'
+    # HIP arm
+    net = net.to(gpu)
+    dcn = [p for n, p in net.named_parameters() if 'dcn' in n]
+    rest = [p for n, p in net.named_parameters() if 'dcn' not in n]
+    opt = FusedAdam([{'params': rest, 'lr': lr}, {'params': dcn, 'lr': lr}], lr=lr, betas=(0.9, 0.99))
+    dev = [(x.to(gpu), gt.to(gpu)) for x, gt in batches]
+    loss32 = []
+    for it in range(steps):
+        x, gt = dev[it % 2]
+        opt.zero_grad(set_to_none=True)
+        l = charbonnier_loss(net(x), gt)
+        l.backward()
+        opt.step()
+        loss32.append(l.item())
+    curve = [abs(a - b) / b for a, b in zip(loss32, loss64)]
+    assert max(curve) < 1e-4, (curve, loss32, loss64)
+    worst = (0.0, '')
+    for k, p in net.named_parameters():
+        ref = sd[k].detach()
+        diff = (p.detach().double().cpu() - ref).abs().flatten()
+        scale = ref.abs().max().item()
+        assert diff.max().item() <= 2.1 * lr * steps, (k, diff.max().item())
+        q = torch.quantile(diff, 0.999).item() if diff.numel() > 1000 else diff.max().item()
+        if scale > 0:
+            worst = max(worst, (q / scale, k))
+            assert q <= 1e-4 * scale + 1e-7, (k, q, scale)
+    print(f'trajectory: max loss rel err {max(curve):.1e}; worst 99.9th-percentile weight deviation {worst[0]:.1e} of max|w| at {worst[1]}')

@@ -10,19 +10,27 @@ CONFIGS = {
                          with_predeblur=True), (1, 5, 3, 64, 64)),
     'M_noTSA': (dict(num_feat=32, num_frame=3, num_reconstruct_block=2, center_frame_idx=1, with_tsa=False,
                      deformable_groups=4), (2, 3, 3, 16, 16)),
+    # EDVR-L AS TRAINED (options/train/EDVR/train_EDVR_L_x4_SR_REDS.yml:21-32: 128 features, 40 reconstruction blocks, 5 frames,
+    # 64x64 LR crops): BASELINE configs[3] at its real depth and size, one clip
+    'L_full_T5': (dict(num_feat=128, num_frame=5, num_reconstruct_block=40, center_frame_idx=None), (1, 5, 3, 64, 64)),
 }
 
 
-def randomize_offsets(net, seed=123):
+def randomize_offsets(net, seed=123, bias_sigma=0.5):
     """Default init zeroes conv_offset (deform_conv.py:377-381): every tap would sit on the integer grid
-    and the bilinear gather would never be exercised (SURVEY.md finding 5)."""
+    and the bilinear gather would never be exercised (SURVEY.md finding 5).  bias_sigma: spread of the per-channel constants -
+    0.5 = sub-pixel taps (a lightly trained model), 4 / 10 = the multi-pixel per-tap displacements of a trained one (the mask
+    channels keep 0.5: they go through a sigmoid)."""
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         for n, p in net.named_parameters():
             if n.endswith('conv_offset.weight'):
                 p.copy_(torch.randn(p.shape, generator=g) * 0.02)
             elif n.endswith('conv_offset.bias'):
-                p.copy_(torch.randn(p.shape, generator=g) * 0.5)
+                b = torch.randn(p.shape, generator=g) * 0.5
+                if bias_sigma != 0.5:
+                    b[:2 * p.shape[0] // 3] *= bias_sigma / 0.5  # offset channels only (same random draws)
+                p.copy_(b)
     return net
 
 
