@@ -70,26 +70,23 @@ def offset_mask_conv(conv_offset, feat):
     return conv(conv_offset, feat, act=ACT_SIGMOID, act_from=2 * co // 3)
 
 
-SMOOTH_ROUGHNESS = 0.45  # mean |offset[x] - offset[x + 1]| below which a field counts as spatially smooth: white noise of sigma 0.4
-#                          (1.13 sigma) leaves the +-1.5 px slack of a shifted window on 1e-4 of the taps; sigma 0.5 on 3e-3, i.e. on some
-#                          lane of every sixth (wave, step)
-TAPWIN_MIN_ABSMEAN = float(__import__('os').environ.get('EDVR_DCN_TAPWIN_MIN_ABSMEAN', '0'))  # smooth fields below this mean |offset| stay on the zero-centred halo kernel
+ROUGH_LIMIT = float(__import__('os').environ.get('EDVR_DCN_TAPWIN_ROUGH_LIMIT', '6.0'))
 
 
 def halo_hint_from_stats(absmean, rough):
     """Kernel class of the fused DCNv2 forward from the statistics of the PREVIOUS call of the same layer (a performance hint only):
-    `absmean` = mean |offset|, `rough` = mean |horizontal neighbour difference| (None = unknown).  A spatially smooth field - what
-    conv_offset produces once trained: per-tap displacements of any size that vary slowly across the image - runs on the kernel whose
-    staged window follows every tap's displacement (csrc/dcn_tapwin.hip: cost independent of the magnitude).  A rough field keeps the
-    zero-centred halo while it is small (|offset| ~ N(0, s): mean = 0.8 s; R covers ~2.4 s for R = 3 at mean 1) and the
-    column-buffer path beyond."""
-    if absmean is None:
-        return 3
-    if rough is not None and rough < SMOOTH_ROUGHNESS and absmean >= TAPWIN_MIN_ABSMEAN:
-        return ops.DCN_HALO_TAPWIN
-    if absmean < 1.2:
-        return 3
-    return 7 if absmean < 3.0 else -1
+    `absmean` = mean |offset|, `rough` = mean |horizontal neighbour difference| (None = unknown).  The kernel whose staged windows
+    follow every tap's displacement (csrc/dcn_tapwin.hip, EDVR_DCN_HALO_TAPWIN) is the default: on a spatially smooth field - what
+    conv_offset produces, fresh or trained: per-tap displacements of any size that vary slowly across the image - its cost does not
+    depend on the offsets at all, and it is also the fastest class measured on white-noise fields up to sigma = 4 px
+    (profiles/r4/dcn_sigma_sweep.log).  Only a field that is BOTH large and rough (white noise of many pixels: every tap of every
+    lane through the fix-up pass) goes to the column-buffer path.  Layers the tap-window kernel does not take (widths not a multiple
+    of 4, other group sizes) fall back to the zero-centred halo inside the C entry point."""
+    if rough is not None and rough >= ROUGH_LIMIT and absmean is not None and absmean >= 3.0:
+        return -1
+    if rough is None and absmean is not None and absmean >= 3.0:
+        return -1  # (no roughness statistic: rows that are not 16-byte groups - the tap-window kernel does not take those anyway)
+    return ops.DCN_HALO_TAPWIN
 
 
 def halo_hint_from_absmean(absmean):
@@ -98,17 +95,16 @@ def halo_hint_from_absmean(absmean):
 
 def scatter_hint_from_stats(absmean, rough):
     """How the DCNv2 backward accumulates dx (include/edvr_amd.h EDVR_DCN_SCATTER_*), from the statistics of the layer's latest forward.
-    Sub-pixel offsets (fresh or lightly trained conv_offset): the kernels that need no scatter for taps with |offset| < 1.  Larger
-    but spatially SMOOTH offsets (a trained conv_offset): device atomics - neighbouring pixels hit neighbouring addresses, so the
-    atomics coalesce in L2 at any displacement, as in the reference's col2im (.cu:688).  Rough fields go through the LDS window,
-    whose cost does not depend on the offset field (6x faster than device atomics on a white-noise field)."""
+    Sub-pixel offsets (fresh or lightly trained conv_offset): the kernels that need no scatter for taps with |offset| < 1.  Anything
+    larger goes through the LDS window, whose cost barely depends on the offset field (12.7 - 15.6 ms on smooth multi-pixel fields,
+    18 ms on white noise, where device atomics need 30 - 120 ms: profiles/r4/dcn_sigma_sweep.log); device atomics only in the
+    narrow band where most taps are still sub-pixel.  `rough` is accepted for symmetry with the forward's hint; the measured
+    choice does not depend on it."""
     if absmean is None:
         return ops.DCN_SCATTER_LDS
     if absmean < 0.4:  # white-noise offsets of sigma 0.5 (|mean| 0.4): 9 % of the taps already leave the sub-pixel window
         return ops.DCN_SCATTER_STRIP
-    if rough is not None and rough < SMOOTH_ROUGHNESS:
-        return ops.DCN_SCATTER_DEVICE
-    return ops.DCN_SCATTER_DEVICE if absmean < 0.75 else ops.DCN_SCATTER_LDS
+    return ops.DCN_SCATTER_DEVICE if absmean < 0.75 and (rough is None or rough >= 0.45) else ops.DCN_SCATTER_LDS
 
 
 def scatter_hint_from_absmean(absmean):

@@ -444,16 +444,22 @@ def test_edvr_parameter_gradients_unfollowed(gpu, name):
 
 
 def test_training_trajectory_matches_oracle_adam(gpu):
-    """Ten optimizer steps, not one (sr_model.py:88-112 in a loop): the HIP network + edvr_amd.optim.FusedAdam against the fp64 CPU
-    oracle + torch.optim.Adam from identical weights on identical batches (two alternating batches of two clips, EDVR-M with 4
-    reconstruction blocks, the reference's lr 4e-4 / betas (0.9, 0.99), both dcn_lr_mul groups).  What only a trajectory catches:
-    state that outlives an iteration - the packed-weight cache (ops.prepack_conv_weights rewrites its buffers in place after every
-    step), the per-layer kernel hints, FusedAdam's multi-tensor table and moments.  A forward pass on stale weights leaves the loss
-    curve by >= 1e-3 in the first iterations and turns the sign-like Adam updates of most elements around.
-    Bounds: every loss within 1e-4 relative; per tensor, 99.9 % of the final weights within 1e-4 of max |w| (Adam divides by
-    sqrt(v): an element whose gradient is at fp32 noise level moves by +-lr per step whichever sign the noise has - a 1e-5 fraction of
-    the elements), none further than the 2 * lr * steps Adam can move two copies apart."""
-    from edvr_amd import EDVR
+    """Ten optimizer steps, not one (sr_model.py:88-112 in a loop), three arms from identical weights on identical batches (two
+    alternating batches of two clips, EDVR-M with 4 reconstruction blocks, the reference's lr 4e-4 / betas (0.9, 0.99), both
+    dcn_lr_mul groups):
+      O  the fp64 CPU oracle + torch.optim.Adam                                   (the absolute anchor)
+      A  the product path: HIP network + edvr_amd.optim.FusedAdam, every cache live
+      B  the HIP network + torch.optim.Adam with the packed-weight cache dropped and the kernel hints reset before EVERY forward
+    What only a trajectory catches is state that outlives an iteration: the packed-weight cache (ops.prepack_conv_weights rewrites
+    its buffers in place after every step), the per-layer kernel hints, FusedAdam's multi-tensor table and moments.
+    A vs B isolates exactly that state, at rounding level: same kernels on the same weights, so the loss curves agree to 1e-6 and
+    every tensor's accumulated update to 1e-3.  A vs O bounds the arithmetic: every loss within 1e-4 relative.  The final weights
+    are compared through the UPDATE, per tensor || (w_A - w_0) - (w_O - w_0) ||_2 / || w_O - w_0 ||_2: Adam divides by sqrt(v), so
+    an element whose gradient is small against its tensor's largest moves by a sizeable fraction of lr per step on rounding-level
+    differences - the fp32 CPU oracle itself ends 5 % (median over tensors) to 10.5 % (worst) away from the fp64 one on this very
+    trajectory, 2.8e-3 = seven steps of lr at single elements - so a 1e-4 max-norm bound is not what the optimizer preserves; the
+    bounds are 12 % / 30 % and the 2 * lr * steps two copies can drift apart at all.  Stale weights or moments give errors of order 1."""
+    from edvr_amd import EDVR, ops
     from edvr_amd.autograd import charbonnier_loss
     from edvr_amd.optim import FusedAdam
     from oracle import dcn_oracle as O, edvr_oracle as EO
@@ -462,10 +468,11 @@ def test_training_trajectory_matches_oracle_adam(gpu):
     steps, lr = 10, 4e-4
     torch.manual_seed(10)
     net = randomize_offsets(EDVR(**kwargs)).train()
+    state0 = {k: v.detach().clone() for k, v in net.state_dict().items()}
     g = torch.Generator().manual_seed(7)
     batches = [(torch.rand(2, 5, 3, 32, 32, generator=g), torch.rand(2, 3, 128, 128, generator=g)) for _ in range(2)]
-    # oracle arm
-    sd = {k: v.detach().double().clone().requires_grad_() for k, v in net.state_dict().items()}
+    # arm O
+    sd = {k: v.detach().double().clone().requires_grad_() for k, v in state0.items()}
     opt64 = torch.optim.Adam(list(sd.values()), lr=lr, betas=(0.9, 0.99))
     loss64 = []
     for it in range(steps):
@@ -476,30 +483,52 @@ def test_training_trajectory_matches_oracle_adam(gpu):
         opt64.step()
         loss64.append(l.item())
     assert abs(loss64[2] - loss64[0]) / loss64[0] > 1e-3, 'the test needs a loss that moves'
-    # HIP arm
-    net = net.to(gpu)
-    dcn = [p for n, p in net.named_parameters() if 'dcn' in n]
-    rest = [p for n, p in net.named_parameters() if 'dcn' not in n]
-    opt = FusedAdam([{'params': rest, 'lr': lr}, {'params': dcn, 'lr': lr}], lr=lr, betas=(0.9, 0.99))
     dev = [(x.to(gpu), gt.to(gpu)) for x, gt in batches]
-    loss32 = []
-    for it in range(steps):
-        x, gt = dev[it % 2]
-        opt.zero_grad(set_to_none=True)
-        l = charbonnier_loss(net(x), gt)
-        l.backward()
-        opt.step()
-        loss32.append(l.item())
-    curve = [abs(a - b) / b for a, b in zip(loss32, loss64)]
-    assert max(curve) < 1e-4, (curve, loss32, loss64)
-    worst = (0.0, '')
-    for k, p in net.named_parameters():
-        ref = sd[k].detach()
-        diff = (p.detach().double().cpu() - ref).abs().flatten()
-        scale = ref.abs().max().item()
-        assert diff.max().item() <= 2.1 * lr * steps, (k, diff.max().item())
-        q = torch.quantile(diff, 0.999).item() if diff.numel() > 1000 else diff.max().item()
-        if scale > 0:
-            worst = max(worst, (q / scale, k))
-            assert q <= 1e-4 * scale + 1e-7, (k, q, scale)
-    print(f'trajectory: max loss rel err {max(curve):.1e}; worst 99.9th-percentile weight deviation {worst[0]:.1e} of max|w| at {worst[1]}')
+
+    def hip_arm(fused):
+        torch.manual_seed(10)
+        m = randomize_offsets(EDVR(**kwargs)).train().to(gpu)
+        dcn = [p for n, p in m.named_parameters() if 'dcn' in n]
+        rest = [p for n, p in m.named_parameters() if 'dcn' not in n]
+        groups = [{'params': rest, 'lr': lr}, {'params': dcn, 'lr': lr}]
+        opt = (FusedAdam if fused else torch.optim.Adam)(groups, lr=lr, betas=(0.9, 0.99))
+        losses = []
+        for it in range(steps):
+            x, gt = dev[it % 2]
+            if not fused:  # arm B: nothing survives an iteration but the weights and torch's own optimizer state
+                ops.invalidate_packed_weights()
+                for d in m.pcd_align.dcn_modules():
+                    d.last_offset_absmean = d.last_offset_rough = None
+            opt.zero_grad(set_to_none=True)
+            l = charbonnier_loss(m(x), gt)
+            l.backward()
+            opt.step()
+            losses.append(l.item())
+        return losses, {k: p.detach().double().cpu() for k, p in m.named_parameters()}
+
+    loss_a, w_a = hip_arm(True)
+    loss_b, w_b = hip_arm(False)
+    w0 = {k: v.detach().double() for k, v in state0.items()}
+
+    def update_errors(w, ref):
+        out = []
+        for k in w:
+            du = (ref[k] - w0[k]).norm().item()
+            assert du > 0, k
+            out.append((((w[k] - w0[k]) - (ref[k] - w0[k])).norm().item() / du, k))
+        return sorted(out)
+
+    # A vs B: the state that outlives an iteration
+    assert max(abs(a - b) / b for a, b in zip(loss_a, loss_b)) < 1e-6, (loss_a, loss_b)
+    ab = update_errors(w_a, w_b)
+    assert ab[-1][0] < 1e-3, ab[-3:]
+    # A vs O: the arithmetic
+    curve = [abs(a - b) / b for a, b in zip(loss_a, loss64)]
+    assert max(curve) < 1e-4, (curve, loss_a, loss64)
+    w_o = {k: v.detach() for k, v in sd.items()}
+    ao = update_errors(w_a, w_o)
+    for k in w_a:
+        assert (w_a[k] - w_o[k]).abs().max().item() <= 2.1 * lr * steps, (k, (w_a[k] - w_o[k]).abs().max().item())
+    print(f'trajectory: loss rel err vs oracle {max(curve):.1e}; update error vs oracle median {ao[len(ao) // 2][0]:.2e}, worst {ao[-1][0]:.2e} '
+          f'at {ao[-1][1]}; cached vs uncached HIP arms: worst update error {ab[-1][0]:.1e}')
+    assert ao[len(ao) // 2][0] < 0.12 and ao[-1][0] < 0.30, (ao[len(ao) // 2], ao[-1])
