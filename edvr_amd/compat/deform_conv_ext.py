@@ -51,6 +51,22 @@ def _scatter_hint(offset):
     return scatter_hint_from_stats(*st)
 
 
+_DW_MEMO = []  # [(key, d(weight))] of the latest deform_conv_backward_input call
+
+
+def _memo_key(input, offset, grad_output, geometry):
+    return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (input, offset, grad_output)) + (geometry,)
+
+
+def _out_view(output, input, weight, offset):
+    """The caller's `output` buffer as the (B, Co, Ho, Wo) tensor the kernels write in place (the reference resizes / views it,
+    deform_conv_cuda.cpp:530-536); a buffer of another size or layout is replaced like `output.resize_` would."""
+    shape = (input.shape[0], weight.shape[0], offset.shape[2], offset.shape[3])
+    if output.numel() != shape[0] * shape[1] * shape[2] * shape[3] or not output.is_contiguous():
+        output.resize_(shape)
+    return output.view(shape)
+
+
 def _check(input, weight, kh, kw, group):
     for t in (input, weight):
         if not t.is_cuda:
@@ -67,9 +83,8 @@ def _check(input, weight, kh, kw, group):
 def modulated_deform_conv_forward(input, weight, bias, ones, offset, mask, output, columns, kernel_h, kernel_w, stride_h, stride_w,
                                   pad_h, pad_w, dilation_h, dilation_w, group, deformable_group, with_bias):
     _check(input, weight, kernel_h, kernel_w, group)
-    y = ops.dcnv2_forward(input, offset, mask, weight, bias if with_bias else None, (stride_h, stride_w), (pad_h, pad_w),
-                          (dilation_h, dilation_w), group, deformable_group)
-    output.view_as(y).copy_(y)
+    ops.dcnv2_forward(input, offset, mask, weight, bias if with_bias else None, (stride_h, stride_w), (pad_h, pad_w),
+                      (dilation_h, dilation_w), group, deformable_group, out=_out_view(output, input, weight, offset))
     _note_offsets(offset)
 
 
@@ -77,31 +92,40 @@ def modulated_deform_conv_backward(input, weight, bias, ones, offset, mask, colu
                                    grad_mask, grad_output, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w,
                                    group, deformable_group, with_bias):
     _check(input, weight, kernel_h, kernel_w, group)
+    # d(offset) / d(mask) are overwritten by the reference's col2im_coord (.cu:696-767): written in place here; d(input) /
+    # d(weight) / d(bias) are ACCUMULATED by the reference (atomicAdd / addmm_ on the caller's buffers): computed, then added
+    direct = all(t.is_contiguous() and t.dtype == offset.dtype for t in (grad_offset, grad_mask)) and \
+        tuple(grad_offset.shape) == tuple(offset.shape) and tuple(grad_mask.shape) == tuple(mask.shape)
     dx, doff, dmsk, dw, db = ops.dcnv2_backward(input, offset, mask, weight, grad_output, bool(with_bias), (stride_h, stride_w),
                                                 (pad_h, pad_w), (dilation_h, dilation_w), group, deformable_group,
+                                                doffset=grad_offset if direct else None, dmask=grad_mask if direct else None,
                                                 scatter_hint=_scatter_hint(offset))
     grad_input.view_as(dx).add_(dx)
     grad_weight.add_(dw)
     if with_bias:
         grad_bias.add_(db)
-    grad_offset.copy_(doff)
-    grad_mask.copy_(dmsk)
+    if not direct:
+        grad_offset.copy_(doff)
+        grad_mask.copy_(dmsk)
 
 
 # ------------------------------------------------------------------------------------------------ DCNv1
 def deform_conv_forward(input, weight, offset, output, columns, ones, kW, kH, dW, dH, padW, padH, dilationW, dilationH, group,
                         deformable_group, im2col_step):
     _check(input, weight, kH, kW, group)
-    y = ops.dcnv1_forward(input, offset, weight, (dH, dW), (padH, padW), (dilationH, dilationW), group, deformable_group)
-    output.view_as(y).copy_(y)
+    ops.dcnv1_forward(input, offset, weight, (dH, dW), (padH, padW), (dilationH, dilationW), group, deformable_group,
+                      out=_out_view(output, input, weight, offset))
     return 1  # the reference returns 1 on success (deform_conv_cuda.cpp:242)
 
 
 def deform_conv_backward_input(input, offset, gradOutput, gradInput, gradOffset, weight, columns, kW, kH, dW, dH, padW, padH, dilationW,
                                dilationH, group, deformable_group, im2col_step):
     _check(input, weight, kH, kW, group)
-    dx, doff, _ = ops.dcnv1_backward(input, offset, weight, gradOutput, (dH, dW), (padH, padW), (dilationH, dilationW), group,
-                                     deformable_group)
+    dx, doff, dw = ops.dcnv1_backward(input, offset, weight, gradOutput, (dH, dW), (padH, padW), (dilationH, dilationW), group,
+                                      deformable_group)
+    # the reference's Function calls backward_input and backward_parameters back to back on the same tensors (deform_conv.py:77-97);
+    # the one launch sequence above produced d(weight) as well: kept for that second call instead of running everything again
+    _DW_MEMO[:] = [(_memo_key(input, offset, gradOutput, (kW, kH, dW, dH, padW, padH, dilationW, dilationH, group, deformable_group)), dw)]
     gradInput.view_as(dx).add_(dx)
     gradOffset.copy_(doff)
     return 1
@@ -110,8 +134,13 @@ def deform_conv_backward_input(input, offset, gradOutput, gradInput, gradOffset,
 def deform_conv_backward_parameters(input, offset, gradOutput, gradWeight, columns, ones, kW, kH, dW, dH, padW, padH, dilationW,
                                     dilationH, group, deformable_group, scale, im2col_step):
     _check(input, gradWeight, kH, kW, group)
-    weight = torch.zeros_like(gradWeight)  # d(weight) does not depend on the weight values; the one-call ABI wants a pointer
-    _, _, dw = ops.dcnv1_backward(input, offset, weight, gradOutput, (dH, dW), (padH, padW), (dilationH, dilationW), group,
-                                  deformable_group)
+    key = _memo_key(input, offset, gradOutput, (kW, kH, dW, dH, padW, padH, dilationW, dilationH, group, deformable_group))
+    memo = _DW_MEMO.pop() if _DW_MEMO else None
+    if memo is not None and memo[0] == key and tuple(memo[1].shape) == tuple(gradWeight.shape):
+        dw = memo[1]
+    else:
+        weight = torch.zeros_like(gradWeight)  # d(weight) does not depend on the weight values; the one-call ABI wants a pointer
+        _, _, dw = ops.dcnv1_backward(input, offset, weight, gradOutput, (dH, dW), (padH, padW), (dilationH, dilationW), group,
+                                      deformable_group)
     gradWeight.add_(dw, alpha=float(scale))
     return 1

@@ -46,6 +46,28 @@ constexpr int BF_PR = 5, BF_PC = BF_TW + 4, BF_PCH = BF_PR * BF_PC, BF_PW = BF_C
 __host__ __device__ constexpr int bf_tap(int tp, int hf) { return hf == 0 ? (tp < 3 ? tp : (tp == 3 ? 6 : 8)) : (tp < 3 ? 3 + tp : (tp == 3 ? 7 : 9)); }
 }  // namespace
 
+typedef int bf_i32x4 __attribute__((ext_vector_type(4)));
+
+// LDS-DMA from inline assembly (see dcn_tapwin.hip): the compiler puts `s_waitcnt vmcnt(0)` in front of the first LDS read that
+// follows the builtin form - here that was the first W^T operand read of EVERY step, right after the request for the next step's
+// slab, i.e. the fetch was waited for instead of overlapping the 64 MFMAs.  Issued this way the wait-count pass does not see the
+// request; the kernel waits itself (`s_waitcnt vmcnt(0)` after the MFMAs), the barriers order it against the readers.
+__device__ __forceinline__ void bf_dma16(bf_i32x4 rsrc, unsigned lds, int voff, int soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
+}
+__device__ __forceinline__ void bf_dma4(bf_i32x4 rsrc, unsigned lds, int voff, int soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
+}
+__device__ __forceinline__ bf_i32x4 bf_rsrc4(const void *ptr, int bytes) {
+  const uint64_t pv = reinterpret_cast<uint64_t>(ptr);
+  bf_i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)pv);
+  r[1] = __builtin_amdgcn_readfirstlane((int)(pv >> 32)) & 0xffff;
+  r[2] = bytes;
+  r[3] = 0x00020000;
+  return r;
+}
+
 struct DcnBwdFusedArgs {
   const float *x, *offset, *mask, *wbk, *dy;
   float *col, *dx, *doffset, *dmask;
@@ -142,25 +164,26 @@ __global__ __launch_bounds__(BF_NT) void dcn_bwd_fused_kernel(const DcnBwdFusedA
     const int gy = wy0 + iy, gx = wx0 + ix;
     xoff[k] = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (gy * a.W + gx) * 4 : OOB;
   }
+  const bf_i32x4 x_rsrc4 = bf_rsrc4(x_img, a.C * P * 4);
+  const bf_i32x4 w_rsrc4 = bf_rsrc4(a.wbk, a.dg * BF_TP * SLAB * 4);
+  const unsigned xs_lds = (unsigned)(size_t)(lvoid *)xs, wsl_lds = (unsigned)(size_t)(lvoid *)wsl;
   auto dma_x = [&](int g) {
 #pragma unroll
     for (int k = 0; k < NXK; ++k)
       if (tid + k * NT < CHS) {  // the lanes past the end are masked off (LDS-DMA writes active lanes only)
 #pragma unroll
-        for (int ch = 0; ch < CPG; ++ch)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lvoid *)(xs + ch * CHS + k * NT + wave * 64), 4, xoff[k], (g * CPG + ch) * P * 4, 0, 0);
+        for (int ch = 0; ch < CPG; ++ch) bf_dma4(x_rsrc4, xs_lds + (ch * CHS + k * NT + wave * 64) * 4, xoff[k], (g * CPG + ch) * P * 4);
       }
   };
   // ---- W^T slab of (group, step) i -> LDS buffer: a linear copy of 17 KB in 16-byte pieces
-  auto dma_w = [&](float *dst, int i) {
+  auto dma_w = [&](int buf, int i) {
     constexpr int TOTAL = SLAB / 4;  // float4 pieces
-    const float *src = a.wbk + (int64_t)i * SLAB;
     for (int q0 = wave * 64; q0 < TOTAL; q0 += NT)
-      if (q0 + lane < TOTAL) __builtin_amdgcn_global_load_lds((gvoid *)(src + (q0 + lane) * 4), (lvoid *)(dst + q0 * 4), 16, 0, 0);
+      if (q0 + lane < TOTAL) bf_dma16(w_rsrc4, wsl_lds + (buf * SLAB + q0 * 4) * 4, (q0 + lane) * 16, i * SLAB * 4);
   };
 
   for (int i = tid; i < TH * PW; i += NT) priv[i] = 0.f;
-  dma_w(wsl, 0);
+  dma_w(0, 0);
   dma_x(0);
   // offsets / mask of the lane's tap of a step: requested at the top of the step, used after its MFMAs
   auto tap_voff = [&](int tp, int &v1, int &v2) {  // lane offsets of (tap plane, pixel) in 9-plane and 18-plane groups
@@ -192,7 +215,7 @@ __global__ __launch_bounds__(BF_NT) void dcn_bwd_fused_kernel(const DcnBwdFusedA
     // slab i - 1 or updates accumulator rows of the step before any more
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const float *slab = wsl + (i & 1) * SLAB;
-    if (i + 1 < n_steps) dma_w(wsl + ((i + 1) & 1) * SLAB, i + 1);
+    if (i + 1 < n_steps) dma_w((i + 1) & 1, i + 1);
     float o_h, o_w, o_m;  // offsets / mask of the lane's tap: requested here, landed by the end of the MFMAs
     fetch_tap(g, TP, o_h, o_w, o_m);
 

@@ -70,22 +70,25 @@ def offset_mask_conv(conv_offset, feat):
     return conv(conv_offset, feat, act=ACT_SIGMOID, act_from=2 * co // 3)
 
 
-ROUGH_LIMIT = float(__import__('os').environ.get('EDVR_DCN_TAPWIN_ROUGH_LIMIT', '6.0'))
-
-
 def halo_hint_from_stats(absmean, rough):
     """Kernel class of the fused DCNv2 forward from the statistics of the PREVIOUS call of the same layer (a performance hint only):
     `absmean` = mean |offset|, `rough` = mean |horizontal neighbour difference| (None = unknown).  The kernel whose staged windows
     follow every tap's displacement (csrc/dcn_tapwin.hip, EDVR_DCN_HALO_TAPWIN) is the default: on a spatially smooth field - what
     conv_offset produces, fresh or trained: per-tap displacements of any size that vary slowly across the image - its cost does not
-    depend on the offsets at all, and it is also the fastest class measured on white-noise fields up to sigma = 4 px
-    (profiles/r4/dcn_sigma_sweep.log).  Only a field that is BOTH large and rough (white noise of many pixels: every tap of every
-    lane through the fix-up pass) goes to the column-buffer path.  Layers the tap-window kernel does not take (widths not a multiple
-    of 4, other group sizes) fall back to the zero-centred halo inside the C entry point."""
-    if rough is not None and rough >= ROUGH_LIMIT and absmean is not None and absmean >= 3.0:
+    depend on the offsets at all (98 - 101 TF/s on the 20 x 128 x 180x320 layer from 0 to 8 px mean |offset|), and it is the fastest
+    class on most white-noise fields too (profiles/r4/dcn_sigma_sweep.log: 99 TF/s at sigma 0.5, 41 at 4, 28 at 16).  Two
+    exceptions, both rough fields: white noise of about a pixel, which the zero-centred R = 7 halo covers completely (83 vs 67
+    TF/s at sigma 1), and white noise of tens of pixels (every tap of every lane through the fix-up pass: the column-buffer path,
+    19 vs 17.5 TF/s at sigma 64).  Layers the tap-window kernel does not take (widths not a multiple of 4, other group sizes) fall
+    back to the zero-centred halo inside the C entry point."""
+    if absmean is None:
+        return ops.DCN_HALO_TAPWIN
+    if rough is None:  # rows that are not 16-byte groups: the tap-window kernel does not take those anyway -> halo classes by magnitude
+        return 3 if absmean < 1.2 else (7 if absmean < 3.0 else -1)
+    if rough >= 0.85 and absmean < 2.0:
+        return 7
+    if rough >= 40.0 and absmean >= 30.0:
         return -1
-    if rough is None and absmean is not None and absmean >= 3.0:
-        return -1  # (no roughness statistic: rows that are not 16-byte groups - the tap-window kernel does not take those anyway)
     return ops.DCN_HALO_TAPWIN
 
 
@@ -98,13 +101,14 @@ def scatter_hint_from_stats(absmean, rough):
     Sub-pixel offsets (fresh or lightly trained conv_offset): the kernels that need no scatter for taps with |offset| < 1.  Anything
     larger goes through the LDS window, whose cost barely depends on the offset field (12.7 - 15.6 ms on smooth multi-pixel fields,
     18 ms on white noise, where device atomics need 30 - 120 ms: profiles/r4/dcn_sigma_sweep.log); device atomics only in the
-    narrow band where most taps are still sub-pixel.  `rough` is accepted for symmetry with the forward's hint; the measured
-    choice does not depend on it."""
+    narrow band where most taps of a ROUGH field are still sub-pixel (a smooth field of that size keeps the no-scatter kernels)."""
     if absmean is None:
         return ops.DCN_SCATTER_LDS
     if absmean < 0.4:  # white-noise offsets of sigma 0.5 (|mean| 0.4): 9 % of the taps already leave the sub-pixel window
         return ops.DCN_SCATTER_STRIP
-    return ops.DCN_SCATTER_DEVICE if absmean < 0.75 and (rough is None or rough >= 0.45) else ops.DCN_SCATTER_LDS
+    if rough is not None and rough < 0.45:  # smooth: per-tap constants - most taps are still sub-pixel up to ~0.6 (11.9 vs 14.8 ms at 0.5)
+        return ops.DCN_SCATTER_STRIP if absmean < 0.6 else ops.DCN_SCATTER_LDS
+    return ops.DCN_SCATTER_DEVICE if absmean < 0.75 else ops.DCN_SCATTER_LDS
 
 
 def scatter_hint_from_absmean(absmean):

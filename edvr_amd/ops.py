@@ -359,16 +359,22 @@ def _ones_mask(offset):
     return torch.ones(offset.shape[0], offset.shape[1] // 2, offset.shape[2], offset.shape[3], dtype=offset.dtype, device=offset.device)
 
 
-def dcnv1_forward(x, offset, weight, stride, pad, dil, groups, dg, halo_hint=0):
-    """DeformConv forward (no mask, no bias): edvr_dcnv1_fwd_f32; float64 / float16: DCNv2 with an all-ones mask on edvr_dcnv2_fwd_any."""
+def dcnv1_forward(x, offset, weight, stride, pad, dil, groups, dg, halo_hint=0, out=None):
+    """DeformConv forward (no mask, no bias): edvr_dcnv1_fwd_f32; float64 / float16: DCNv2 with an all-ones mask on edvr_dcnv2_fwd_any.
+    out: optional preallocated contiguous output written in place."""
     if require_gpu(x, offset, weight, dtypes=tuple(DCN_DTYPES)) != torch.float32:
-        return dcnv2_forward(x, offset, _ones_mask(offset), weight, None, stride, pad, dil, groups, dg)
+        return dcnv2_forward(x, offset, _ones_mask(offset), weight, None, stride, pad, dil, groups, dg, out=out)
     L = _lib.lib()
     offset = _as_planes(offset)
     dims = _dcn_dims(x, weight, stride, pad, dil, groups, dg)
     B, C, H, W, Co, kh, kw = dims[:7]
     ho, wo = offset.shape[2], offset.shape[3]
-    y = torch.empty(B, Co, ho, wo, dtype=torch.float32, device=x.device)
+    if out is not None:
+        if tuple(out.shape) != (B, Co, ho, wo) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:
+            raise RuntimeError(f'out must be a contiguous float32 tensor of shape {(B, Co, ho, wo)} on {x.device}')
+        y = out
+    else:
+        y = torch.empty(B, Co, ho, wo, dtype=torch.float32, device=x.device)
     nbytes = L.edvr_dcnv1_fwd_ws_bytes(*dims)
     ws = workspace(nbytes, x.device)
     _run('dcnv1_fwd', lambda: _lib.check(L.edvr_dcnv1_fwd_f32(_ptr(x), _ptr(offset), _ptr(weight), _ptr(y), *dims, _bstride(offset), halo_hint, _ptr(ws), nbytes,
@@ -421,7 +427,9 @@ def _bstride(t):
     return t.stride(0) if t.shape[0] > 1 else 0
 
 
-def dcnv2_forward(x, offset, mask, weight, bias, stride, pad, dil, groups, dg, act=ACT_NONE, halo_hint=0):
+def dcnv2_forward(x, offset, mask, weight, bias, stride, pad, dil, groups, dg, act=ACT_NONE, halo_hint=0, out=None):
+    """out: optional preallocated (B, Co, Ho, Wo) contiguous tensor the kernels write in place (the reference's `output` argument,
+    deform_conv_cuda.cpp:530-568)."""
     dt = require_gpu(x, offset, mask, weight, bias, dtypes=tuple(DCN_DTYPES))
     L = _lib.lib()
     if not x.is_contiguous() or not weight.is_contiguous():
@@ -436,9 +444,16 @@ def dcnv2_forward(x, offset, mask, weight, bias, stride, pad, dil, groups, dg, a
     Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
     if Ho <= 0 or Wo <= 0:
         raise ValueError(f'convolution input is too small (output would be {Ho}x{Wo})')
-    assert tuple(offset.shape[1:]) == (dg * 2 * kh * kw, Ho, Wo), f'offset shape {tuple(offset.shape)}'
-    assert tuple(mask.shape[1:]) == (dg * kh * kw, Ho, Wo), f'mask shape {tuple(mask.shape)}'
-    y = torch.empty(B, Co, Ho, Wo, dtype=dt, device=x.device)
+    if tuple(offset.shape[1:]) != (dg * 2 * kh * kw, Ho, Wo):  # (RuntimeError like the reference's TORCH_CHECKs, deform_conv_cuda.cpp:64-66)
+        raise RuntimeError(f'invalid spatial size / channels of offset: got {tuple(offset.shape)}, expected (B, {dg * 2 * kh * kw}, {Ho}, {Wo})')
+    if tuple(mask.shape[1:]) != (dg * kh * kw, Ho, Wo):
+        raise RuntimeError(f'invalid spatial size / channels of mask: got {tuple(mask.shape)}, expected (B, {dg * kh * kw}, {Ho}, {Wo})')
+    if out is not None:
+        if tuple(out.shape) != (B, Co, Ho, Wo) or out.dtype != dt or not out.is_contiguous() or out.device != x.device:
+            raise RuntimeError(f'out must be a contiguous {dt} tensor of shape {(B, Co, Ho, Wo)} on {x.device}')
+        y = out
+    else:
+        y = torch.empty(B, Co, Ho, Wo, dtype=dt, device=x.device)
     if dt != torch.float32:  # float64 / float16: the reference's other dispatch legs (csrc/dcn_any.hip); no fused activation there
         if act != ACT_NONE:
             raise NotImplementedError('the fused activation of dcnv2_forward exists in fp32 only')

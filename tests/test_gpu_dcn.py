@@ -293,6 +293,6 @@ def test_offset_statistics_kernels(gpu):
     r4 = ref.view(2, 144, 16, 16, 4)
     assert _rel(stats[0], ref.abs().sum((1, 2, 3))) < 1e-4
     assert _rel(stats[1], (r4[..., 1:] - r4[..., :-1]).abs().sum((1, 2, 3, 4))) < 1e-4
-    assert F_.halo_hint_from_stats(3.0, 0.1) == ops.DCN_HALO_TAPWIN and F_.halo_hint_from_stats(13.0, 18.0) == -1
-    assert F_.halo_hint_from_stats(None, None) == ops.DCN_HALO_TAPWIN
+    assert F_.halo_hint_from_stats(3.0, 0.1) == ops.DCN_HALO_TAPWIN and F_.halo_hint_from_stats(51.0, 72.0) == -1
+    assert F_.halo_hint_from_stats(None, None) == ops.DCN_HALO_TAPWIN and F_.halo_hint_from_stats(0.8, 1.1) == 7
     assert F_.scatter_hint_from_stats(3.0, 0.1) == ops.DCN_SCATTER_LDS and F_.scatter_hint_from_stats(0.2, 0.1) == ops.DCN_SCATTER_STRIP

@@ -82,14 +82,16 @@ def test_kernel_hints_from_offset_statistics():
     assert F_.scatter_hint_from_absmean(0.05) == ops.DCN_SCATTER_STRIP     # fresh conv_offset: sub-pixel, no scatter at all
     assert F_.scatter_hint_from_absmean(0.6) == ops.DCN_SCATTER_DEVICE
     assert F_.scatter_hint_from_absmean(3.0) == ops.DCN_SCATTER_LDS
-    # forward: the per-tap-window kernel unless the field is both large and rough (or large with the roughness unknown)
+    # forward: the per-tap-window kernel except on rough fields of about a pixel (R = 7 halo) or of tens of pixels (column buffer)
     T = ops.DCN_HALO_TAPWIN
-    assert T == 16 and F_.halo_hint_from_stats(None, None) == T and F_.halo_hint_from_stats(0.4, None) == T
-    assert F_.halo_hint_from_stats(8.0, 0.2) == T and F_.halo_hint_from_stats(3.2, 4.5) == T
-    assert F_.halo_hint_from_stats(12.8, 18.0) == -1 and F_.halo_hint_from_stats(8.0, None) == -1
-    # backward: the roughness statistic does not change the measured choice beyond the sub-pixel band
+    assert T == 16 and F_.halo_hint_from_stats(None, None) == T and F_.halo_hint_from_stats(0.4, 0.56) == T
+    assert F_.halo_hint_from_stats(8.0, 0.2) == T and F_.halo_hint_from_stats(3.2, 4.5) == T and F_.halo_hint_from_stats(12.8, 18.0) == T
+    assert F_.halo_hint_from_stats(0.8, 1.13) == 7 and F_.halo_hint_from_stats(51.0, 72.0) == -1
+    assert F_.halo_hint_from_stats(0.4, None) == 3 and F_.halo_hint_from_stats(8.0, None) == -1
+    # backward
     assert F_.scatter_hint_from_stats(8.0, 0.2) == ops.DCN_SCATTER_LDS and F_.scatter_hint_from_stats(8.0, 1.5) == ops.DCN_SCATTER_LDS
-    assert F_.scatter_hint_from_stats(0.1, 0.2) == ops.DCN_SCATTER_STRIP and F_.scatter_hint_from_stats(0.6, 0.17) == ops.DCN_SCATTER_LDS
+    assert F_.scatter_hint_from_stats(0.1, 0.2) == ops.DCN_SCATTER_STRIP and F_.scatter_hint_from_stats(0.5, 0.17) == ops.DCN_SCATTER_STRIP
+    assert F_.scatter_hint_from_stats(0.6, 1.0) == ops.DCN_SCATTER_DEVICE and F_.scatter_hint_from_stats(1.6, 0.17) == ops.DCN_SCATTER_LDS
     st = torch.tensor([[6.0, 2.0], [3.0, 0.0]])  # (2, n) sums of abs_stats_per_image over 16 elements in all
     assert ops.offset_stats(st, 16) == (0.5, 0.25) and ops.offset_stats(torch.tensor([[8.0], [-1.0]]), 16) == (0.5, None)
     assert (ops.DCN_SCATTER_AUTO, ops.DCN_SCATTER_DEVICE, ops.DCN_SCATTER_LDS, ops.DCN_SCATTER_STRIP) == (0, 1, 2, 3)
