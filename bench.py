@@ -453,8 +453,9 @@ def trained_like_leg(cfg, batch, args, device, rank, world, dist, sigmas=(4.0, 1
             if not args.no_roofline:
                 per = instrumented_pass(step, 1)
                 tab = kernel_table(per, 1, elapsed / steps)
-                if 'dcnv2_fwd' in tab:
-                    rec['dcnv2_fwd'] = tab['dcnv2_fwd']
+                for k, v in tab.items():
+                    if k.startswith('dcnv2_fwd'):
+                        rec[k] = v
             if world == 1 and not args.no_stock_baseline:
                 from oracle import dcn_oracle, edvr_oracle as EO
                 try:
@@ -711,7 +712,8 @@ def main():
             result['trained_like'] = tl
             for rec in tl.values():
                 rec['vs_headline'] = round(rec['value'] / result['value'], 4)
-    if args.workload == 'edvr_l_x4_t5_180x320' and args.mode == 'infer' and not args.no_configs:
+    if args.workload == 'edvr_l_x4_t5_180x320' and args.mode == 'infer' and not args.no_configs and world == 1:
+        # (N = 1 only: a configuration that fails on ONE rank - out of memory - must not leave the others waiting in a collective)
         net = None  # (the headline network is not needed any more: the remaining legs build their own)
         torch.cuda.empty_cache()
         cf = configs_leg(args, device, rank, world, dist)  # all ranks

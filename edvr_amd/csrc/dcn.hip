@@ -759,6 +759,23 @@ int edvr_dcnv2_fwd_f32(const float *x, const float *offset, const float *mask, c
   return EDVR_OK;
 }
 
+int edvr_dcnv2_fwd_kernel_name(const float *x, int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil, int groups,
+                               int dg, int halo_hint, char *buf, size_t buf_len) {
+  using namespace edvr;
+  EDVR_REQUIRE(buf && buf_len > 0, "dcnv2_fwd_kernel_name: null buffer");
+  DcnShape s;
+  int rc = dcn_fill_shape(s, B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, 0, 0);
+  if (rc) return rc;
+  const char *name = "dcn_im2col_kernel";
+  if (use_fused(s) && halo_hint >= 0) {
+    const bool tapwin = halo_hint == EDVR_DCN_HALO_TAPWIN && dcn_tapwin_supported(C, Co, H, W, kh, kw, s.stride, s.pad, s.dil, groups, dg) &&
+                        (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    name = tapwin ? "dcn_tapwin_fwd_kernel" : "dcn_fused_fwd_kernel";
+  }
+  snprintf(buf, buf_len, "%s", name);
+  return EDVR_OK;
+}
+
 int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, const float *weight, const float *dy, float *dx,
                        float *doffset, float *dmask, float *dweight, float *dbias, int B, int C, int H, int W, int Co, int kh,
                        int kw, int stride, int pad, int dil, int groups, int dg, int64_t offset_bstride, int64_t mask_bstride,

@@ -11,7 +11,7 @@
 //   walk (deformable group g) -> (tap t) -> (channel pair):  one step = one (g, t) = 16 channels x MT x 32 output channels.
 //   Per step the input window of the group's channels is fetched by LDS-DMA around  tile + regular tap position + s(g, t),
 //   s = the rounded mid-range of that tap's offsets over the tile (a small pre-pass per workgroup): 12 rows x 40 columns per
-//   channel in 16-byte pieces, i.e. +-2 px of slack around the 8 x 32 pixel tile in both directions after the shift (the
+//   channel (dense, 480 floats) in 16-byte pieces, i.e. +-2 px of slack around the 8 x 32 pixel tile in both directions after the shift (the
 //   columns start on a multiple of 4 so that every piece is one aligned dwordx4).  Pieces outside the image carry an
 //   out-of-range buffer offset and arrive as zeros: the reference's per-corner bounds test (.cu:481-491) falls out of the data.
 //   A lane whose 2x2 cell still leaves the window (an object boundary inside the tile, a rough field) takes a wave-uniform
@@ -23,7 +23,7 @@
 //   (sub-tiles): every weight operand read from LDS feeds 2 x MT MFMAs instead of MT.
 //
 // Per workgroup (256 threads, 4 waves, 2 workgroups per CU): 8 x 32 output pixels x up to 128 output channels.
-// LDS: 2 x 31 KB windows + 2 x 8 KB weight slabs (both double-buffered, both by LDS-DMA: no staging registers) + the shifts.
+// LDS: 2 x 30 KB windows + 2 x 8 KB weight slabs (both double-buffered, both by LDS-DMA: no staging registers) + the shifts.
 // One barrier per step (64 MFMAs per wave); nothing waits on vector memory between the DMA issue at the top of a step and the
 // last MFMA of the step (no scratch, tap values consumed after the MFMAs).
 #include <type_traits>
@@ -43,9 +43,10 @@ constexpr int TWN_IH = TWN_TH + 2 * TWN_RY;               // 12 rows: fl(dy) - s
 constexpr int TWN_IW = (TWN_TW + 2 * TWN_RX + 3 + 3) / 4 * 4;  // 40 columns: 36 needed + up to 3 lost to the 16-byte alignment
 constexpr int TWN_PPR = TWN_IW / 4;                       // 10 16-byte pieces per row
 constexpr int TWN_HR = TWN_IH / 2;                        // one DMA instruction moves 6 rows x 10 pieces (lanes 0-59) of one channel
-constexpr int TWN_HB = 256;                               // ... to a 1 KB block: rows 0-5 at float 0, rows 6-11 at float 256 of the channel
-constexpr int TWN_CHS = TWN_HB + TWN_HR * TWN_IW;         // 496 floats per channel (16 floats of padding after the first half)
-static_assert(TWN_HR * TWN_PPR <= 64 && TWN_HR * TWN_IW <= TWN_HB && TWN_IH == 2 * TWN_HR, "window halves must fit one wave instruction");
+constexpr int TWN_HB = TWN_HR * TWN_IW;                   // ... to floats [0, 240) / [240, 480) of the channel: the rows stay dense
+constexpr int TWN_CHS = TWN_IH * TWN_IW;                  // 480 floats per channel = 32 (mod 64): the two half-waves of a gather (channels
+                                                          // c / c + 1, same position) fall on disjoint halves of the 64 LDS banks
+static_assert(TWN_HR * TWN_PPR <= 64 && TWN_IH == 2 * TWN_HR && TWN_CHS % 64 == 32, "window halves must fit one wave instruction");
 constexpr int TWN_MAX_DG = 16;
 constexpr int TWN_OOB = (int)0x80000000;
 constexpr int TWN_RSRC_FLAGS = 0x00020000;
@@ -91,7 +92,7 @@ template <int MT, int CPG>
 __global__ __launch_bounds__(256, 2) void dcn_tapwin_fwd_kernel(const DcnTapwinArgs a) {
   constexpr int TH = TWN_TH, TW = TWN_TW, IH = TWN_IH, IW = TWN_IW, CHS = TWN_CHS, KK = 9, OOB = TWN_OOB;
   constexpr int MB = 32 * MT, NQ = CPG / 2;
-  constexpr int XW = CPG * CHS;            // floats of one window buffer (16 channels: 7936 = 31 KB)
+  constexpr int XW = CPG * CHS;            // floats of one window buffer (16 channels: 7680 = 30 KB)
   constexpr int WS = CPG * MB;             // floats of one weight slab (16 x 128: 8 KB)
   constexpr int CPW = CPG / 4;             // channels whose window this wave fetches (2 instructions each)
   static_assert(CPG % 4 == 0, "four waves share the channels of a group");
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void dcn_tapwin_fwd_kernel(const DcnTapwinA
 
   // ---- per-step sampling state of the two pixels
   float bw[2][4];
-  int addr[2], addr2[2];  // upper / lower row of the 2x2 cell (the rows of a window are not equidistant: see TWN_HB)
+  int addr[2];
   unsigned slow = 0;      // bit s: the 2x2 cell of sub-tile s's pixel is valid but not inside the staged window
   unsigned slow_any = 0;  // any lane of the wave (scalar)
   auto make_state = [&](int t, int wy0, int wx0, const float (&d)[6]) {
@@ -227,9 +228,7 @@ __global__ __launch_bounds__(256, 2) void dcn_tapwin_fwd_kernel(const DcnTapwinA
       bw[s][1] = inside ? (1.f - lh) * lw * m : 0.f;
       bw[s][2] = inside ? lh * (1.f - lw) * m : 0.f;
       bw[s][3] = inside ? lh * lw * m : 0.f;
-      const int rya = inside ? ry : 0, rxa = inside ? rx : 0;
-      addr[s] = half * CHS + rya * IW + (rya >= TWN_HR ? TWN_HB - TWN_HR * IW : 0) + rxa;
-      addr2[s] = half * CHS + (rya + 1) * IW + (rya + 1 >= TWN_HR ? TWN_HB - TWN_HR * IW : 0) + rxa;
+      addr[s] = half * CHS + (inside ? ry * IW + rx : 0);
       if (valid && !inside) slow |= 1u << s;
     }
     slow_any = __builtin_amdgcn_readfirstlane(__any(slow != 0) ? 1 : 0);
@@ -241,11 +240,11 @@ __global__ __launch_bounds__(256, 2) void dcn_tapwin_fwd_kernel(const DcnTapwinA
     auto issue = [&](int q, float (&c)[2][4], float (&aw)[MT]) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const float *cell = xb + addr[s] + 2 * q * CHS, *cell2 = xb + addr2[s] + 2 * q * CHS;
+        const float *cell = xb + addr[s] + 2 * q * CHS;
         c[s][0] = cell[0];
         c[s][1] = cell[1];
-        c[s][2] = cell2[0];
-        c[s][3] = cell2[1];
+        c[s][2] = cell[IW];
+        c[s][3] = cell[IW + 1];
       }
       const float *ap = wb + (2 * q + half) * MB + j * MT;  // slab rows are stored [j][m] (dcn_fused_pack_kernel): MT adjacent weights
       if constexpr (MT == 4) {
@@ -290,18 +289,31 @@ __global__ __launch_bounds__(256, 2) void dcn_tapwin_fwd_kernel(const DcnTapwinA
         }
       }
     } else {
+      // Three-stage software pipeline over the channel pairs: stage q issues the LDS reads of pair q + 2, the bilinear arithmetic
+      // of pair q + 1 and the 2 MT MFMAs of pair q.  (Left free, hipcc sinks every LDS read to just before its first use - `ds_read ...
+      // s_waitcnt lgkmcnt(0) ... 7 VALU ... 4 MFMAs` per group; measured on four schedules, from that one to DS / MFMA / VALU groups
+      // pinned instruction by instruction: 100.1 - 100.9 TF/s all of them - with two waves per SIMD one wave's gaps are the other's
+      // issue slots.  profiles/r4/tapwin_sched_ab.log)
       float cv[3][2][4], av[3][MT];
       issue(0, cv[0], av[0]);
       if (NQ > 1) issue(1, cv[1], av[1]);
+      float b0 = sample(0, cv[0][0]), b1 = sample(1, cv[0][1]);
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        const int cur = q % 3;
-        if (q + 2 < NQ) issue(q + 2, cv[(q + 2) % 3], av[(q + 2) % 3]);
-        const float b0 = sample(0, cv[cur][0]), b1 = sample(1, cv[cur][1]);
+        const int cur = q % 3, n1 = (q + 1) % 3, n2 = (q + 2) % 3;
+        if (q + 2 < NQ) issue(q + 2, cv[n2], av[n2]);
+        float nb0 = 0.f, nb1 = 0.f;
+        if (q + 1 < NQ) {
+          nb0 = sample(0, cv[n1][0]);
+          nb1 = sample(1, cv[n1][1]);
+        }
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][m], b0, acc[0][m], 0, 0, 0);
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][m], b1, acc[1][m], 0, 0, 0);
+        b0 = nb0;
+        b1 = nb1;
+        __builtin_amdgcn_sched_barrier(0);  // stage boundary: nothing moves across (finer pinning - DS / MFMA / VALU groups - measured: no difference)
       }
     }
   };

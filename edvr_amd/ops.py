@@ -464,7 +464,12 @@ def dcnv2_forward(x, offset, mask, weight, bias, stride, pad, dil, groups, dg, a
         return y
     nbytes = L.edvr_dcnv2_fwd_ws_bytes(*dims)
     ws = workspace(nbytes, x.device)
-    _run('dcnv2_fwd', lambda: _lib.check(L.edvr_dcnv2_fwd_f32(_ptr(x), _ptr(offset), _ptr(mask), _ptr(weight), _ptr(bias), _ptr(y), *dims,
+    name = 'dcnv2_fwd'
+    if LAUNCH_HOOK is not None:  # measurement only (bench.py): which kernel class this call runs on
+        buf = ctypes.create_string_buffer(64)
+        if L.edvr_dcnv2_fwd_kernel_name(_ptr(x), *dims, int(halo_hint), buf, 64) == 0:
+            name = f'dcnv2_fwd[{buf.value.decode()}]'
+    _run(name, lambda: _lib.check(L.edvr_dcnv2_fwd_f32(_ptr(x), _ptr(offset), _ptr(mask), _ptr(weight), _ptr(bias), _ptr(y), *dims,
                                     _bstride(offset), _bstride(mask), act, halo_hint, _ptr(ws), nbytes, _stream()),
                                        'edvr_dcnv2_fwd_f32'), 2.0 * B * Co * Ho * Wo * weight.shape[1] * kh * kw, _nb(x, offset, mask, weight, y))
     return y

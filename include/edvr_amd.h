@@ -197,6 +197,11 @@ int edvr_dcnv2_fwd_f32(const float *x, const float *offset, const float *mask, c
                        int pad, int dil, int groups, int dg, int64_t offset_bstride, int64_t mask_bstride, int act,
                        int halo_hint, void *ws, size_t ws_bytes, edvr_stream_t stream);
 
+/* Name of the kernel edvr_dcnv2_fwd_f32 would launch for these arguments (as rocprofv3 prints it): dcn_tapwin_fwd_kernel,
+ * dcn_fused_fwd_kernel or dcn_im2col_kernel (+ the conv kernel of its GEMM).  Measurement aid only. */
+int edvr_dcnv2_fwd_kernel_name(const float *x, int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil,
+                               int groups, int dg, int halo_hint, char *buf, size_t buf_len);
+
 size_t edvr_dcnv2_bwd_ws_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil,
                                int groups, int dg);
 /* Gradients are OVERWRITTEN (no pre-zeroing needed).  dbias may be NULL.  dx accumulates by fp32

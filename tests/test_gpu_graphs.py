@@ -95,3 +95,34 @@ def test_graph_replay_latency_on_a_small_clip(gpu):
     print(f'EDVR-M 64x64 b1: eager {t_eager * 1e3:.2f} ms, graph replay {t_graph * 1e3:.2f} ms per clip')
     assert torch.equal(g(x), eager())
     assert t_graph < 1.15 * t_eager
+
+
+def test_graph_keeps_its_packed_weights_through_a_training_step(gpu):
+    """The captured launches read the packed weight layouts of capture time.  The training path re-packs every layout after an
+    optimizer step, IN PLACE where the cache is the buffer's only owner (ops.prepack_conv_weights): the graph pins its layouts
+    (ops.pin_packed_weights), so a replay with check_weights=False keeps producing the capture-time result, bit for bit, and the
+    eager path sees the new weights."""
+    from edvr_amd import ops
+    from edvr_amd.graphs import GraphedEDVR
+    net, x, _ = build('M_T5')
+    net = net.to(gpu)
+    xg = x.to(gpu)
+    g = GraphedEDVR(net, xg, check_weights=False)
+    before = g(xg).clone()
+    pinned = set(ops._PINNED_PACKED)
+    assert pinned
+    net.train()
+    opt = torch.optim.SGD(net.parameters(), lr=1e-3)
+    for _ in range(2):  # forward (packs the current versions) + backward + step (new versions)
+        opt.zero_grad()
+        net(xg).square().mean().backward()
+        opt.step()
+    net.eval()
+    with torch.no_grad():
+        after = net(xg).clone()
+    assert not torch.equal(after, before)       # the eager path runs on the updated weights
+    assert torch.equal(g(xg), before)           # the replay still reads the layouts it was captured with
+    assert pinned <= set(ops._PINNED_PACKED)
+    g.refresh()
+    assert torch.equal(g(xg), after)
+    del g
