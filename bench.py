@@ -20,6 +20,7 @@ Objects in the line besides the contract's fields (everything below runs OUTSIDE
                       timed the same way (barrier + synchronize, max over ranks), with its F(4x4) roofline fraction and parity
                       (max rel err, dPSNR) against the stock-PyTorch-ROCm arm on the same clip.
   train               BASELINE.json's second headline (training iters/sec) on the cfg4 per-GPU shape, run on ALL ranks (DDP), with
+                      `trained_like` (the same step with multi-pixel per-tap offsets: what the DCN backward costs there) and
                       `parity`: the same 2-clip batch and weights through oracle/edvr_oracle.py in stock fp32 torch ops + torch
                       autograd on this GPU - loss and every parameter gradient compared (the bounds of tests/test_gpu_train.py).
   trained_like        the headline workload with the offsets a TRAINED EDVR predicts: conv_offset.bias ~ N(0, 4^2) / N(0, 10^2) per
@@ -527,6 +528,22 @@ def train_leg(args, device, rank, world, dist):
         for key, label in (('conv3x3_winograd_f4_kernel', 'fwd_dgrad_f4'), ('conv3x3_winograd_kernel', 'fwd_dgrad_f2'), ('conv3x3_winograd_wgrad_kernel', 'wgrad')):
             if key in tab:
                 out[f'{label}_mfma_frac'] = tab[key]['frac_of_mfma_peak']
+    if not args.no_trained_like:
+        # the same training step with the offsets of a TRAINED model (conv_offset.bias ~ N(0, 4^2): every tap its own multi-pixel
+        # displacement): the forward's cost does not change (tap-window kernel), the backward's dX leaves the no-scatter kernels
+        del step, net
+        torch.cuda.empty_cache()
+        net = build_net(cfg, device, offset_bias_sigma=4.0)
+        step = make_train_step(net, cfg, cfg['batch'], device, rank, 'fused')
+        tsteps = 10
+        e2 = timed(step, tsteps, 3, dist, device)  # all ranks (DDP collectives)
+        tl = {'offset_bias_sigma': 4.0, 'iters_per_sec': round(tsteps / e2, 4), 'ms_per_iter': round(e2 / tsteps * 1e3, 2), 'steps': tsteps,
+              'vs_sub_pixel_offsets': round((tsteps / e2) / (args.train_steps / elapsed), 4)}
+        if rank == 0 and not args.no_roofline and world == 1:
+            tab = kernel_table(instrumented_pass(step, 1), 1, e2 / tsteps)
+            tl['dcn_kernels'] = {k: v for k, v in tab.items() if k.startswith('dcnv2')}
+            tl['mean_abs_offset_px'] = [round(m.last_offset_absmean, 3) for m in net.pcd_align.dcn_modules()]
+        out['trained_like'] = tl
     if rank == 0 and world == 1 and not args.no_stock_baseline:
         del step, net
         step = None

@@ -190,6 +190,86 @@ class REDSClipPlanner:
         return lq_out, gt_out
 
 
+class Vimeo90KClipPlanner:
+    """The decisions of Vimeo90KDataset.__getitem__ (the TRAINING set, basicsr/data/vimeo90k_dataset.py:10-134) for the same loader:
+    7-frame sequences `<root>/<clip>/<seq>/im1.png .. im7.png`, keys from the meta file (`00001/0001 7 (256,448,3)`), GT = im4,
+    the centred window of `num_frame` frames, and the reference's draws in its order: [reverse], crop top, crop left, [hflip],
+    [vflip], [rot90].  The reference reverses its neighbour list IN PLACE (:82-83), so the orientation persists from one sample to
+    the next: plan() keeps that state too (one planner = one dataset object)."""
+
+    def __init__(self, opt, client=None):
+        self.opt = opt
+        self.num_frame = opt['num_frame']
+        self.scale, self.gt_size = opt['scale'], opt['gt_size']
+        self.lq_size = self.gt_size // self.scale
+        with open(opt['meta_info_file'], 'r') as fin:
+            self.keys = [line.split(' ')[0] for line in fin]
+        self.neighbor_list = [i + (9 - self.num_frame) // 2 for i in range(self.num_frame)]
+        self.random_reverse = opt['random_reverse']
+        roots = {'lq': opt['dataroot_lq'], 'gt': opt['dataroot_gt']}
+        backend = dict(opt['io_backend'])['type']
+        if client is not None:
+            self.client = client
+        elif backend == 'lmdb':
+            self.client = LmdbClient(roots)
+        elif backend == 'disk':
+            self.client = DiskClient(roots)
+        else:
+            raise ValueError(f'io_backend {backend} is not supported (disk, lmdb)')
+
+    def __len__(self):
+        return len(self.keys)
+
+    def reset_epoch(self):
+        """Canonical orientation of the neighbour list at the start of an epoch: what a fresh DataLoader worker's copy of the
+        dataset has in the reference (workers are re-created per epoch), and what makes an epoch a function of (seed, epoch) only."""
+        self.neighbor_list = [i + (9 - self.num_frame) // 2 for i in range(self.num_frame)]
+
+    def plan(self, index, rng=random):
+        if self.random_reverse and rng.random() < 0.5:
+            self.neighbor_list.reverse()
+        key = self.keys[index]
+        frames = list(self.neighbor_list)
+        h_lq, w_lq = self.client.size('lq', key, f'im{frames[0]}')
+        h_gt, w_gt = self.client.size('gt', key, 'im4')
+        if h_gt != h_lq * self.scale or w_gt != w_lq * self.scale:
+            raise ValueError(f'Scale mismatches. GT ({h_gt}, {w_gt}) is not {self.scale}x multiplication of LQ ({h_lq}, {w_lq}).')
+        if h_lq < self.lq_size or w_lq < self.lq_size:
+            raise ValueError(f'LQ ({h_lq}, {w_lq}) is smaller than patch size ({self.lq_size}, {self.lq_size}). Please remove {key}.')
+        top = rng.randint(0, h_lq - self.lq_size)
+        left = rng.randint(0, w_lq - self.lq_size)
+        flags = 0
+        if self.opt['use_flip'] and rng.random() < 0.5:
+            flags |= AUG_HFLIP
+        if self.opt['use_rot'] and rng.random() < 0.5:
+            flags |= AUG_VFLIP
+        if self.opt['use_rot'] and rng.random() < 0.5:
+            flags |= AUG_ROT90
+        return ClipPlan(key, key, 4, frames, top, left, flags)
+
+    def load(self, plan, lq_out=None, gt_out=None):
+        p, P, s = self.lq_size, self.gt_size, self.scale
+        if lq_out is None:
+            lq_out = np.empty((self.num_frame, p, p, 3), np.uint8)
+        if gt_out is None:
+            gt_out = np.empty((P, P, 3), np.uint8)
+        for i, f in enumerate(plan.frames):
+            lq_out[i] = decode_image(self.client.get('lq', plan.clip, f'im{f}'))[plan.top:plan.top + p, plan.left:plan.left + p]
+        gt_out[...] = decode_image(self.client.get('gt', plan.clip, 'im4'))[plan.top * s:plan.top * s + P, plan.left * s:plan.left * s + P]
+        return lq_out, gt_out
+
+
+def make_planner(opt, client=None):
+    """The planner of a training dataset option block, chosen like the reference's dataset registry does: by `type`
+    (`REDSDataset` - the default - or `Vimeo90KDataset`; options/train/EDVR/*.yml use the former)."""
+    kind = opt.get('type', 'REDSDataset')
+    if kind == 'REDSDataset':
+        return REDSClipPlanner(opt, client)
+    if kind == 'Vimeo90KDataset':
+        return Vimeo90KClipPlanner(opt, client)
+    raise ValueError(f'dataset type {kind} is not supported (REDSDataset, Vimeo90KDataset)')
+
+
 class EnlargedSampler:
     """Per-rank index order for iteration-based training (data_sampler.py:6-49): a seeded permutation of `ratio` copies of the
     dataset, strided over the ranks - the clip sharding of the data-parallel step (no data-path collective)."""
@@ -363,7 +443,7 @@ def epoch_rng(seed, epoch):
 
 
 class REDSDeviceLoader:
-    """REDSDataset + DataLoader + EnlargedSampler + CUDAPrefetcher in one object, one per rank.
+    """REDSDataset (or Vimeo90KDataset: `opt['type']`) + DataLoader + EnlargedSampler + CUDAPrefetcher in one object, one per rank.
 
     next() -> {'lq': (b, t, 3, p, p), 'gt': (b, 3, P, P) float32 device tensors, 'key': [str]} or None at the end of the epoch
     (CUDAPrefetcher.next, prefetch_dataloader.py:118-122); reset() starts the next epoch.  A planner thread makes the random
@@ -374,7 +454,7 @@ class REDSDeviceLoader:
                  client=None):
         if not torch.cuda.is_available():
             raise RuntimeError('REDSDeviceLoader needs a GPU (uint8 staging is converted on the device; there is no CPU fallback)')
-        self.planner = REDSClipPlanner(opt, client)
+        self.planner = make_planner(opt, client)  # REDSDataset (default) or Vimeo90KDataset, by opt['type']
         self.sampler = EnlargedSampler(self.planner, world_size, rank, ratio)
         self.batch_size, self.device, self.drop_last = batch_size, torch.device(device), drop_last
         self.seed = seed + rank  # the reference seeds every worker with seed + rank * workers + id (data/__init__.py)
@@ -399,6 +479,8 @@ class REDSDeviceLoader:
         self.stop = threading.Event()
         self.sampler.set_epoch(self.epoch)
         self.rng = epoch_rng(self.seed, self.epoch)
+        if hasattr(self.planner, 'reset_epoch'):
+            self.planner.reset_epoch()
         self.thread = threading.Thread(target=self._produce, args=(list(self.sampler), self.stop, self.free, self.ready), daemon=True)
         self.thread.start()
         self.batch = None

@@ -129,6 +129,26 @@ def reds_getitem(keys, opt, index, rng, fetch):
     return dict(lq=torch.stack(tens[:-1], 0), gt=tens[-1], key=key, frames=neighbors, center=center, top=top, left=left, aug=aug)
 
 
+def vimeo90k_neighbor_list(num_frame):
+    """vimeo90k_dataset.py:69-71."""
+    return [i + (9 - num_frame) // 2 for i in range(num_frame)]
+
+
+def vimeo90k_getitem(keys, opt, index, rng, fetch, neighbor_list):
+    """vimeo90k_dataset.py:73-131.  `neighbor_list` is the dataset object's list and is REVERSED IN PLACE when the reverse draw
+    hits (:82-83) - the orientation persists into the following samples, as in the reference.  fetch(kind, 'clip/seq', 'im<n>') ->
+    uint8 BGR.  The GT frame is always im4."""
+    if opt['random_reverse'] and rng.random() < 0.5:
+        neighbor_list.reverse()
+    key = keys[index]
+    img_gt = imfrombytes_float(fetch('gt', key, 'im4'))
+    img_lqs = [imfrombytes_float(fetch('lq', key, f'im{n}')) for n in neighbor_list]
+    img_gt, img_lqs, top, left = paired_random_crop(img_gt, img_lqs, opt['gt_size'], opt['scale'], rng)
+    imgs, aug = augment(img_lqs + [img_gt], opt['use_flip'], opt['use_rot'], rng)
+    tens = [img2tensor(i) for i in imgs]
+    return dict(lq=torch.stack(tens[:-1], 0), gt=tens[-1], key=key, frames=list(neighbor_list), top=top, left=left, aug=aug)
+
+
 def read_img_seq(frames_bgr_u8, require_mod_crop=False, scale=1):
     """data_util.py:11-33 on decoded frames: (t, 3, h, w) RGB float32 in [0, 1]."""
     imgs = [imfrombytes_float(f) for f in frames_bgr_u8]

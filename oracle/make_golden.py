@@ -356,6 +356,105 @@ def data_case():
             sys.modules[k] = m
 
 
+def vimeo_train_case():
+    """Vimeo90KDataset (training; basicsr/data/vimeo90k_dataset.py:10-134) of the reference, executed from its source on synthetic
+    7-frame sequences through the same numpy stand-ins for cv2 as data_case.  The class REVERSES ITS NEIGHBOUR LIST IN PLACE
+    (:82-83): the state carries over from one sample to the next, so the samples are drawn from one dataset object in sequence and
+    the fixture records that order."""
+    import importlib.util
+    import logging
+    import random
+    import struct
+    import sys
+    import types
+    import numpy as np
+    from oracle import data_oracle as DO
+
+    cv2 = types.ModuleType('cv2')
+    cv2.IMREAD_COLOR, cv2.IMREAD_GRAYSCALE, cv2.IMREAD_UNCHANGED, cv2.COLOR_BGR2RGB = 1, 0, -1, 4
+
+    def flip(src, code, dst=None):
+        out = src[:, ::-1].copy() if code == 1 else src[::-1].copy()
+        if dst is not None:
+            dst[...] = out
+            return dst
+        return out
+
+    def imdecode(buf, flag):  # b'RAW0' + <h, w> + BGR bytes
+        raw = buf.tobytes()
+        assert raw[:4] == b'RAW0' and flag == cv2.IMREAD_COLOR
+        h, w = struct.unpack('<ii', raw[4:12])
+        return np.frombuffer(raw[12:], np.uint8).reshape(h, w, 3).copy()
+
+    cv2.flip, cv2.imdecode = flip, imdecode
+    cv2.cvtColor = lambda img, code: np.ascontiguousarray(img[:, :, ::-1])
+    names = ('cv2', 'torchvision', 'torchvision.utils', 'basicsr', 'basicsr.utils', 'basicsr.data', 'basicsr.utils.img_util',
+             'basicsr.data.transforms', 'basicsr.data.vimeo90k_dataset')
+    saved = {k: sys.modules.get(k) for k in names}
+    sys.modules['cv2'] = cv2
+    tv, tvu = types.ModuleType('torchvision'), types.ModuleType('torchvision.utils')
+    tvu.make_grid = None
+    sys.modules['torchvision'], sys.modules['torchvision.utils'] = tv, tvu
+
+    def load(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join('/root/reference', rel))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+        return mod
+
+    for pkg in ('basicsr', 'basicsr.utils', 'basicsr.data'):
+        m = types.ModuleType(pkg)
+        m.__path__ = []
+        sys.modules[pkg] = m
+    img_util = load('basicsr.utils.img_util', 'basicsr/utils/img_util.py')
+    LQ_HW, SCALE = (16, 28), 4
+
+    class FileClient:  # disk backend: <root>/<clip>/<seq>/im<n>.png -> bytes of synthetic_frame(kind, '<clip>/<seq>', 'im<n>')
+        def __init__(self, backend, **kw):
+            assert backend == 'disk'
+
+        def get(self, path, client_key):
+            clip, seq, frame = str(path).split('/')[-3:]
+            h, w = LQ_HW if client_key == 'lq' else (LQ_HW[0] * SCALE, LQ_HW[1] * SCALE)
+            return b'RAW0' + struct.pack('<ii', h, w) + DO.synthetic_frame(client_key, f'{clip}/{seq}', frame[:-4], h, w).tobytes()
+
+    u = sys.modules['basicsr.utils']
+    u.FileClient, u.get_root_logger = FileClient, lambda: logging.getLogger('ref')
+    u.imfrombytes, u.img2tensor = img_util.imfrombytes, img_util.img2tensor
+    load('basicsr.data.transforms', 'basicsr/data/transforms.py')
+    vim = load('basicsr.data.vimeo90k_dataset', 'basicsr/data/vimeo90k_dataset.py')
+
+    meta = [f'{c:05d}/{q:04d} 7 (64,112,3)\n' for c, q in ((1, 1), (1, 2), (1, 266), (2, 1), (3, 7), (96, 1000))]
+    meta_path = '/tmp/edvr_meta_info_vimeo_golden.txt'
+    with open(meta_path, 'w') as f:
+        f.writelines(meta)
+    out = dict(meta=meta, lq_hw=LQ_HW, scale=SCALE, runs=[])
+    variants = [dict(num_frame=7, random_reverse=False, use_flip=True, use_rot=True),
+                dict(num_frame=5, random_reverse=True, use_flip=True, use_rot=True),
+                dict(num_frame=3, random_reverse=True, use_flip=False, use_rot=True),
+                dict(num_frame=5, random_reverse=True, use_flip=True, use_rot=False)]  # (num_frame = 1 crashes in the reference: :116)
+    for vi, v in enumerate(variants):
+        opt = dict(v, dataroot_gt='/data/gt', dataroot_lq='/data/lq', meta_info_file=meta_path, io_backend=dict(type='disk'), gt_size=32,
+                   scale=SCALE)
+        ds = vim.Vimeo90KDataset(opt)
+        assert len(ds) == len(meta)
+        random.seed(500 + vi)
+        samples = []
+        for index in (0, 5, 2, 2, 1, 4, 3, 0):  # one dataset object, in sequence: the neighbour list's orientation persists
+            item = ds[index]
+            lq8, gt8 = (item['lq'] * 255).round().to(torch.uint8), (item['gt'] * 255).round().to(torch.uint8)
+            assert torch.equal(lq8.float() / 255., item['lq']) and torch.equal(gt8.float() / 255., item['gt'])
+            samples.append(dict(index=index, key=item['key'], lq_u8=lq8, gt_u8=gt8, neighbors=list(ds.neighbor_list)))
+        out['runs'].append(dict(opt=v, seed=500 + vi, samples=samples, next_random=random.random()))
+    torch.save(out, os.path.join(OUT, 'vimeo90k_train.pt'))
+    for k, m in saved.items():
+        if m is None:
+            sys.modules.pop(k, None)
+        else:
+            sys.modules[k] = m
+
+
 def video_test_case():
     """VideoTestDataset (basicsr/data/video_test_dataset.py) of the reference, executed from its source on a small PNG tree
     (2 folders x 7 frames of synthetic_frame, a dot file that scandir has to skip), for cache_data on / off and two padding
@@ -463,6 +562,7 @@ def main():
     ssim_case()
     frame_indices_case()
     data_case()
+    vimeo_train_case()
     video_test_case()
     for name in EDVR_CASES:
         torch.save(edvr_case(name), os.path.join(OUT, f'edvr_{name}.pt'))

@@ -192,3 +192,37 @@ def test_training_loop_from_png_folders(gpu, tmp_path):
     args.resume, args.pretrain, args.iters, args.save_dir = os.path.join(root, 'ckpt', '4.state'), os.path.join(root, 'ckpt', 'net_g_4.pth'), 6, None
     more = tr.train(args, log=lines.append)
     assert len(more) == 2 and all(math.isfinite(v) for v in more)
+
+
+def test_vimeo90k_training_loader(gpu, tmp_path):
+    """The same device loader on the Vimeo90K TRAINING set (`type: Vimeo90KDataset`, basicsr/data/vimeo90k_dataset.py): PNG tree ->
+    planner (the reference's draws, its in-place reversal of the neighbour list) -> threaded decode -> device conversion, against the
+    oracle restatement (pinned on the reference's own class: tests/golden/vimeo90k_train.pt) over the same order and random stream."""
+    from edvr_amd import data as D
+    from util_data import write_vimeo_train_tree
+    lq_hw, scale, bs = (12, 20), 4, 3
+    keys = [f'{c:05d}/{q:04d}' for c in (1, 2) for q in (1, 2, 3, 4, 5, 6)]
+    meta = write_vimeo_train_tree(str(tmp_path), keys, lq_hw, scale)
+    opt = dict(type='Vimeo90KDataset', dataroot_gt=str(tmp_path / 'gt'), dataroot_lq=str(tmp_path / 'lq'), meta_info_file=meta,
+               io_backend=dict(type='disk'), num_frame=5, gt_size=32, scale=scale, random_reverse=True, use_flip=True, use_rot=True)
+    loader = D.REDSDeviceLoader(opt, bs, device=gpu, rank=0, world_size=1, seed=3, num_threads=4, depth=2)
+    fetch = fetch_bgr(lq_hw, scale)
+    assert len(loader) == len(keys) // bs
+    for epoch in (0, 1):
+        order = DO.enlarged_sampler_indices(len(keys), 1, 0, 1, epoch)
+        rng = D.epoch_rng(3, epoch)
+        nb_list = DO.vimeo90k_neighbor_list(5)
+        nb = 0
+        while True:
+            batch = loader.next()
+            if batch is None:
+                break
+            ref = [DO.vimeo90k_getitem(keys, opt, i, rng, fetch, nb_list) for i in order[nb * bs:(nb + 1) * bs]]
+            assert batch['key'] == [r['key'] for r in ref]
+            assert batch['lq'].shape == (bs, 5, 3, 8, 8) and batch['gt'].shape == (bs, 3, 32, 32)
+            assert torch.equal(batch['lq'].cpu(), torch.stack([r['lq'] for r in ref]))
+            assert torch.equal(batch['gt'].cpu(), torch.stack([r['gt'] for r in ref]))
+            nb += 1
+        assert nb == len(loader)
+        loader.reset()
+    loader.close()

@@ -98,31 +98,46 @@ def test_graph_replay_latency_on_a_small_clip(gpu):
 
 
 def test_graph_keeps_its_packed_weights_through_a_training_step(gpu):
-    """The captured launches read the packed weight layouts of capture time.  The training path re-packs every layout after an
-    optimizer step, IN PLACE where the cache is the buffer's only owner (ops.prepack_conv_weights): the graph pins its layouts
-    (ops.pin_packed_weights), so a replay with check_weights=False keeps producing the capture-time result, bit for bit, and the
-    eager path sees the new weights."""
+    """The captured launches read the packed conv-weight layouts of capture time.  The training path re-packs every layout after
+    an optimizer step, IN PLACE where the cache is the buffer's only owner (ops.prepack_conv_weights): the graph holds and pins
+    its layouts (ops.pin_packed_weights), so training steps leave them bit-for-bit as captured and pack into fresh buffers; once
+    the graph is gone the in-place rewriting resumes.  (Biases and the DCN weights are read from the live parameters by the
+    captured launches, which is why `check_weights=True` - the default - refuses a replay after any parameter change.)"""
+    import gc
     from edvr_amd import ops
     from edvr_amd.graphs import GraphedEDVR
     net, x, _ = build('M_T5')
     net = net.to(gpu)
     xg = x.to(gpu)
-    g = GraphedEDVR(net, xg, check_weights=False)
+    g = GraphedEDVR(net, xg)
     before = g(xg).clone()
-    pinned = set(ops._PINNED_PACKED)
-    assert pinned
+    assert g._pinned and {b.data_ptr() for b in g._pinned} <= ops._PINNED_PACKED
+    snap = [(b, b.clone()) for b in g._pinned]
+    w = net.conv_l2_2.weight
+    ptr_captured = ops.pack_conv_weight(w).data_ptr()
     net.train()
     opt = torch.optim.SGD(net.parameters(), lr=1e-3)
-    for _ in range(2):  # forward (packs the current versions) + backward + step (new versions)
+    for _ in range(2):  # forward (packs the current versions in one launch) + backward + step (new versions)
         opt.zero_grad()
         net(xg).square().mean().backward()
         opt.step()
     net.eval()
     with torch.no_grad():
         after = net(xg).clone()
-    assert not torch.equal(after, before)       # the eager path runs on the updated weights
-    assert torch.equal(g(xg), before)           # the replay still reads the layouts it was captured with
-    assert pinned <= set(ops._PINNED_PACKED)
+    assert not torch.equal(after, before)                                  # the eager path runs on the updated weights
+    assert all(torch.equal(b, c) for b, c in snap)                         # the captured layouts were not rewritten
+    assert ops.pack_conv_weight(w).data_ptr() != ptr_captured              # ... the new versions went to fresh buffers
+    with pytest.raises(RuntimeError):
+        g(xg)                                                              # parameters changed: refresh() first
     g.refresh()
     assert torch.equal(g(xg), after)
-    del g
+    del g, snap
+    gc.collect()
+    assert not ops._PINNED_PACKED
+    net.train()
+    ptr_now = ops.pack_conv_weight(w).data_ptr()
+    opt.zero_grad()
+    net(xg).square().mean().backward()
+    opt.step()
+    net(xg)                                                                # training forward: re-packs, in place again
+    assert ops.pack_conv_weight(w).data_ptr() == ptr_now

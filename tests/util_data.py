@@ -75,3 +75,19 @@ def write_video_test_tree(root, spec):
 def video_test_opt(root, run):
     return dict(name='REDS4', dataroot_gt=os.path.join(root, 'gt'), dataroot_lq=os.path.join(root, 'lq'), io_backend=dict(type='disk'),
                 cache_data=run['cache_data'], num_frame=run['num_frame'], padding=run['padding'])
+
+
+def write_vimeo_train_tree(root, keys, lq_hw, scale):
+    """<root>/{lq,gt}/<clip>/<seq>/im1.png .. im7.png + the meta file of the Vimeo90K training set (docs/DatasetPreparation.md)."""
+    for kind in ('lq', 'gt'):
+        h, w = lq_hw if kind == 'lq' else (lq_hw[0] * scale, lq_hw[1] * scale)
+        for key in keys:
+            d = os.path.join(root, kind, *key.split('/'))
+            os.makedirs(d, exist_ok=True)
+            for n in range(1, 8):
+                with open(os.path.join(d, f'im{n}.png'), 'wb') as fh:
+                    fh.write(png_bytes(DO.synthetic_frame(kind, key, f'im{n}', h, w)))
+    meta = os.path.join(root, 'meta_info_Vimeo90K_train_GT.txt')
+    with open(meta, 'w') as fh:
+        fh.writelines(f'{key} 7 ({lq_hw[0] * scale},{lq_hw[1] * scale},3)\n' for key in keys)
+    return meta
