@@ -22,7 +22,7 @@ class ConvDesc(ctypes.Structure):
         ('bias', vp), ('co', i32), ('ks', i32), ('stride', i32), ('act', i32), ('act_from', i32), ('res1', vp),
         ('res2', vp), ('res1_img_stride', i64), ('res2_img_stride', i64), ('y', vp), ('y_img_stride', i64),
         ('out_mode', i32), ('algo', i32), ('gate', vp), ('gate_img_stride', i64), ('gate_slope', f32), ('y_scale', f32),
-        ('wpk_f4', vp), ('abs_sum', vp), ('abs_sum_channels', i32), ('abs_diff', vp),
+        ('wpk_f4', vp), ('abs_sum', vp), ('abs_sum_channels', i32),
     ]
 
 

@@ -376,10 +376,6 @@ int conv2d_launch(const edvr_conv2d_desc &d, hipStream_t stream) {
     set_error("conv2d: abs_sum is an epilogue of the F(4x4) Winograd kernel's NCHW store only (ask edvr_conv2d_abs_sum_supported)");
     return EDVR_ERR_UNSUPPORTED;
   }
-  if (d.abs_diff && !d.abs_sum) {
-    set_error("conv2d: abs_diff is accumulated next to abs_sum (set both)");
-    return EDVR_ERR_ARG;
-  }
   if (!d.gate && !scaled && conv_small_eligible(d)) return conv_small_launch(d, stream);
   if (winograd_f4_eligible(d)) return winograd_f4_launch(d, stream);
   if (winograd_eligible(d)) {

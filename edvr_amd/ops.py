@@ -274,8 +274,8 @@ def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NON
     (3x3 kernels; in the Winograd kernel's epilogue where that kernel applies, else in the direct kernel's).
     y_scale: ResidualBlockNoBN's res_scale (arch_util.py:95), 3x3 kernels only.
     abs_sum_channels > 0: returns (y, stats) with stats (2, n) = abs_stats_per_image(y[:, :abs_sum_channels]) (sums of |y| and of the
-    horizontal neighbour differences) - in the conv's own epilogue where the launch runs on the F(4x4) kernel
-    (edvr_conv2d_desc.abs_sum / abs_diff), by the separate reduction kernel otherwise.
+    horizontal neighbour differences) - the sums in the conv's own epilogue where the launch runs on the F(4x4) kernel
+    (edvr_conv2d_desc.abs_sum), the differences estimated from the first image; by the separate reduction kernel otherwise.
     """
     require_gpu(x1, x2, wpk, bias, res1, res2)
     L = _lib.lib()
@@ -325,7 +325,7 @@ def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NON
     sums = None
     if abs_sum_channels > 0 and L.edvr_conv2d_abs_sum_supported(ctypes.byref(d)):
         sums = torch.zeros(2, n, dtype=torch.float32, device=x1.device)
-        d.abs_sum, d.abs_sum_channels, d.abs_diff = _ptr(sums), int(abs_sum_channels), _ptr(sums[1])
+        d.abs_sum, d.abs_sum_channels = _ptr(sums), int(abs_sum_channels)
     name, flops, nbytes, executed = 'conv2d', 0.0, 0.0, None
     if LAUNCH_HOOK is not None:  # measurement only (bench.py): brackets the launch with events on this stream
         buf = ctypes.create_string_buffer(96)
@@ -340,7 +340,14 @@ def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NON
                         + co * (c1 + d.c2) * ks * ks)
     _run(name, lambda: _lib.check(L.edvr_conv2d_f32(ctypes.byref(d), _stream()), 'edvr_conv2d_f32'), flops, nbytes, executed)
     if abs_sum_channels > 0:
-        return out, (sums if sums is not None else abs_stats_per_image(out[:, :abs_sum_channels]))
+        if sums is None:
+            return out, abs_stats_per_image(out[:, :abs_sum_channels])
+        # the epilogue took the sums of |y|; the roughness statistic is ESTIMATED from the first image (a 30 MB pass on the L1 layer,
+        # ~10 us) and scaled to the batch - one more accumulator in the F(4x4) kernel's staging waves spills (128 registers) and
+        # slows every layer of the network by 4 %
+        r = abs_stats_per_image(out[:1, :abs_sum_channels])
+        sums[1, :1] = r[1] * float(n)
+        return out, sums
     return out
 
 
@@ -753,7 +760,7 @@ def abs_mean_if_ready(rec):
 
 def offset_stats(stats, count):
     """(mean |offset|, mean |horizontal neighbour difference| or None) from the (2, n) sums of `abs_stats_per_image` over `count`
-    elements in all.  The difference sum covers 3 of every 4 horizontal pairs (include/edvr_amd.h, abs_diff)."""
+    elements in all.  The difference sum covers 3 of every 4 horizontal pairs (include/edvr_amd.h, edvr_abs_stats_f32)."""
     tot = stats.double().sum(-1).tolist() if stats.dim() == 2 else [float(stats.double().sum()), -1.0]
     return tot[0] / count, (tot[1] / (0.75 * count) if tot[1] >= 0 else None)
 

@@ -127,10 +127,6 @@ typedef struct edvr_conv2d_desc {
                            * edvr_conv2d_abs_sum_supported; EDVR_ERR_UNSUPPORTED otherwise.  The sum is taken over conv + bias (+ the
                            * activation of channels >= act_from), BEFORE gate, y_scale and the residuals are applied. */
   int abs_sum_channels;
-  float *abs_diff;        /* optional (n), with abs_sum only: abs_diff[i] += sum |y[i, c, r, x] - y[i, c, r, x + 1]| over the same channels
-                           * for the three horizontal neighbour pairs inside every aligned group of four columns (3 of every 4 pairs) -
-                           * the ROUGHNESS of the offset field.  Together with abs_sum it tells which DCN kernel suits the layer:
-                           * a smooth field of any magnitude runs on the per-tap windows (EDVR_DCN_HALO_TAPWIN), a rough one does not. */
 } edvr_conv2d_desc;
 
 size_t edvr_conv2d_packed_weight_elems(int co, int ci, int ks);
@@ -288,7 +284,10 @@ int edvr_act_bwd_f32(const float *dy, const float *y, const float *res1, const f
  * "offset abs mean > 50" warning of arch_util.py:248-253 without a per-call host sync. */
 int edvr_abs_sum_f32(const float *x, float *out, int n, int64_t per_img, int64_t img_stride, edvr_stream_t stream);
 /* The same sums in out[0 .. n) plus, in out[n .. 2n), sum |x[i, c, r, col] - x[i, c, r, col + 1]| over the three neighbour pairs inside
- * every aligned group of four columns of the w-wide rows (the roughness statistic of edvr_conv2d_desc.abs_diff; per_img % w == 0).
+ * every aligned group of four columns of the w-wide rows (3 of every 4 horizontal pairs; per_img % w == 0) - the ROUGHNESS of an
+ * offset field: together with the sums it tells which DCN kernel suits the layer (a smooth field of any magnitude runs on the per-tap
+ * windows, EDVR_DCN_HALO_TAPWIN).  (The F(4x4) conv epilogue only takes the plain sums, edvr_conv2d_desc.abs_sum: one more
+ * accumulator in its staging waves spills - 128 registers - and costs the kernel 4 % on EVERY layer, measured.)
  * Rows that are not whole 16-byte groups (w % 4 != 0 or unaligned views): out[n .. 2n) = -1 (unknown). */
 int edvr_abs_stats_f32(const float *x, float *out, int n, int64_t per_img, int w, int64_t img_stride, edvr_stream_t stream);
 

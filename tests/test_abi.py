@@ -71,3 +71,34 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', txt, flags=re.M), f
                 assert 'liboracle' not in txt and 'libdcn_ref' not in txt, f
+
+
+def test_hot_kernels_do_not_spill():
+    """hipcc's resource report for the two kernels that carry the inference step: no scratch.  The F(4x4) kernel runs at exactly its
+    128-register budget (16 waves per workgroup): round 4 added ONE accumulator to its staging waves (a roughness sum next to
+    abs_sum), the allocator spilled 8 bytes per lane and every layer of the network got 4 % slower - invisible in every parity
+    test.  This is the guard."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('hipcc not available')
+    root = os.path.join(os.path.dirname(__file__), '..')
+    for src, kernels in (('winograd_f4.hip', ('conv3x3_winograd_f4_kernelILi3E', 'conv3x3_winograd_f4_kernelILi4E')),
+                         ('dcn_tapwin.hip', ('dcn_tapwin_fwd_kernelILi4ELi16E', 'dcn_tapwin_fwd_kernelILi2ELi8E'))):
+        r = subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-ffp-contract=fast', '-c',
+                            os.path.join(root, 'edvr_amd', 'csrc', src), '-o', os.devnull, '-Rpass-analysis=kernel-resource-usage'],
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        cur, seen = None, {}
+        for line in r.stderr.splitlines():
+            m = re.search(r'Function Name: (\S+)', line)
+            if m:
+                cur = m.group(1)
+            m = re.search(r'ScratchSize \[bytes/lane\]: (\d+)', line)
+            if m and cur:
+                seen[cur] = int(m.group(1))
+        for k in kernels:
+            hits = [v for name, v in seen.items() if k in name]
+            assert hits and max(hits) == 0, (src, k, seen)
