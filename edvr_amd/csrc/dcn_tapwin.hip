@@ -224,10 +224,12 @@ __global__ __launch_bounds__(256, 2) void dcn_tapwin_fwd_kernel(const DcnTapwinA
       const float lh = h - fh, lw = w - fw, m = d[3 * s + 2];
       const int ry = (int)fh - wy0, rx = (int)fw - wx0;
       const bool inside = valid && ry >= 0 && ry <= IH - 2 && rx >= 0 && rx <= IW - 2;
-      bw[s][0] = inside ? (1.f - lh) * (1.f - lw) * m : 0.f;  // (a valid tap outside the window: zero here, added by the fix-up pass)
-      bw[s][1] = inside ? (1.f - lh) * lw * m : 0.f;
-      bw[s][2] = inside ? lh * (1.f - lw) * m : 0.f;
-      bw[s][3] = inside ? lh * lw * m : 0.f;
+      const float mm = inside ? m : 0.f;  // (a valid tap outside the window: zero here, added by the fix-up pass)
+      const float hm = (1.f - lh) * mm, lm = lh * mm, hw = 1.f - lw;
+      bw[s][0] = hm * hw;
+      bw[s][1] = hm * lw;
+      bw[s][2] = lm * hw;
+      bw[s][3] = lm * lw;
       addr[s] = half * CHS + (inside ? ry * IW + rx : 0);
       if (valid && !inside) slow |= 1u << s;
     }
@@ -237,10 +239,17 @@ __global__ __launch_bounds__(256, 2) void dcn_tapwin_fwd_kernel(const DcnTapwinA
   // ---- one step: NQ channel pairs x 2 sub-tiles x MT MFMAs.  Operands of pair q + 2 are requested while pair q multiplies.
   auto run_step = [&](auto SLOWT, const float *xb, const float *wb, int g, int t) {
     constexpr bool SLOW = decltype(SLOWT)::value;
+    const unsigned cbase[2] = {(unsigned)(size_t)(lvoid *)xb + (unsigned)addr[0] * 4u, (unsigned)(size_t)(lvoid *)xb + (unsigned)addr[1] * 4u};
     auto issue = [&](int q, float (&c)[2][4], float (&aw)[MT]) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const float *cell = xb + addr[s] + 2 * q * CHS;
+        // (the pair's element offset is made opaque to the optimiser: it would otherwise fold the row offset into a SECOND base
+        //  register per pair - the byte offset of the lower row exceeds ds_read2's 8-bit field only together with the pair's 3840 q -
+        //  instead of `offset0:40 offset1:41` on one base)
+        typedef __attribute__((address_space(3))) const float lds_cf;
+        unsigned co = cbase[s] + q * (2 * CHS * 4);  // LDS byte address of the cell in this pair's first channel
+        asm volatile("" : "+v"(co));
+        lds_cf *cell = (lds_cf *)(size_t)co;
         c[s][0] = cell[0];
         c[s][1] = cell[1];
         c[s][2] = cell[IW];
@@ -258,7 +267,11 @@ __global__ __launch_bounds__(256, 2) void dcn_tapwin_fwd_kernel(const DcnTapwinA
         for (int m = 0; m < MT; ++m) aw[m] = ap[m];
       }
     };
-    auto sample = [&](int s, const float (&c)[4]) -> float { return bw[s][0] * c[0] + bw[s][1] * c[1] + bw[s][2] * c[2] + bw[s][3] * c[3]; };
+    // four dependent FMAs per sample, written out: left to `-ffp-contract`, hipcc forms the four products first (v_mul / v_pk_mul) and
+    // adds them up - 7 vector instructions instead of 4, and the vector instruction count next to the MFMAs is what this loop costs
+    auto sample = [&](int s, const float (&c)[4]) -> float {
+      return __builtin_fmaf(bw[s][3], c[3], __builtin_fmaf(bw[s][2], c[2], __builtin_fmaf(bw[s][1], c[1], bw[s][0] * c[0])));
+    };
     if constexpr (SLOW) {
       // Fix-up pass after the regular one (in which the slow lanes carried zero weights): the lanes whose cell lies outside the
       // window gather their four corners from global memory with the full bounds logic (dcn_tap.h), every other lane contributes
