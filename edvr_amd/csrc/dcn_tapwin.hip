@@ -47,7 +47,7 @@ constexpr int TWN_HB = TWN_HR * TWN_IW;                   // ... to floats [0, 2
 constexpr int TWN_CHS = TWN_IH * TWN_IW;                  // 480 floats per channel = 32 (mod 64): the two half-waves of a gather (channels
                                                           // c / c + 1, same position) fall on disjoint halves of the 64 LDS banks
 static_assert(TWN_HR * TWN_PPR <= 64 && TWN_IH == 2 * TWN_HR && TWN_CHS % 64 == 32, "window halves must fit one wave instruction");
-constexpr int TWN_MAX_DG = 16;
+constexpr int TWN_MAX_DG = 8;   // (the shift table and the tap staging area share the last 3.6 KB of the workgroup's 80 KB)
 constexpr int TWN_OOB = (int)0x80000000;
 constexpr int TWN_RSRC_FLAGS = 0x00020000;
 }  // namespace
@@ -69,6 +69,10 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // (m0 = LDS base; one wait state between the scalar write of m0 and the instruction that uses it)
 __device__ __forceinline__ void twn_dma16(i32x4 rsrc, unsigned lds, int voff, int soff) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
+}
+
+__device__ __forceinline__ void twn_dma4(i32x4 rsrc, unsigned lds, int voff, int soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
 }
 
 __device__ __forceinline__ i32x4 twn_rsrc4(const void *ptr, int bytes) {
@@ -99,6 +103,7 @@ __global__ __launch_bounds__(256, 2) void dcn_tapwin_fwd_kernel(const DcnTapwinA
   __shared__ __attribute__((aligned(16))) float xw[2 * XW];
   __shared__ __attribute__((aligned(16))) float wsl[2 * WS];
   __shared__ int shifts[TWN_MAX_DG * 18];
+  __shared__ float tpl[4 * 3 * 64];  // offsets / mask of the NEXT step's tap: [wave][dy | dx | mask][pixel row 2][column 32], wave-private
 
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, j = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -197,49 +202,63 @@ __global__ __launch_bounds__(256, 2) void dcn_tapwin_fwd_kernel(const DcnTapwinA
     wy0 = ty0 - 1 + ti + sy - TWN_RY;
     wx0 = (tx0 - 1 + tj + sx - TWN_RX) & ~3;
   };
-  // offsets / mask of this lane's two pixels for tap (g, t): requested at the top of the step before, consumed after its MFMAs
-  auto load_taps = [&](int g, int t, float (&d)[6]) {
+  // offsets / mask of a tap for this wave's 64 pixels -> the wave's private staging rows, by LDS-DMA (lane = (pixel row, column)),
+  // requested TWO steps ahead; a lane reads the six values of its two pixels (both half-waves read the same words: broadcast)
+  const i32x4 off_rsrc4 = twn_rsrc4(off_b, a.dg * 18 * P * 4), msk_rsrc4 = twn_rsrc4(msk_b, a.dg * 9 * P * 4);
+  const unsigned tpl_lds = (unsigned)(size_t)(lvoid *)tpl + wave * (3 * 64 * 4);
+  const int tvd = half ? tvo[1] : tvo[0];  // (here the lane's upper bit selects the pixel ROW, not the channel parity)
+  auto dma_taps = [&](int g, int t) {
+    twn_dma4(off_rsrc4, tpl_lds, tvd, (g * 18 + 2 * t) * P * 4);
+    twn_dma4(off_rsrc4, tpl_lds + 256, tvd, (g * 18 + 2 * t + 1) * P * 4);
+    twn_dma4(msk_rsrc4, tpl_lds + 512, tvd, (g * 9 + t) * P * 4);
+  };
+  auto read_taps = [&](float (&d)[6]) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      d[3 * s + 0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(off_rsrc, tvo[s], (g * 18 + 2 * t) * P * 4, 0));
-      d[3 * s + 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(off_rsrc, tvo[s], (g * 18 + 2 * t + 1) * P * 4, 0));
-      d[3 * s + 2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(msk_rsrc, tvo[s], (g * 9 + t) * P * 4, 0));
-    }
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int v = 0; v < 3; ++v) d[3 * s + v] = tpl[wave * 192 + v * 64 + s * 32 + j];
   };
 
   // ---- per-step sampling state of the two pixels
-  float bw[2][4];
-  int addr[2];
-  unsigned slow = 0;      // bit s: the 2x2 cell of sub-tile s's pixel is valid but not inside the staged window
-  unsigned slow_any = 0;  // any lane of the wave (scalar)
-  auto make_state = [&](int t, int wy0, int wx0, const float (&d)[6]) {
+  struct St {
+    float bw[2][4];
+    int addr[2];
+    unsigned slow;      // bit s: the 2x2 cell of sub-tile s's pixel is valid but not inside the staged window
+    unsigned slow_any;  // any lane of the wave (scalar)
+  };
+  // (pure register arithmetic, no memory access; split per sub-tile so that the halves can sit in different stages of the step before)
+  auto state_half = [&](St &st, int s, int t, int wy0, int wx0, const float (&d)[6]) {
     const int ti = t / 3, tj = t - 3 * ti;
-    slow = 0;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const bool pix_ok = s ? ok1 : ok0;
-      const float h = (float)(oy0 + s - 1 + ti) + d[3 * s], w = (float)(ox - 1 + tj) + d[3 * s + 1];
-      const bool valid = pix_ok && h > -1.f && w > -1.f && h < (float)a.H && w < (float)a.W;  // .cu:618
-      const float fh = floorf(h), fw = floorf(w);
-      const float lh = h - fh, lw = w - fw, m = d[3 * s + 2];
-      const int ry = (int)fh - wy0, rx = (int)fw - wx0;
-      const bool inside = valid && ry >= 0 && ry <= IH - 2 && rx >= 0 && rx <= IW - 2;
-      const float mm = inside ? m : 0.f;  // (a valid tap outside the window: zero here, added by the fix-up pass)
-      const float hm = (1.f - lh) * mm, lm = lh * mm, hw = 1.f - lw;
-      bw[s][0] = hm * hw;
-      bw[s][1] = hm * lw;
-      bw[s][2] = lm * hw;
-      bw[s][3] = lm * lw;
-      addr[s] = half * CHS + (inside ? ry * IW + rx : 0);
-      if (valid && !inside) slow |= 1u << s;
-    }
-    slow_any = __builtin_amdgcn_readfirstlane(__any(slow != 0) ? 1 : 0);
+    const bool pix_ok = s ? ok1 : ok0;
+    const float h = (float)(oy0 + s - 1 + ti) + d[3 * s], w = (float)(ox - 1 + tj) + d[3 * s + 1];
+    const bool valid = pix_ok && h > -1.f && w > -1.f && h < (float)a.H && w < (float)a.W;  // .cu:618
+    const float fh = floorf(h), fw = floorf(w);
+    const float lh = h - fh, lw = w - fw, m = d[3 * s + 2];
+    const int ry = (int)fh - wy0, rx = (int)fw - wx0;
+    const bool inside = valid && ry >= 0 && ry <= IH - 2 && rx >= 0 && rx <= IW - 2;
+    const float mm = inside ? m : 0.f;  // (a valid tap outside the window: zero here, added by the fix-up pass)
+    const float hm = (1.f - lh) * mm, lm = lh * mm, hw = 1.f - lw;
+    st.bw[s][0] = hm * hw;
+    st.bw[s][1] = hm * lw;
+    st.bw[s][2] = lm * hw;
+    st.bw[s][3] = lm * lw;
+    st.addr[s] = half * CHS + (inside ? ry * IW + rx : 0);
+    st.slow = (s ? st.slow : 0u) | ((valid && !inside) ? 1u << s : 0u);
+  };
+  auto state_any = [&](St &st) { st.slow_any = __builtin_amdgcn_readfirstlane(__any(st.slow != 0) ? 1 : 0); };
+  auto make_state = [&](St &st, int t, int wy0, int wx0, const float (&d)[6]) {
+    state_half(st, 0, t, wy0, wx0, d);
+    state_half(st, 1, t, wy0, wx0, d);
+    state_any(st);
   };
 
   // ---- one step: NQ channel pairs x 2 sub-tiles x MT MFMAs.  Operands of pair q + 2 are requested while pair q multiplies.
-  auto run_step = [&](auto SLOWT, const float *xb, const float *wb, int g, int t) {
+  auto run_step = [&](auto SLOWT, const St &cur, const float *xb, const float *wb, int g, int t, St &nxt, int tn, int ny0, int nx0,
+                      const float (&tnv)[6]) {
     constexpr bool SLOW = decltype(SLOWT)::value;
-    const unsigned cbase[2] = {(unsigned)(size_t)(lvoid *)xb + (unsigned)addr[0] * 4u, (unsigned)(size_t)(lvoid *)xb + (unsigned)addr[1] * 4u};
+    const float (&bw)[2][4] = cur.bw;
+    const unsigned slow = cur.slow;
+    const unsigned cbase[2] = {(unsigned)(size_t)(lvoid *)xb + (unsigned)cur.addr[0] * 4u, (unsigned)(size_t)(lvoid *)xb + (unsigned)cur.addr[1] * 4u};
     auto issue = [&](int q, float (&c)[2][4], float (&aw)[MT]) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -313,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void dcn_tapwin_fwd_kernel(const DcnTapwinA
       float b0 = sample(0, cv[0][0]), b1 = sample(1, cv[0][1]);
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        const int cur = q % 3, n1 = (q + 1) % 3, n2 = (q + 2) % 3;
+        const int cq = q % 3, n1 = (q + 1) % 3, n2 = (q + 2) % 3;
         if (q + 2 < NQ) issue(q + 2, cv[n2], av[n2]);
         float nb0 = 0.f, nb1 = 0.f;
         if (q + 1 < NQ) {
@@ -321,48 +340,74 @@ __global__ __launch_bounds__(256, 2) void dcn_tapwin_fwd_kernel(const DcnTapwinA
           nb1 = sample(1, cv[n1][1]);
         }
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][m], b0, acc[0][m], 0, 0, 0);
+        for (int m = 0; m < MT; ++m) acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cq][m], b0, acc[0][m], 0, 0, 0);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][m], b1, acc[1][m], 0, 0, 0);
+        for (int m = 0; m < MT; ++m) acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cq][m], b1, acc[1][m], 0, 0, 0);
         b0 = nb0;
         b1 = nb1;
+        // the NEXT step's sampling state, from tap values that are already in registers: ~70 vector instructions with no memory
+        // access and no dependence on this step, one sub-tile in each of the first two stages - under the MFMAs of the SIMD's other
+        // wave they cost next to nothing; after the last MFMA of the step (first version) they were 9 % of the kernel
+        // (profiles/r4/tapwin_ablations.log).  The empty asm statements DEFINE the values here: hipcc otherwise sinks the
+        // arithmetic into the block after the fix-up branch, where they are first used.
+        if (q < 2) {
+          state_half(nxt, q, tn, ny0, nx0, tnv);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(nxt.bw[q][i]));
+          asm volatile("" : "+v"(nxt.addr[q]), "+v"(nxt.slow));
+        }
+        if (q == 2) {
+          state_any(nxt);
+          asm volatile("" : "+s"(nxt.slow_any));
+        }
         __builtin_amdgcn_sched_barrier(0);  // stage boundary: nothing moves across (finer pinning - DS / MFMA / VALU groups - measured: no difference)
       }
     }
   };
 
-  // ---- schedule.  Step k computes on buffers k & 1; at its top (after the barrier: nobody reads buffers (k + 1) & 1 any more, and
-  //      every wave's pieces of step k have landed - each wave waited for its own before the barrier) the DMA of step k + 1 and
-  //      the tap values of step k + 1 are requested; they are waited for AFTER the MFMAs of step k.
+  // ---- schedule.  Step k computes on buffers k & 1.  At its top (after the barrier: nobody reads buffers (k + 1) & 1 any more, every
+  //      wave's pieces of step k have landed - each wave waited for its own before the barrier) the tap values of step k + 1 are
+  //      read from the wave's staging rows into registers, the DMA of step k + 1 (window, weights) and of the tap values of step k + 2
+  //      is requested, and the state of step k + 1 is computed BETWEEN the MFMAs of step k.  One wait (vmcnt(0)) after the MFMAs.
   __syncthreads();  // shifts
   const int n_steps = a.dg * KK;
-  float taps[6];
-  int wy0, wx0;
-  origin(0, 0, wy0, wx0);
-  dma_x(0, 0, wy0, wx0);
+  St cur, nxt;
+  float tnv[6];
+  int o1y, o1x;
+  origin(0, 0, o1y, o1x);
+  dma_x(0, 0, o1y, o1x);
   dma_w(0, 0, 0);
-  load_taps(0, 0, taps);
+  dma_taps(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  make_state(0, wy0, wx0, taps);
-  int g = 0, t = 0;
+  read_taps(tnv);
+  make_state(cur, 0, o1y, o1x, tnv);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the staging rows are read before they are requested again)
+  int g = 0, t = 0, g1 = 0, t1 = 1;  // (g1, t1) = step k + 1
+  if (n_steps > 1) {
+    origin(g1, t1, o1y, o1x);
+    dma_taps(g1, t1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   for (int k = 0; k < n_steps; ++k) {
     __syncthreads();
-    const int gn = (t == KK - 1) ? g + 1 : g, tn = (t == KK - 1) ? 0 : t + 1;
-    const bool more = k + 1 < n_steps;
-    int ny0 = 0, nx0 = 0;
-    if (more) {
-      origin(gn, tn, ny0, nx0);
-      dma_x((k + 1) & 1, gn, ny0, nx0);
-      dma_w((k + 1) & 1, gn, tn);
-      load_taps(gn, tn, taps);
+    const int g2 = (t1 == KK - 1) ? g1 + 1 : g1, t2 = (t1 == KK - 1) ? 0 : t1 + 1;  // step k + 2
+    int o2y = 0, o2x = 0;
+    if (k + 1 < n_steps) {
+      read_taps(tnv);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      dma_x((k + 1) & 1, g1, o1y, o1x);
+      dma_w((k + 1) & 1, g1, t1);
+      if (k + 2 < n_steps) {
+        origin(g2, t2, o2y, o2x);
+        dma_taps(g2, t2);
+      }
     }
     const float *xb = xw + (k & 1) * XW, *wb = wsl + (k & 1) * WS;
-    run_step(std::false_type{}, xb, wb, g, t);
-    if (slow_any) run_step(std::true_type{}, xb, wb, g, t);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces and tap values of step k + 1
-    if (more) make_state(tn, ny0, nx0, taps);
-    g = gn;
-    t = tn;
+    run_step(std::false_type{}, cur, xb, wb, g, t, nxt, t1, o1y, o1x, tnv);
+    if (cur.slow_any) run_step(std::true_type{}, cur, xb, wb, g, t, nxt, t1, o1y, o1x, tnv);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of step k + 1 and tap values of step k + 2
+    cur = nxt;
+    g = g1; t = t1; g1 = g2; t1 = t2; o1y = o2y; o1x = o2x;
   }
 
   // ---- epilogue: bias, activation, store.  Buffer instructions (wave-uniform resource + 32-bit lane offset + scalar channel offset):

@@ -185,7 +185,7 @@ int edvr_conv2d_executed_flops(const edvr_conv2d_desc *d, double *flops);
  * (group, tap) is centred on that tap's displacement over the tile, so the cost does not depend on the offset MAGNITUDE as long as
  * the field is spatially smooth (+-2 px inside an 8 x 32 pixel tile) - what a trained conv_offset produces, and what the
  * reference's gather costs at any offset (.cu:570-633).  Needs W % 4 == 0, W >= 32, 8 or 16 channels per deformable group,
- * dg <= 16 and a 16-byte aligned x; otherwise the R = 7 kernel runs. */
+ * dg <= 8 and a 16-byte aligned x; otherwise the R = 7 kernel runs. */
 size_t edvr_dcnv2_fwd_ws_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil,
                                int groups, int dg);
 int edvr_dcnv2_fwd_f32(const float *x, const float *offset, const float *mask, const float *weight,

@@ -206,7 +206,8 @@ TAPWIN_CASES = [
     (1, 128, 9, 36, 96, 8, 2.0, 3, 0),      # three channel tiles, width % 32 != 0, outliers
     (1, 128, 40, 100, 40, 8, 6.0, 0, 1),    # tail channel tile (Co % 32 != 0), ReLU
     (1, 128, 8, 32, 128, 8, 0.0, 0, 0),     # zero offsets, exactly one tile
-    (1, 256, 12, 48, 160, 16, 5.0, 2, 0),   # 16 groups, two launches (128 + 32 output channels)
+    (1, 256, 12, 48, 160, 16, 5.0, 2, 0),   # 16 groups: more than the kernel's 8 -> the request falls back to the R = 7 kernel
+    (1, 128, 12, 48, 160, 8, 5.0, 2, 0),    # two launches (128 + 32 output channels)
     (3, 128, 33, 72, 128, 8, 64.0, 0, 0),   # displacements larger than the image: every window empty or clipped
 ]
 
