@@ -37,9 +37,12 @@ struct WinoWgradArgs {
 };
 
 __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const WinoWgradArgs a) {
-  constexpr int TS = 16 * 64 + 4;  // floats per tile in a slab: [tile][xi][channel], +4 so the 8 tiles x 4 channels a half-wave
-                                   // writes per pass land in 32 different banks (PMC: +8 left 25 % of the LDS cycles in conflicts)
-  constexpr int SLAB = 8 * TS, SMEM = 4 * SLAB;  // (Z, V) x 2 stages = 132 KB
+  constexpr int CS = 20;       // floats per (tile, channel) row of a slab: its 16 positions + 4 - with a row stride of 20 the eight lanes
+                               // of a 16-byte LDS access cover all 32 banks (0, 20, 8, 28, 16, 4, 24, 12), reads and writes alike
+  constexpr int TS = 64 * CS;  // floats per tile: [tile][channel][xi]: the four positions a group of MFMAs consumes are ONE ds_read_b128
+                               // and a transformed row is ONE ds_write_b128 (first layout: [tile][xi][channel], 4-byte accesses - 96
+                               // LDS instructions per 32 MFMAs and wave, now 24)
+  constexpr int SLAB = 8 * TS, SMEM = 4 * SLAB;  // (Z, V) x 2 stages = 160 KB: all of the CU's LDS
   constexpr int RSRC_FLAGS = 0x00020000;
   constexpr int OOB = (int)0x80000000;  // >= num_records: the load returns 0 without touching memory
   __shared__ __attribute__((aligned(16))) float smem[SMEM];
@@ -61,8 +64,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
   const int q1 = __builtin_amdgcn_readfirstlane(2 * (int)((int64_t)pairs_total * (split + 1) / a.splits));
   if (q0 >= q1) return;  // (never with splits <= pairs_total; the partial of this split would stay unwritten)
 
-  // ---- staging role of this thread: channel chl = 8 wave + (lane >> 3) of the block, tile t = lane & 7 of the chunk
-  const int t = lane & 7, chl = wave * 8 + (lane >> 3);
+  // ---- staging role of this thread: channel chl = 8 wave + (lane & 7) of the block, tile t = lane >> 3 of the chunk (channel-fast:
+  //      the eight lanes of a 16-byte LDS write then differ in the channel - conflict-free, see CS)
+  const int t = lane >> 3, chl = wave * 8 + (lane & 7);
   const bool use_x2 = a.c2 > 0 && ci_blk >= a.c1;  // blocks never straddle x1 / x2 (c1 % 64 == 0, checked by the host)
   const int ci_s = ci_blk + chl, co_s = co_blk + chl;
   const bool valid_ci = ci_s < (use_x2 || a.c2 == 0 ? ci_total : a.c1), valid_co = co_s < a.co;
@@ -178,14 +182,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
     tt[r * 4 + 3] = d1 - d3;
   };
   auto commit_v_row = [&](float *Vs, int r) {  // positions xi = 4r .. 4r+3 of B^T (d B): B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]
-    float *dst = Vs + t * TS + (r * 4) * 64 + chl;
+    float *dst = Vs + t * TS + chl * CS + r * 4;
     const float *ra = tt + (r == 0 ? 0 : r == 1 ? 1 : r == 2 ? 2 : 1) * 4, *rb = tt + (r == 0 ? 2 : r == 1 ? 2 : r == 2 ? 1 : 3) * 4;
 #ifdef WW_EXP_NOCOMMIT
     if (ra[0] == 12345.f)  /* ablation only */
 #endif
     {
+      f32x4 v;
 #pragma unroll
-      for (int jx = 0; jx < 4; ++jx) dst[jx * 64] = r == 1 ? ra[jx] + rb[jx] : ra[jx] - rb[jx];
+      for (int jx = 0; jx < 4; ++jx) v[jx] = r == 1 ? ra[jx] + rb[jx] : ra[jx] - rb[jx];
+      *reinterpret_cast<f32x4 *>(dst) = v;
     }
   };
   float bvalid = 1.f;  // 0 once the chunk being committed lies beyond this split's range (its dY must not be counted)
@@ -196,15 +202,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
     // rows of A dY: (p, qq), (p + u, qq + v), (p - u, qq - v), (-u, -v)
     const float e = r == 0 ? p : r == 1 ? p + u : r == 2 ? p - u : -u;
     const float f = r == 0 ? qq : r == 1 ? qq + v : r == 2 ? qq - v : -v;
-    float *dst = Zs + t * TS + (r * 4) * 64 + chl;
-    dst[0 * 64] = e;
-    dst[1 * 64] = e + f;
-    dst[2 * 64] = e - f;
-    dst[3 * 64] = -f;
+    f32x4 zv;
+    zv[0] = e;
+    zv[1] = e + f;
+    zv[2] = e - f;
+    zv[3] = -f;
+    *reinterpret_cast<f32x4 *>(Zs + t * TS + chl * CS + r * 4) = zv;
   };
 
-  const int abase = half * TS + ph * 8 * 64 + wm * 32 + j;  // A operand (Z): tile `half` of the pair, this wave's co tile
-  const int bbase = half * TS + ph * 8 * 64 + wn * 32 + j;  // B operand (V): this wave's ci tile
+  const int abase = half * TS + (wm * 32 + j) * CS + ph * 8;  // A operand (Z): tile `half` of the pair, this wave's co tile
+  const int bbase = half * TS + (wn * 32 + j) * CS + ph * 8;  // B operand (V): this wave's ci tile
   // One chunk (parity P): 8 groups (tile pair s = g >> 1, positions 8 ph + 4 (g & 1) .. +3) of 4 MFMAs on LDS stage P; the
   // chunk held in registers (k+1) is transformed into stage 1-P and every register is reloaded with chunk k+2 right after
   // its last use.  Branch-free.
@@ -213,22 +220,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
     using Other = std::integral_constant<int, 1 - P>;
     const float *Zs = smem + P * 2 * SLAB, *Vs = Zs + SLAB;
     float *Zd = smem + (1 - P) * 2 * SLAB, *Vd = Zd + SLAB;
-    float av[2][4], bv[2][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      av[0][i] = Zs[abase + i * 64];
-      bv[0][i] = Vs[bbase + i * 64];
-    }
+    f32x4 av[2], bv[2];
+    av[0] = *reinterpret_cast<const f32x4 *>(Zs + abase);
+    bv[0] = *reinterpret_cast<const f32x4 *>(Vs + bbase);
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
       const int cur = g & 1, nxt = cur ^ 1;
       if (g + 1 < 8) {
         const int sn = (g + 1) >> 1, x0n = ((g + 1) & 1) * 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          av[nxt][i] = Zs[abase + 2 * sn * TS + (x0n + i) * 64];
-          bv[nxt][i] = Vs[bbase + 2 * sn * TS + (x0n + i) * 64];
-        }
+        av[nxt] = *reinterpret_cast<const f32x4 *>(Zs + abase + 2 * sn * TS + x0n);
+        bv[nxt] = *reinterpret_cast<const f32x4 *>(Vs + bbase + 2 * sn * TS + x0n);
       }
       const int x0 = (g & 1) * 4;
 #pragma unroll
@@ -288,13 +289,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
     iteration(S1{});
   }
 
-  // ---- bias gradient partial of this split: sum over the 8 tiles a channel's lanes hold (lanes chl*8 + t), written by the
+  // ---- bias gradient partial of this split: sum over the 8 tiles a channel's lanes hold (lanes 8 t + channel), written by the
   //      workgroups of input-channel block 0 only (every ci block saw the same dY)
   if (a.want_db && ci_blk == 0) {
     float s = bsum;
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 8, 64);
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
     if (t == 0 && valid_co) (a.ws + (int64_t)a.splits * a.co * ci_total * 9)[(int64_t)split * a.co + co_s] = s;
   }
 
