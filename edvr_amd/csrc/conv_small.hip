@@ -50,19 +50,32 @@ __global__ __launch_bounds__(256) void conv3x3_smallco_kernel(const SmallCoArgs 
     g_off[k] = (p < IH * IW && gy >= 0 && gy < d.h && gx >= 0 && gx < d.w) ? gy * d.w + gx : -1;
   }
 
-  for (int c0 = 0; c0 < a.ci; c0 += CKS) {
-    // stage the halo tile of 8 channels (zero outside the image and past the last channel): lanes along x
+  // The halo tile of 8 channels (zero outside the image and past the last channel; lanes along x) and the chunk's weights are
+  // fetched into registers one chunk AHEAD: the loads of chunk k + 1 are in flight during the FMAs of chunk k (round 4; fetched
+  // in front of the FMAs, every chunk began with a full memory round trip that only other workgroups could cover: 0.25 of the HBM rate)
+  float pre[CKS][NPOS];
+  f32x4 wpre = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](int c0) {
 #pragma unroll
     for (int ch = 0; ch < CKS; ++ch) {
       const int c = c0 + ch;
       const float *plane = c < d.c1 ? x1 + (int64_t)c * hw : x2 + (int64_t)(c - d.c1) * hw;  // wave-uniform
 #pragma unroll
-      for (int k = 0; k < NPOS; ++k)
-        if (l_off[k] >= 0) xs[ch * IH * RS + l_off[k]] = (c < a.ci && g_off[k] >= 0) ? plane[g_off[k]] : 0.f;
+      for (int k = 0; k < NPOS; ++k) pre[ch][k] = (c < a.ci && g_off[k] >= 0) ? plane[g_off[k]] : 0.f;
     }
     if (tid < CKS * 9)  // packed direct layout [ci_pad16][9][cop]: channels past ci are zero rows there
-      wl[tid] = *reinterpret_cast<const f32x4 *>(d.wpk + ((int64_t)(c0 + tid / 9) * 9 + tid % 9) * a.cop);
+      wpre = *reinterpret_cast<const f32x4 *>(d.wpk + ((int64_t)(c0 + tid / 9) * 9 + tid % 9) * a.cop);
+  };
+  fetch(0);
+  for (int c0 = 0; c0 < a.ci; c0 += CKS) {
+#pragma unroll
+    for (int ch = 0; ch < CKS; ++ch)
+#pragma unroll
+      for (int k = 0; k < NPOS; ++k)
+        if (l_off[k] >= 0) xs[ch * IH * RS + l_off[k]] = pre[ch][k];
+    if (tid < CKS * 9) wl[tid] = wpre;
     __syncthreads();
+    if (c0 + CKS < a.ci) fetch(c0 + CKS);
 #pragma unroll
     for (int ch = 0; ch < CKS; ++ch) {
 #pragma unroll
@@ -135,7 +148,7 @@ struct SmallCoWgradArgs {
   int tiles_x, tiles_y, tiles, splits;
 };
 
-__global__ __launch_bounds__(256) void wgrad3x3_smallco_kernel(const SmallCoWgradArgs a) {
+__global__ __launch_bounds__(256, 2) void wgrad3x3_smallco_kernel(const SmallCoWgradArgs a) {
   constexpr int TH = 4, TW = 32, IH = TH + 2, IW = TW + 2, CHS = IH * IW + 1;  // 205: odd channel stride, lanes = channels
   __shared__ float xs[64 * CHS];
   __shared__ float zs[4 * TH * TW];
@@ -149,31 +162,52 @@ __global__ __launch_bounds__(256) void wgrad3x3_smallco_kernel(const SmallCoWgra
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[o][t] = 0.f;
 
-  for (int tile = t_begin; tile < t_end; ++tile) {
+  // Thread p < 204 owns halo position p of ALL 64 channels: the position (and its validity) is resolved once per tile, the channel
+  // loop is 64 independent loads at a constant stride (rows coalesced along p).  The loads of tile k + 1 are issued into registers
+  // BEFORE the arithmetic of tile k (round 4: staged in front of the arithmetic, eight at a time, their latency - eight round trips
+  // per tile with three workgroups per CU - was the kernel: 0.06 of the HBM rate; an earlier flat (channel, position) walk with two
+  // integer divisions per element the same).
+  float pre[64], zpre[2];
+  auto fetch = [&](int tile) {
     const int img = tile / (a.tiles_x * a.tiles_y), tr = tile - img * (a.tiles_x * a.tiles_y);
     const int ty0 = (tr / a.tiles_x) * TH, tx0 = (tr % a.tiles_x) * TW;
     const float *xi = a.x + (int64_t)img * a.x_img_stride;
     const float *zi = a.dz + (int64_t)img * a.dz_img_stride;
-    __syncthreads();  // previous tile fully consumed
-    // Thread p < 204 owns halo position p of ALL 64 channels: the position (and its validity) is resolved once per tile, the channel
-    // loop is 64 independent loads at a constant stride (rows coalesced along p), eight in flight per thread.  (Until round 3 a flat
-    // index walked (channel, position) with two integer divisions per element: 51 dependent iterations per tile, 0.06 of the HBM
-    // rate - the staging, not the 36 FMAs per pixel and channel, was the kernel's time.)
-    if (tid < IH * IW) {
+    {
+      // buffer loads: one wave-uniform resource over this block's channel planes of the image + ONE 32-bit lane offset, the channel
+      // in the scalar offset (64-bit pointers per load: 128 address registers, one wave per SIMD); positions outside the image and
+      // the lanes beyond the halo carry the out-of-range offset, channels past the last one lie beyond num_records: all read 0
       const int r = tid / IW, col = tid - r * IW;
       const int gy = ty0 - 1 + r, gx = tx0 - 1 + col;
-      const bool inside = gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
-      const float *src = xi + (int64_t)ci0 * hw + (inside ? gy * a.w + gx : 0);
-      float *dst = xs + tid;
-#pragma unroll 8
-      for (int ch = 0; ch < 64; ++ch) dst[ch * CHS] = (inside && ci0 + ch < a.ci) ? src[(int64_t)ch * hw] : 0.f;
+      const bool inside = tid < IH * IW && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+      const int nch = min(64, a.ci - ci0);
+      const uint64_t pv = reinterpret_cast<uint64_t>(xi + (int64_t)ci0 * hw);
+      const uint64_t pu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pv >> 32)) << 32) |
+                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pv);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(pu), (short)0, nch * hw * 4, 0x00020000);
+      const int vo = inside ? (gy * a.w + gx) * 4 : (int)0x80000000;
+#pragma unroll
+      for (int ch = 0; ch < 64; ++ch) pre[ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, ch * hw * 4, 0));
     }
-    for (int i = tid; i < 4 * TH * TW; i += 256) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {  // 4 x TH x TW = 512 dz values: two per thread
+      const int i = tid + 256 * k;
       const int o = i / (TH * TW), rem = i - o * (TH * TW), r = rem / TW, col = rem - r * TW;
       const int gy = ty0 + r, gx = tx0 + col;
-      zs[i] = (o < a.co && gy < a.h && gx < a.w) ? zi[(int64_t)o * hw + gy * a.w + gx] : 0.f;
+      zpre[k] = (o < a.co && gy < a.h && gx < a.w) ? zi[(int64_t)o * hw + gy * a.w + gx] : 0.f;
     }
+  };
+  if (t_begin < t_end) fetch(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    __syncthreads();  // previous tile fully consumed
+    if (tid < IH * IW) {
+#pragma unroll
+      for (int ch = 0; ch < 64; ++ch) xs[tid + ch * CHS] = pre[ch];
+    }
+    zs[tid] = zpre[0];
+    zs[tid + 256] = zpre[1];
     __syncthreads();
+    if (tile + 1 < t_end) fetch(tile + 1);  // in flight during the arithmetic below
     // this thread: channel cl, output row q of the tile; slide along x with a 3-column window of its three input rows
     const float *xr = xs + cl * CHS + q * IW;
     float w0[3], w1[3], w2[3];  // columns px-1, px, px+1 of rows q, q+1, q+2 (halo coordinates)
@@ -224,6 +258,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_smallco_kernel(const SmallCoWgra
 
 bool wgrad_small_plan(int n, int c1, int c2, int h, int w, int co, int ks, int stride, int *splits) {
   if (ks != 3 || stride != 1 || co > 4 || c2 != 0) return false;
+  if ((int64_t)64 * h * w * 4 >= ((int64_t)1 << 31)) return false;  // 32-bit buffer offsets over a block of 64 channel planes
   const int tiles = n * cdiv(h, 4) * cdiv(w, 32);
   *splits = std::max(1, std::min(tiles, 512 / cdiv(c1, 64)));
   return true;

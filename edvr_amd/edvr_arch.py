@@ -284,9 +284,11 @@ class EDVR(nn.Module):
 
     def _queue_offset_check(self, sink, b, t):
         """arch_util.py:248-253, evaluated per (DCN layer, frame) like the reference's per-call check, with ONE device->host
-        copy per forward.  Training (grad mode) evaluates it right away - the backward of the same iteration picks its dX
-        strategy from these statistics.  No-grad forwards do not wait for the GPU: the copy goes to pinned memory behind an
-        event and is examined by `check_offsets` (called when the next forward starts, or by the user)."""
+        copy per forward.  No forward waits for the GPU: the copy goes to pinned memory behind an event and is examined by
+        `check_offsets` (called when the next forward starts, or by the user).  In training the backward of the same iteration
+        picks its dX STRATEGY (never a value) from the statistics that have arrived by then - normally the previous iteration's,
+        whose offsets differ by one optimizer step; EDVR_DCN_HINT_WAIT=1 evaluates them right away instead (one host
+        synchronisation per iteration, deterministic kernel choice)."""
         if not sink:
             return
         import torch
@@ -295,7 +297,7 @@ class EDVR(nn.Module):
         if torch.cuda.is_current_stream_capturing():  # hipGraph capture (edvr_amd/graphs.py): the sums are outputs of the graph,
             self._captured_offset_stats = (sums, recs)  # read back on demand by GraphedEDVR.check_offsets
             return
-        if torch.is_grad_enabled():
+        if torch.is_grad_enabled() and F_.ops.HINT_WAIT:
             self._examine_offsets(sums.cpu(), recs)
             return
         host = torch.empty(sums.shape, dtype=sums.dtype, pin_memory=True)

@@ -119,9 +119,10 @@ print("ok")
     assert r.returncode == 0 and 'ok' in r.stdout, r.stdout + r.stderr
 
 
-def test_offset_check_is_lazy_in_inference_and_eager_in_training(gpu, caplog):
+def test_offset_check_never_waits_for_the_gpu(gpu, caplog, monkeypatch):
     """arch_util.py:248-253's `Offset abs mean is ..., larger than 50` warning: no host synchronisation in a no-grad forward
-    (the statistics are examined when the next forward starts or on check_offsets()); evaluated right away in grad mode."""
+    or in a training forward (the statistics are examined when the next forward starts, on check_offsets() or on train() / eval());
+    evaluated right away in grad mode only under EDVR_DCN_HINT_WAIT=1 (deterministic choice of the backward's dX strategy)."""
     import logging
     net, x, _ = build('M_T5')
     with torch.no_grad():
@@ -149,7 +150,17 @@ def test_offset_check_is_lazy_in_inference_and_eager_in_training(gpu, caplog):
         net.check_offsets()
         caplog.clear()
         net.train()  # (train() / eval() also flush whatever is pending: nothing here)
-        net(xg).sum().backward()  # grad mode: evaluated inside the forward (the backward's scatter strategy needs it)
+        net(xg).sum().backward()  # grad mode: queued as well - the backward picks its dX strategy from what has arrived
+        assert len(net._pending_offset_stats) == 1
+        assert not [r for r in caplog.records if 'larger than 50' in r.getMessage()]
+        net.eval()  # flushes the queue
+        assert not net._pending_offset_stats
+        assert len([r for r in caplog.records if 'larger than 50' in r.getMessage()]) == n_inf
+        caplog.clear()
+        from edvr_amd import ops
+        monkeypatch.setattr(ops, 'HINT_WAIT', True)  # EDVR_DCN_HINT_WAIT=1: evaluated inside the training forward
+        net.train()
+        net(xg).sum().backward()
         assert not net._pending_offset_stats
         assert len([r for r in caplog.records if 'larger than 50' in r.getMessage()]) == n_inf
     assert torch.isfinite(out).all()

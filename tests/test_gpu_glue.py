@@ -32,13 +32,20 @@ def test_pool_maxavg(gpu, hw):
     assert _rel(ops.pool_maxavg(x.to(gpu)), ref) < TOL
 
 
-@pytest.mark.parametrize('hw', [(8, 8), (45, 80), (5, 3), (6, 2), (1, 4), (3, 130)])
+@pytest.mark.parametrize('hw', [(8, 8), (45, 80), (5, 3), (6, 2), (1, 4), (3, 130), (7, 256), (5, 260), (2, 12)])
 def test_upsample2x_and_4x_add(gpu, hw):
     from edvr_amd import ops
     g = torch.Generator().manual_seed(3)
     x = torch.randn(2, 3, *hw, generator=g)
     ref2 = F.interpolate(x.double(), scale_factor=2, mode='bilinear', align_corners=False) * 2
     assert _rel(ops.upsample2x(x.to(gpu), 2.0), ref2) < TOL
+    # the three x2 kernels (16-byte groups with lane exchanges / 8-byte pairs / generic) evaluate the same expression per output:
+    # the same values from an 8-byte aligned and from a 4-byte aligned view of the input are bit-identical
+    got = ops.upsample2x(x.to(gpu), 2.0)
+    for shift in (2, 1):
+        flat = torch.zeros(x.numel() + shift, device=gpu)
+        flat[shift:] = x.to(gpu).reshape(-1)
+        assert torch.equal(ops.upsample2x(flat[shift:].view(x.shape), 2.0), got)
     y = torch.randn(2, 3, 4 * hw[0], 4 * hw[1], generator=g)
     ref4 = y.double() + F.interpolate(x.double(), scale_factor=4, mode='bilinear', align_corners=False)
     assert _rel(ops.upsample4x_add_(y.to(gpu), x.to(gpu)), ref4) < TOL
