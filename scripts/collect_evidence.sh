@@ -1,5 +1,5 @@
 #!/bin/bash
-# collect_evidence.sh SRC_DIR ROUND   e.g. gpurun_out/r4j r4 : copy what scripts/gpu_run10.sh wrote into profiles/ROUND/
+# collect_evidence.sh SRC_DIR ROUND   e.g. gpurun_out/r4j r4 : copy what scripts/gpu_evidence.sh wrote into profiles/ROUND/
 set -e
 S=$1; D=profiles/$2
 cp $S/bench_default.json $D/bench_default_run.json

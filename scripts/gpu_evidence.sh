@@ -1,3 +1,5 @@
+# GPU box: every file profiles/rN/ is built from (kernel stats, traffic, PMC passes, sweeps, the default bench line) -> gpurun_out/r4j;
+# then on the build host: scripts/collect_evidence.sh gpurun_out/r4j r4.   gpurun --timeout 1500 -- "bash scripts/gpu_evidence.sh"
 mkdir -p gpurun_out/r4j
 export PYTHONUNBUFFERED=1
 R=$PWD

@@ -1,3 +1,4 @@
+# GPU box: the whole -m gpu suite + __graft_entry__.smoke().   gpurun --timeout 1500 -- "bash scripts/gpu_full_suite.sh"
 mkdir -p gpurun_out/r4k
 export PYTHONUNBUFFERED=1
 ( timeout 1800 python -m pytest tests -q -m gpu 2>&1 | tail -15 ) > gpurun_out/r4k/test_gpu_all.log 2>&1
