@@ -346,7 +346,27 @@ def test_edvr_l_full_depth_parameter_gradients_match_oracle(gpu):
     _followed_gradient_check(gpu, 'L_full_T5')
 
 
-def _followed_gradient_check(gpu, name):
+@pytest.mark.parametrize('name,hint_wait', [('M_T5_b2_rect', True), ('M_T5_b2_rect', False), ('L_T7', True)])
+def test_edvr_parameter_gradients_with_multi_pixel_offsets(gpu, name, hint_wait, monkeypatch):
+    """The same whole-network check on the offsets of a TRAINED model (`conv_offset.bias ~ N(0, 4^2)` per channel: per-tap
+    displacements of several pixels, the `trained_like` legs of bench.py): the forward runs on the tap-window kernel where the level
+    is wide enough (44 / 48 columns: L1; the narrower levels on the halo / column kernels), the backward on the dX strategies
+    the statistics of THIS forward select (hint_wait, the deterministic mode: LDS window / device atomics) or on the default
+    strategy a first iteration gets (statistics not yet examined)."""
+    from edvr_amd import ops
+    monkeypatch.setattr(ops, 'HINT_WAIT', hint_wait)
+    launches = []
+
+    def hook(name_, flops, launch, *rest):
+        launches.append(name_)
+        launch()
+
+    monkeypatch.setattr(ops, 'LAUNCH_HOOK', hook)
+    _followed_gradient_check(gpu, name, bias_sigma=4.0)
+    assert any('dcn_tapwin_fwd_kernel' in n for n in launches), sorted(set(launches))
+
+
+def _followed_gradient_check(gpu, name, bias_sigma=0.5):
     """Whole network: d(Charbonnier sum)/d(every parameter), HIP fp32 vs oracle autograd fp64.
     The bound is calibrated per tensor against the fp32 noise floor of the oracle itself (same algorithm in fp32 on the
     CPU vs fp64): ours must be within max(1e-3, 4 x that floor) of the fp64 truth, relative to max|grad|.
@@ -362,7 +382,7 @@ def _followed_gradient_check(gpu, name):
     from edvr_amd.autograd import charbonnier_loss
     from oracle import dcn_oracle as O, edvr_oracle as EO
     from util_edvr import DecisionRecorder
-    net, x, kwargs = build(name)
+    net, x, kwargs = build(name, bias_sigma=bias_sigma)
     net.train()
     state = {k: v.detach().clone() for k, v in net.state_dict().items()}
     net = net.to(gpu)

@@ -34,11 +34,11 @@ def randomize_offsets(net, seed=123, bias_sigma=0.5):
     return net
 
 
-def build(name, seed=10):
+def build(name, seed=10, bias_sigma=0.5):
     from edvr_amd import EDVR
     kwargs, shape = CONFIGS[name]
     torch.manual_seed(seed)
-    net = randomize_offsets(EDVR(**kwargs)).eval()
+    net = randomize_offsets(EDVR(**kwargs), bias_sigma=bias_sigma).eval()
     x = torch.rand(*shape, generator=torch.Generator().manual_seed(0))
     return net, x, kwargs
 
