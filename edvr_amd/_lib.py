@@ -73,6 +73,7 @@ PROTOTYPES = {
     'edvr_conv2d_wgrad_f32': (i32, [vp] * 4 + [i32] * 8 + [i64, i64, i32, i32, i32, i64, i32, vp, vp, sz, vp]),
     'edvr_channel_sum_f32': (i32, [vp, vp, i32, i32, i64, i64, vp, sz, vp]),
     'edvr_pixel_unshuffle2_f32': (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    'edvr_pixel_unshuffle2_act_bwd_f32': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     'edvr_zero_stuff2_f32': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     'edvr_frame_reduce_add_f32': (i32, [vp, vp, i32, i32, i32, i64, vp]),
     'edvr_upsample2x_bwd_f32': (i32, [vp, vp, i32, i32, i32, f32, vp]),

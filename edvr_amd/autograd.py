@@ -41,7 +41,7 @@ class ConvFn(Function):
         dres = dy if (has_r1 and need[4]) or (has_r2 and need[5]) else None
         # gradient w.r.t. the pre-activation conv output z (n, co, ho, wo)
         if out_mode == OUT_PIXEL_SHUFFLE2:
-            dz = ops.pixel_unshuffle2(ops.act_backward(dy, y, act) if act != ACT_NONE else dy)
+            dz = ops.pixel_unshuffle2_act_backward(dy, y, act)  # activation backward and un-shuffle in one pass
         else:
             dz = ops.act_backward(dy, y, act, act_from, res1, res2) if act != ACT_NONE else dy
         want_db = has_bias and need[3]

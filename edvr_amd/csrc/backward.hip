@@ -26,6 +26,42 @@ __global__ __launch_bounds__(256) void pixel_unshuffle2_kernel(const float *__re
   }
 }
 
+// The same with the activation backward folded in (gradient of `PixelShuffle(act(conv))`, the two up-convolutions of the tail): dz =
+// unshuffle(dy * act'(y)), y = the shuffled activation output.  One thread = one 2 x 2 block of the shuffled tensor = the same
+// pixel of four channel planes: two 8-byte loads per input, four plane-coalesced stores (the plain kernel above gathers every
+// second float of a row per thread; as two launches the gradient made two round trips over the largest tensors of the step).
+__global__ __launch_bounds__(256) void pixel_unshuffle2_act_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y,
+                                                                       float *__restrict__ dz, int64_t blocks, int h, int w, int act) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < blocks; i += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(i % w);
+    const int oy = (int)((i / w) % h);
+    const int64_t pl = i / ((int64_t)w * h);  // n * c + oc
+    const int64_t src = (pl * (2 * h) + 2 * oy) * (int64_t)(2 * w) + 2 * ox;
+    float g[4], v[4] = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+    for (int sy = 0; sy < 2; ++sy) {
+      const f32x2 a = *reinterpret_cast<const f32x2 *>(dy + src + (int64_t)sy * 2 * w);
+      g[2 * sy] = a[0];
+      g[2 * sy + 1] = a[1];
+      if (y) {
+        const f32x2 b = *reinterpret_cast<const f32x2 *>(y + src + (int64_t)sy * 2 * w);
+        v[2 * sy] = b[0];
+        v[2 * sy + 1] = b[1];
+      }
+    }
+    float *dst = dz + (pl * 4 * h + oy) * (int64_t)w + ox;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float r = g[k];
+      if (act == EDVR_ACT_RELU) r = v[k] > 0.f ? r : 0.f;
+      else if (act == EDVR_ACT_LRELU) r = v[k] > 0.f ? r : 0.1f * r;
+      else if (act == EDVR_ACT_SIGMOID) r = r * v[k] * (1.f - v[k]);
+      dst[(int64_t)k * h * w] = r;
+    }
+  }
+}
+
 // z (n, c, H, W) with z[2oy, 2ox] = dz[oy, ox], zero elsewhere: stride-2 data gradient = stride-1 conv of z
 __global__ __launch_bounds__(256) void zero_stuff2_kernel(const float *__restrict__ dz, float *__restrict__ z, int64_t total, int H, int W,
                                                           int ho, int wo) {
@@ -202,6 +238,17 @@ int edvr_pixel_unshuffle2_f32(const float *x, float *y, int n, int c, int h, int
   const int64_t total = (int64_t)n * 4 * c * h * w;
   hipLaunchKernelGGL(pixel_unshuffle2_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, y, total, 4 * c, h, w);
   return check_launch("pixel_unshuffle2_kernel");
+}
+
+int edvr_pixel_unshuffle2_act_bwd_f32(const float *dy, const float *y, float *dz, int n, int c, int h, int w, int act, edvr_stream_t stream) {
+  using namespace edvr;
+  EDVR_REQUIRE(dy && dz && n > 0 && c > 0 && h > 0 && w > 0, "pixel_unshuffle2_act_bwd: bad arguments");
+  EDVR_REQUIRE(y || act == EDVR_ACT_NONE, "pixel_unshuffle2_act_bwd: an activation needs its output");
+  EDVR_REQUIRE((reinterpret_cast<uintptr_t>(dy) & 7) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0, "pixel_unshuffle2_act_bwd: 8-byte aligned tensors");
+  const int64_t blocks = (int64_t)n * c * h * w;
+  hipLaunchKernelGGL(pixel_unshuffle2_act_bwd_kernel, dim3(grid_for(blocks)), dim3(256), 0, as_stream(stream), dy, act == EDVR_ACT_NONE ? nullptr : y, dz,
+                     blocks, h, w, act);
+  return check_launch("pixel_unshuffle2_act_bwd_kernel");
 }
 
 int edvr_zero_stuff2_f32(const float *dz, float *z, int nc, int H, int W, int ho, int wo, edvr_stream_t stream) {

@@ -652,6 +652,23 @@ def pixel_unshuffle2(x):
     return y
 
 
+def pixel_unshuffle2_act_backward(dy, y, act):
+    """unshuffle(dy * act'(y)): the gradient of PixelShuffle(2)(act(z)) w.r.t. z in one launch (y = the shuffled activation output)."""
+    require_gpu(dy)
+    dy = dy.contiguous()
+    n, c, h2, w2 = dy.shape
+    if act != ACT_NONE:
+        require_gpu(y)
+        y = y.contiguous()
+        if tuple(y.shape) != tuple(dy.shape):
+            raise RuntimeError(f'pixel_unshuffle2_act_backward: y {tuple(y.shape)} vs dy {tuple(dy.shape)}')
+    dz = torch.empty(n, 4 * c, h2 // 2, w2 // 2, dtype=torch.float32, device=dy.device)
+    _run('pixel_unshuffle2_act_bwd', lambda: _lib.check(_lib.lib().edvr_pixel_unshuffle2_act_bwd_f32(
+        _ptr(dy), _ptr(y) if act != ACT_NONE else None, _ptr(dz), n, c, h2 // 2, w2 // 2, int(act), _stream()), 'edvr_pixel_unshuffle2_act_bwd_f32'),
+        0, _nb(dy, dz) + (_nb(y) if act != ACT_NONE else 0.0))
+    return dz
+
+
 def zero_stuff2(dz, H, W):
     require_gpu(dz)
     dz = dz.contiguous()

@@ -316,6 +316,9 @@ int edvr_channel_sum_f32(const float *x, float *out, int n, int c, int64_t hw, i
                          edvr_stream_t stream);
 /* inverse of PixelShuffle(2): x (n, c, 2h, 2w) -> y (n, 4c, h, w) */
 int edvr_pixel_unshuffle2_f32(const float *x, float *y, int n, int c, int h, int w, edvr_stream_t stream);
+/* the same on dy * act'(y): dz (n, 4c, h, w) = unshuffle(dy (n, c, 2h, 2w) gated by the activation output y of the same shape) - the
+ * gradient of PixelShuffle(act(conv(.))) w.r.t. the conv output in one pass (edvr_arch.py:403-404); y may be NULL with EDVR_ACT_NONE */
+int edvr_pixel_unshuffle2_act_bwd_f32(const float *dy, const float *y, float *dz, int n, int c, int h, int w, int act, edvr_stream_t stream);
 /* z (nc, H, W): z[2oy,2ox] = dz[oy,ox] (dz is (nc, ho, wo)), 0 elsewhere - the stride-2 data gradient is the
  * stride-1 transposed-kernel conv of z */
 int edvr_zero_stuff2_f32(const float *dz, float *z, int nc, int H, int W, int ho, int wo, edvr_stream_t stream);

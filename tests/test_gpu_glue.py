@@ -68,3 +68,21 @@ def test_combine_add_abs_sum_act_bwd(gpu):
     s = torch.sigmoid(a)
     ref = torch.cat([b[:, :5], (b * s * (1 - s))[:, 5:]], 1).double()
     assert _rel(ops.act_backward(b.to(gpu), s.to(gpu), ops.ACT_SIGMOID, act_from=5), ref) < 1e-5
+
+
+@pytest.mark.parametrize('act', ['none', 'relu', 'lrelu'])
+def test_pixel_unshuffle2_with_the_activation_backward_folded_in(gpu, act):
+    """Gradient of PixelShuffle(2)(act(z)) w.r.t. z in one launch (the two up-convolutions of the tail, edvr_arch.py:403-404): equals
+    the two-launch form bit for bit and torch's pixel_unshuffle of the gated gradient."""
+    from edvr_amd import ops
+    code = {'none': ops.ACT_NONE, 'relu': ops.ACT_RELU, 'lrelu': ops.ACT_LRELU}[act]
+    g = torch.Generator().manual_seed(21)
+    for shape in [(2, 3, 10, 14), (1, 64, 64, 96), (3, 1, 2, 2)]:
+        dy, z = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
+        y = {'none': z, 'relu': torch.relu(z), 'lrelu': F.leaky_relu(z, 0.1)}[act]
+        gate = {'none': torch.ones_like(z), 'relu': (z > 0).float(), 'lrelu': torch.where(z > 0, 1.0, 0.1)}[act]
+        ref = F.pixel_unshuffle((dy * gate).double(), 2)
+        got = ops.pixel_unshuffle2_act_backward(dy.to(gpu), y.to(gpu), code)
+        assert _rel(got, ref) < TOL
+        two = ops.pixel_unshuffle2(ops.act_backward(dy.to(gpu), y.to(gpu), code) if act != 'none' else dy.to(gpu))
+        assert torch.equal(got, two)
