@@ -78,7 +78,7 @@ PROTOTYPES = {
     'edvr_frame_reduce_add_f32': (i32, [vp, vp, i32, i32, i32, i64, vp]),
     'edvr_upsample2x_bwd_f32': (i32, [vp, vp, i32, i32, i32, f32, vp]),
     'edvr_pool_maxavg_3x3s2_bwd_f32': (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
-    'edvr_tsa_temporal_bwd_f32': (i32, [vp] * 7 + [i32] * 4 + [vp]),
+    'edvr_tsa_temporal_bwd_f32': (i32, [vp] * 7 + [i32] * 4 + [vp, vp]),
     'edvr_tsa_combine_bwd_f32': (i32, [vp] * 5 + [i64, vp]),
     'edvr_charbonnier_f32': (i32, [vp, vp, vp, vp, i64, f32, f32, vp]),
     'edvr_abs_sum_f32': (i32, [vp, vp, i32, i64, i64, vp]),

@@ -127,6 +127,48 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float *__rest
   }
 }
 
+// The same for even widths and 16-byte aligned rows: the adjoint of the x2 bilinear map has the fixed taps (1/4, 3/4, 3/4, 1/4) per
+// axis on output rows / columns 2i - 1 .. 2i + 2 (at the borders the clamped source index folds the outer tap into its neighbour:
+// 0, 1, 3/4, 1/4 at i = 0 and 1/4, 3/4, 1, 0 at the last index).  A thread owns input columns (2j, 2j + 1) of one row: four 16-byte
+// loads of dy (columns 4j .. 4j + 3 of its four rows), the columns 4j - 1 / 4j + 4 come from the neighbouring lanes - 4 loads for 2
+// results where the kernel above issues 32 scalar ones behind its generic index logic (0.17 of the HBM rate in the training step).
+__global__ __launch_bounds__(256) void upsample2x_bwd_wide_kernel(const float *__restrict__ dy, float *__restrict__ dx, int nc, int h, int w, float scale) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const int wq = w >> 1, lane = threadIdx.x & 63, wo = 2 * w, ho = 2 * h;
+  const int64_t total = (int64_t)nc * h * wq;
+  const int64_t rounded = (total + 255) / 256 * 256;
+  for (int64_t base = (int64_t)blockIdx.x * 256; base < rounded; base += (int64_t)gridDim.x * 256) {
+    const int64_t idx_raw = base + threadIdx.x;
+    const bool active = idx_raw < total;
+    const int64_t idx = active ? idx_raw : total - 1;  // (inactive lanes still take part in the lane exchanges)
+    const int j = (int)(idx % wq);
+    const int iy = (int)((idx / wq) % h);
+    const int64_t pl = idx / ((int64_t)wq * h);
+    const float *g = dy + pl * ((int64_t)ho * wo);
+    // row taps: output rows 2 iy - 1 .. 2 iy + 2
+    const float wy[4] = {iy == 0 ? 0.f : 0.25f, iy == 0 ? 1.f : 0.75f, iy == h - 1 ? 1.f : 0.75f, iy == h - 1 ? 0.f : 0.25f};
+    // column taps of input column 2j (output columns 4j - 1 .. 4j + 2) and 2j + 1 (4j + 1 .. 4j + 4)
+    const bool first = j == 0, last = j == wq - 1;
+    const float a0 = first ? 0.f : 0.25f, a1 = first ? 1.f : 0.75f, b2 = last ? 1.f : 0.75f, b3 = last ? 0.f : 0.25f;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int oy = min(max(2 * iy - 1 + a, 0), ho - 1);  // (clamped rows carry the tap 0)
+      const f32x4 m = *reinterpret_cast<const f32x4 *>(g + (int64_t)oy * wo + 4 * j);
+      const float from_left = __shfl_up(m[3], 1, 64), from_right = __shfl_down(m[0], 1, 64);
+      float l = first ? 0.f : from_left, r = last ? 0.f : from_right;
+      if (lane == 0 && !first) l = g[(int64_t)oy * wo + 4 * j - 1];
+      if (lane == 63 && !last) r = g[(int64_t)oy * wo + 4 * j + 4];
+      const float h0 = __builtin_fmaf(a0, l, __builtin_fmaf(a1, m[0], __builtin_fmaf(0.75f, m[1], 0.25f * m[2])));
+      const float h1 = __builtin_fmaf(0.25f, m[1], __builtin_fmaf(0.75f, m[2], __builtin_fmaf(b2, m[3], b3 * r)));
+      s0 = __builtin_fmaf(wy[a], h0, s0);
+      s1 = __builtin_fmaf(wy[a], h1, s1);
+    }
+    if (active) *reinterpret_cast<f32x2 *>(dx + (pl * h + iy) * (int64_t)w + 2 * j) = f32x2{s0 * scale, s1 * scale};
+  }
+}
+
 // dx (n, c, h, w) <- dy (n, 2c, ho, wo) of y = cat(maxpool(x), avgpool(x)), 3x3 / s2 / p1
 __global__ __launch_bounds__(256) void pool_maxavg_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ dx,
                                                               int64_t total, int c, int h, int w, int ho, int wo) {
@@ -196,6 +238,49 @@ __global__ __launch_bounds__(256) void tsa_temporal_bwd_kernel(const float *__re
       for (int ti = 0; ti < t; ++ti) s += ds[ti] * emb[((int64_t)(bi * t + ti) * c + ch) * hw + p];
       d_ref[((int64_t)bi * c + ch) * hw + p] = s;
     }
+  }
+}
+
+// The same in two fully parallel passes (the kernel above runs ONE thread per (clip, pixel) through t x c dependent-address loads:
+// 131 072 threads on the training shape, 0.21 of the HBM rate).  Pass 1, one thread per (clip, frame, pixel): the two channel sums,
+// ds = <dout, aligned> p (1 - p) into a small scratch plane, d_aligned = dout * p and d_emb = ds * ref.  Pass 2, one thread per
+// (clip, channel, pixel): d_ref = sum_t ds[t] * emb[t].  Same arithmetic per element, same summation order over channels / frames.
+__global__ __launch_bounds__(256) void tsa_temporal_bwd_frames_kernel(const float *__restrict__ emb, const float *__restrict__ emb_ref,
+                                                                      const float *__restrict__ aligned, const float *__restrict__ dout,
+                                                                      float *__restrict__ d_emb, float *__restrict__ d_al, float *__restrict__ ds_ws,
+                                                                      int64_t total, int t, int c, int hw) {
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int p = (int)(idx % hw);
+    const int64_t bt = idx / hw;  // clip * t + frame
+    const int64_t bi = bt / t;
+    const float *r = emb_ref + bi * c * hw + p;
+    const int64_t base = bt * c * hw + p;
+    float dot = 0.f, dp = 0.f;
+#pragma unroll 8
+    for (int ch = 0; ch < c; ++ch) {
+      dot += emb[base + (int64_t)ch * hw] * r[(int64_t)ch * hw];
+      dp += dout[base + (int64_t)ch * hw] * aligned[base + (int64_t)ch * hw];
+    }
+    const float pr = sigmoidf_(dot);
+    const float ds = dp * pr * (1.f - pr);
+    ds_ws[idx] = ds;
+#pragma unroll 8
+    for (int ch = 0; ch < c; ++ch) {
+      d_al[base + (int64_t)ch * hw] = dout[base + (int64_t)ch * hw] * pr;
+      d_emb[base + (int64_t)ch * hw] = ds * r[(int64_t)ch * hw];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void tsa_temporal_bwd_ref_kernel(const float *__restrict__ emb, const float *__restrict__ ds_ws, float *__restrict__ d_ref,
+                                                                   int64_t total, int t, int c, int hw) {
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int p = (int)(idx % hw);
+    const int ch = (int)((idx / hw) % c);
+    const int64_t bi = idx / ((int64_t)hw * c);
+    float s = 0.f;
+    for (int ti = 0; ti < t; ++ti) s += ds_ws[(bi * t + ti) * hw + p] * emb[((bi * t + ti) * c + ch) * (int64_t)hw + p];
+    d_ref[idx] = s;
   }
 }
 
@@ -271,6 +356,10 @@ int edvr_upsample2x_bwd_f32(const float *dy, float *dx, int nc, int h, int w, fl
   using namespace edvr;
   EDVR_REQUIRE(dy && dx && nc > 0 && h > 0 && w > 0, "upsample2x_bwd: bad arguments");
   const int64_t total = (int64_t)nc * h * w;
+  if ((w & 1) == 0 && w >= 4 && (((int64_t)h * w) & 1) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 && (reinterpret_cast<uintptr_t>(dx) & 7) == 0) {
+    hipLaunchKernelGGL(upsample2x_bwd_wide_kernel, dim3(grid_for(total / 2)), dim3(256), 0, as_stream(stream), dy, dx, nc, h, w, scale);
+    return check_launch("upsample2x_bwd_wide_kernel");
+  }
   hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), dy, dx, total, h, w, scale);
   return check_launch("upsample2x_bwd_kernel");
 }
@@ -285,10 +374,17 @@ int edvr_pool_maxavg_3x3s2_bwd_f32(const float *x, const float *dy, float *dx, i
 }
 
 int edvr_tsa_temporal_bwd_f32(const float *emb, const float *emb_ref, const float *aligned, const float *dout, float *d_emb, float *d_emb_ref,
-                              float *d_aligned, int b, int t, int c, int hw, edvr_stream_t stream) {
+                              float *d_aligned, int b, int t, int c, int hw, float *ws, edvr_stream_t stream) {
   using namespace edvr;
   EDVR_REQUIRE(emb && emb_ref && aligned && dout && d_emb && d_emb_ref && d_aligned && b > 0 && t > 0 && t <= 16 && c > 0 && hw > 0,
                "tsa_temporal_bwd: bad arguments (t <= 16)");
+  if (ws) {
+    const int64_t frames = (int64_t)b * t * hw, refs = (int64_t)b * c * hw;
+    hipLaunchKernelGGL(tsa_temporal_bwd_frames_kernel, dim3(grid_for(frames)), dim3(256), 0, as_stream(stream), emb, emb_ref, aligned, dout, d_emb,
+                       d_aligned, ws, frames, t, c, hw);
+    hipLaunchKernelGGL(tsa_temporal_bwd_ref_kernel, dim3(grid_for(refs)), dim3(256), 0, as_stream(stream), emb, ws, d_emb_ref, refs, t, c, hw);
+    return check_launch("tsa_temporal_bwd_frames_kernel");
+  }
   hipLaunchKernelGGL(tsa_temporal_bwd_kernel, dim3(grid_for((int64_t)b * hw)), dim3(256), 0, as_stream(stream), emb, emb_ref, aligned, dout, d_emb,
                      d_emb_ref, d_aligned, b, t, c, hw);
   return check_launch("tsa_temporal_bwd_kernel");

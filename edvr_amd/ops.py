@@ -714,8 +714,9 @@ def tsa_temporal_backward(emb, emb_ref, aligned, dout):
     emb, emb_ref, aligned, dout = emb.contiguous(), emb_ref.contiguous(), aligned.contiguous(), dout.contiguous()
     b, t, c, h, w = aligned.shape
     d_emb, d_ref, d_al = torch.empty_like(emb), torch.empty_like(emb_ref), torch.empty_like(aligned)
+    ws = torch.empty(b * t * h * w, dtype=torch.float32, device=emb.device)  # per-(clip, frame, pixel) scalar between the two passes
     _run('tsa_temporal_bwd', lambda: _lib.check(_lib.lib().edvr_tsa_temporal_bwd_f32(_ptr(emb), _ptr(emb_ref), _ptr(aligned), _ptr(dout), _ptr(d_emb), _ptr(d_ref),
-                                                    _ptr(d_al), b, t, c, h * w, _stream()),
+                                                    _ptr(d_al), b, t, c, h * w, _ptr(ws), _stream()),
                                        'edvr_tsa_temporal_bwd_f32'), 0, _nb(emb, emb_ref, aligned, dout, d_emb, d_ref, d_al))
     return d_emb, d_ref, d_al
 

@@ -326,8 +326,9 @@ int edvr_zero_stuff2_f32(const float *dz, float *z, int nc, int H, int W, int ho
 int edvr_frame_reduce_add_f32(const float *src, float *dst, int b, int t, int center, int64_t chw, edvr_stream_t stream);
 int edvr_upsample2x_bwd_f32(const float *dy, float *dx, int nc, int h, int w, float scale, edvr_stream_t stream);
 int edvr_pool_maxavg_3x3s2_bwd_f32(const float *x, const float *dy, float *dx, int n, int c, int h, int w, edvr_stream_t stream);
+/* ws: b*t*hw floats of scratch (two fully parallel passes); NULL = the one-pass kernel, one thread per (clip, pixel) */
 int edvr_tsa_temporal_bwd_f32(const float *emb, const float *emb_ref, const float *aligned, const float *dout, float *d_emb,
-                              float *d_emb_ref, float *d_aligned, int b, int t, int c, int hw, edvr_stream_t stream);
+                              float *d_emb_ref, float *d_aligned, int b, int t, int c, int hw, float *ws, edvr_stream_t stream);
 int edvr_tsa_combine_bwd_f32(const float *feat, const float *attn, const float *dy, float *dfeat, float *dattn, int64_t numel,
                              edvr_stream_t stream);
 /* CharbonnierLoss, reduction 'sum' (basicsr/models/losses/losses.py:23-25): *loss = sum sqrt((p-t)^2 + eps) and, if dpred != NULL,

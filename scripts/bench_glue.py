@@ -40,3 +40,16 @@ for (n, c, h, w_) in [(50, 128, 90, 160), (50, 128, 45, 80), (50, 144, 90, 160)]
     ms = timed(lambda: ops.upsample2x(x, 2.0))
     out.append(f'upsample2x {n}x{c}x{h}x{w_}: {ms:.3f} ms ({x.numel() * 5 * 4 / ms / 1e9:.2f} TB/s)')
 print(f'{label:10s} ' + ' | '.join(out), flush=True)
+# training-side glue: adjoint of the x2 upsampling, TSA temporal attention backward
+out = []
+for (n, c, h, w_) in [(160, 128, 32, 32), (160, 144, 32, 32), (160, 128, 16, 16)]:
+    dy = torch.randn(n, c, 2 * h, 2 * w_, device=dev)
+    ms = timed(lambda: ops.upsample2x_backward(dy, 2.0))
+    out.append(f'upsample2x_bwd {n}x{c}x{h}x{w_}: {ms:.3f} ms ({dy.numel() * 1.25 * 4 / ms / 1e9:.2f} TB/s)')
+emb = torch.randn(32, 5, 128, 64, 64, device=dev) * 0.1
+ref = torch.randn(32, 128, 64, 64, device=dev) * 0.1
+al = torch.randn(32, 5, 128, 64, 64, device=dev)
+do = torch.randn(32, 5, 128, 64, 64, device=dev)
+ms = timed(lambda: ops.tsa_temporal_backward(emb, ref, al, do), reps=10)
+out.append(f'tsa_temporal_bwd 32x5x128x64x64: {ms:.3f} ms ({(6 * emb.numel() + 2 * ref.numel()) * 4 / ms / 1e9:.2f} TB/s)')
+print(f'{label:10s} ' + ' | '.join(out), flush=True)

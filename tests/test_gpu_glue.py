@@ -86,3 +86,32 @@ def test_pixel_unshuffle2_with_the_activation_backward_folded_in(gpu, act):
         assert _rel(got, ref) < TOL
         two = ops.pixel_unshuffle2(ops.act_backward(dy.to(gpu), y.to(gpu), code) if act != 'none' else dy.to(gpu))
         assert torch.equal(got, two)
+
+
+@pytest.mark.parametrize('hw', [(8, 8), (45, 80), (7, 256), (5, 260), (1, 2), (3, 130), (5, 3), (1, 1), (2, 6)])
+def test_upsample2x_backward(gpu, hw):
+    """Adjoint of the x2 bilinear upsampling against torch autograd in fp64: the 16-byte kernel with lane exchanges (even widths; rows
+    that end inside a wave, waves that end inside a row, single-row / two-column borders) and the generic one (odd widths)."""
+    from edvr_amd import ops
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(2, 3, *hw, generator=g).double().requires_grad_()
+    dy = torch.randn(2, 3, 2 * hw[0], 2 * hw[1], generator=g)
+    (F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False) * 1.5).backward(dy.double())
+    assert _rel(ops.upsample2x_backward(dy.to(gpu), 1.5), x.grad) < TOL
+
+
+def test_tsa_temporal_backward_two_pass(gpu):
+    """TSA temporal attention backward (two parallel passes through a scratch plane) against torch autograd in fp64 on a shape with
+    several workgroups per pass."""
+    from edvr_amd import ops
+    g = torch.Generator().manual_seed(32)
+    b, t, c, h, w = 3, 5, 24, 20, 36
+    emb, al = torch.randn(b, t, c, h, w, generator=g) * 0.3, torch.randn(b, t, c, h, w, generator=g)
+    er = torch.randn(b, c, h, w, generator=g) * 0.3
+    leaves = [v.double().requires_grad_() for v in (emb, er, al)]
+    out = leaves[2] * torch.sigmoid((leaves[0] * leaves[1].unsqueeze(1)).sum(2)).unsqueeze(2)
+    dy = torch.randn(out.shape, generator=g)
+    out.backward(dy.double())
+    d_emb, d_ref, d_al = ops.tsa_temporal_backward(emb.to(gpu), er.to(gpu), al.to(gpu), dy.to(gpu))
+    for a, r in zip((d_emb, d_ref, d_al), leaves):
+        assert _rel(a, r.grad) < 1e-4
