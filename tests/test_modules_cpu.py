@@ -55,6 +55,15 @@ def test_cpu_tensors_are_refused_like_the_reference():
         EDVR(num_feat=16, num_reconstruct_block=1)(torch.rand(1, 5, 3, 16, 16))
     with pytest.raises(NotImplementedError):
         ModulatedDeformConvPack(8, 8, 3, padding=1)(torch.randn(1, 8, 6, 6))
+    # the glue operators of the training path have no CPU route either: a CPU tensor is refused, never computed on the host
+    from edvr_amd import ops
+    x = torch.randn(1, 2, 4, 4)
+    for call in (lambda: ops.upsample2x(x), lambda: ops.upsample2x_backward(x), lambda: ops.pixel_unshuffle2(x),
+                 lambda: ops.pixel_unshuffle2_act_backward(x, x, ops.ACT_LRELU), lambda: ops.act_backward(x, x, ops.ACT_RELU),
+                 lambda: ops.tsa_temporal_backward(torch.randn(1, 3, 2, 4, 4), torch.randn(1, 2, 4, 4), torch.randn(1, 3, 2, 4, 4),
+                                                   torch.randn(1, 3, 2, 4, 4))):
+        with pytest.raises(NotImplementedError):
+            call()
 
 
 def test_input_size_assertions():
