@@ -22,7 +22,7 @@ class ConvDesc(ctypes.Structure):
         ('bias', vp), ('co', i32), ('ks', i32), ('stride', i32), ('act', i32), ('act_from', i32), ('res1', vp),
         ('res2', vp), ('res1_img_stride', i64), ('res2_img_stride', i64), ('y', vp), ('y_img_stride', i64),
         ('out_mode', i32), ('algo', i32), ('gate', vp), ('gate_img_stride', i64), ('gate_slope', f32), ('y_scale', f32),
-        ('wpk_f4', vp), ('abs_sum', vp), ('abs_sum_channels', i32),
+        ('wpk_f4', vp), ('abs_sum', vp), ('abs_sum_channels', i32), ('wpk_f4s', vp), ('x_amax', vp),
     ]
 
 
@@ -35,6 +35,9 @@ PROTOTYPES = {
     'edvr_conv2d_pack_weight_f32': (i32, [vp, vp, i32, i32, i32, i32, vp]),
     'edvr_conv2d_packed_weight_f4_elems': (sz, [i32, i32]),
     'edvr_conv2d_pack_weight_f4_f32': (i32, [vp, vp, i32, i32, i32, vp]),
+    'edvr_conv2d_packed_weight_f4s_elems': (sz, [i32, i32]),
+    'edvr_conv2d_pack_weight_f4s_f32': (i32, [vp, vp, i32, i32, i32, vp]),
+    'edvr_amax_f32': (i32, [vp, vp, i32, i64, i64, vp]),
     'edvr_pack_job_bytes': (sz, []),
     'edvr_conv2d_pack_weights_multi': (i32, [vp, i32, i32, vp]),
     'edvr_conv2d_f32': (i32, [ctypes.POINTER(ConvDesc), vp]),
@@ -87,7 +90,7 @@ PROTOTYPES = {
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
 OUT_NCHW, OUT_PIXEL_SHUFFLE2 = 0, 1
-CONV_AUTO, CONV_DIRECT, CONV_WINOGRAD, CONV_WINOGRAD_F4 = 0, 1, 2, 3
+CONV_AUTO, CONV_DIRECT, CONV_WINOGRAD, CONV_WINOGRAD_F4, CONV_WINOGRAD_F4S = 0, 1, 2, 3, 4
 DTYPE_F32, DTYPE_F64, DTYPE_F16 = 0, 1, 2  # EDVR_DTYPE_*
 DCN_HALO_TAPWIN = 16  # EDVR_DCN_HALO_TAPWIN
 

@@ -51,6 +51,11 @@ bool winograd_f4_eligible(const edvr_conv2d_desc &d);
 int winograd_f4_launch(const edvr_conv2d_desc &d, hipStream_t stream);
 double winograd_f4_executed_flops(const edvr_conv2d_desc &d);
 
+// winograd_f4s.hip: the same algorithm with split fp32 operands on the f16 matrix pipe; needs wpk_f4s and x_amax
+bool winograd_f4s_eligible(const edvr_conv2d_desc &d);
+int winograd_f4s_launch(const edvr_conv2d_desc &d, hipStream_t stream);
+double winograd_f4s_executed_flops(const edvr_conv2d_desc &d);
+
 // conv_small.hip: 3x3 / stride-1 conv with <= 4 output channels on the vector ALUs (EDVR's conv_last)
 bool conv_small_eligible(const edvr_conv2d_desc &d);
 int conv_small_launch(const edvr_conv2d_desc &d, hipStream_t stream);

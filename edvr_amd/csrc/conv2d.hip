@@ -372,11 +372,12 @@ int conv2d_launch(const edvr_conv2d_desc &d, hipStream_t stream) {
     set_error("conv2d: gate together with a sigmoid epilogue is not supported");
     return EDVR_ERR_UNSUPPORTED;
   }
-  if (d.abs_sum && (conv_small_eligible(d) || !winograd_f4_eligible(d) || d.out_mode != EDVR_OUT_NCHW)) {
+  if (d.abs_sum && (conv_small_eligible(d) || !(winograd_f4_eligible(d) || winograd_f4s_eligible(d)) || d.out_mode != EDVR_OUT_NCHW)) {
     set_error("conv2d: abs_sum is an epilogue of the F(4x4) Winograd kernel's NCHW store only (ask edvr_conv2d_abs_sum_supported)");
     return EDVR_ERR_UNSUPPORTED;
   }
   if (!d.gate && !scaled && conv_small_eligible(d)) return conv_small_launch(d, stream);
+  if (winograd_f4s_eligible(d)) return winograd_f4s_launch(d, stream);
   if (winograd_f4_eligible(d)) return winograd_f4_launch(d, stream);
   if (winograd_eligible(d)) {
     const float *U = d.wpk + direct_packed_elems(d.co, a.ci, 3);
@@ -419,6 +420,10 @@ int edvr_conv2d_kernel_name(const edvr_conv2d_desc *d, char *buf, size_t buf_len
     snprintf(buf, buf_len, "conv3x3_smallco_kernel");
     return EDVR_OK;
   }
+  if (edvr::winograd_f4s_eligible(*d)) {
+    snprintf(buf, buf_len, "conv3x3_winograd_f4s_kernel");
+    return EDVR_OK;
+  }
   if (edvr::winograd_f4_eligible(*d)) {
     snprintf(buf, buf_len, "conv3x3_winograd_f4_kernel");
     return EDVR_OK;
@@ -441,7 +446,8 @@ int edvr_conv2d_executed_flops(const edvr_conv2d_desc *d, double *flops) {
   EDVR_REQUIRE(d && flops, "executed_flops: bad arguments");
   const int pad = d->ks / 2;
   const double ho = (d->h + 2 * pad - d->ks) / d->stride + 1, wo = (d->w + 2 * pad - d->ks) / d->stride + 1;
-  if (!edvr::conv_small_eligible(*d) && edvr::winograd_f4_eligible(*d)) *flops = edvr::winograd_f4_executed_flops(*d);
+  if (!edvr::conv_small_eligible(*d) && edvr::winograd_f4s_eligible(*d)) *flops = edvr::winograd_f4s_executed_flops(*d);
+  else if (!edvr::conv_small_eligible(*d) && edvr::winograd_f4_eligible(*d)) *flops = edvr::winograd_f4_executed_flops(*d);
   else if (!edvr::conv_small_eligible(*d) && edvr::winograd_eligible(*d)) *flops = edvr::winograd_executed_flops(*d);
   else *flops = 2.0 * d->n * ho * wo * d->co * (d->c1 + d->c2) * d->ks * d->ks;  // direct algorithm (tile padding not counted)
   return EDVR_OK;
@@ -449,7 +455,7 @@ int edvr_conv2d_executed_flops(const edvr_conv2d_desc *d, double *flops) {
 
 int edvr_conv2d_abs_sum_supported(const edvr_conv2d_desc *d) {
   if (!d) return 0;
-  return (!edvr::conv_small_eligible(*d) && edvr::winograd_f4_eligible(*d) && d->out_mode == EDVR_OUT_NCHW) ? 1 : 0;  // (the PixelShuffle store has no such sum)
+  return (!edvr::conv_small_eligible(*d) && (edvr::winograd_f4_eligible(*d) || edvr::winograd_f4s_eligible(*d)) && d->out_mode == EDVR_OUT_NCHW) ? 1 : 0;  // (the PixelShuffle store has no such sum)
 }
 
 int edvr_conv2d_gate_supported(const edvr_conv2d_desc *d) {

@@ -508,7 +508,7 @@ bool winograd_eligible(const edvr_conv2d_desc &d) {
   if (d.algo == EDVR_CONV_DIRECT) return false;
   if (d.y_scale != 0.f && d.y_scale != 1.f && !d.res1 && !d.gate) return false;  // the scale lives in the residual / gate epilogues
   const bool applicable = d.ks == 3 && d.stride == 1;  // any channel count: the loop runs over ci rounded up to 16
-  if (d.algo == EDVR_CONV_WINOGRAD || d.algo == EDVR_CONV_WINOGRAD_F4) return applicable;  // explicit request: any size the kernel can do
+  if (d.algo == EDVR_CONV_WINOGRAD || d.algo == EDVR_CONV_WINOGRAD_F4 || d.algo == EDVR_CONV_WINOGRAD_F4S) return applicable;  // explicit request: any size the kernel can do
   return enabled && applicable && d.co >= 48 && d.c1 + d.c2 >= 32 && d.w > 16 && d.h >= 4;  // auto: only where it beats the direct kernel
 }
 

@@ -665,7 +665,7 @@ bool winograd_f4_supported(const edvr_conv2d_desc &d) {
 
 bool winograd_f4_eligible(const edvr_conv2d_desc &d) {
   if (!winograd_f4_supported(d)) return false;
-  if (d.algo == EDVR_CONV_WINOGRAD_F4) return true;  // explicit request: any size the kernel can do
+  if (d.algo == EDVR_CONV_WINOGRAD_F4 || d.algo == EDVR_CONV_WINOGRAD_F4S) return true;  // explicit request (F4S falls back here): any size the kernel can do
   if (d.algo != EDVR_CONV_AUTO || !winograd_f4_enabled()) return false;
   return d.co >= 48 && d.c1 + d.c2 >= 32 && d.w >= 32 && d.h >= 8;  // auto: only where it beats F(2x2)
 }

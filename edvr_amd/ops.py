@@ -11,7 +11,7 @@ import weakref
 import torch
 
 from . import _lib
-from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, CONV_AUTO, CONV_DIRECT, CONV_WINOGRAD, CONV_WINOGRAD_F4, OUT_NCHW,  # noqa: F401
+from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, CONV_AUTO, CONV_DIRECT, CONV_WINOGRAD, CONV_WINOGRAD_F4, CONV_WINOGRAD_F4S, OUT_NCHW,  # noqa: F401
                    OUT_PIXEL_SHUFFLE2)
 
 
@@ -91,11 +91,12 @@ def workspace(nbytes, device):
 _PACKED = {}  # id(parameter) -> (weakref, {transpose_flip: (version, packed, data_ptr)})
 
 
-def pack_conv_weight(weight, transpose_flip=False, f4=False):
+def pack_conv_weight(weight, transpose_flip=False, f4=False, f4s=False):
     """(co, ci, k, k) parameter -> MFMA-friendly [ci_pad][k*k][co_pad] array, cached per parameter version.
-    f4: the F(4x4,3x3) Winograd weights of a 3x3 kernel instead (conv2d's `wpk_f4`), a separate buffer with its own cache slot."""
+    f4: the F(4x4,3x3) Winograd weights of a 3x3 kernel instead (conv2d's `wpk_f4`), a separate buffer with its own cache slot.
+    f4s: the same weights for the split-operand kernel (conv2d's `wpk_f4s`: scaled, split into f16 (hi, lo) pairs; int32 buffer)."""
     require_gpu(weight)
-    key, wid, ver = (bool(transpose_flip), bool(f4)), id(weight), weight._version
+    key, wid, ver = (bool(transpose_flip), 2 if f4s else bool(f4)), id(weight), weight._version
     ent = _PACKED.get(wid)
     if ent is not None and ent[0]() is weight:
         hit = ent[1].get(key)
@@ -111,7 +112,12 @@ def pack_conv_weight(weight, transpose_flip=False, f4=False):
     o, i, k, k2 = w.shape
     assert k == k2, 'square kernels only'
     co, ci = (i, o) if transpose_flip else (o, i)
-    if f4:
+    if f4s:
+        assert k == 3, 'F(4x4,3x3) weights are for 3x3 kernels'
+        out = torch.empty(L.edvr_conv2d_packed_weight_f4s_elems(co, ci), dtype=torch.int32, device=w.device)
+        _lib.check(L.edvr_conv2d_pack_weight_f4s_f32(_ptr(w), _ptr(out), co, ci, 1 if transpose_flip else 0, _stream()),
+                   'edvr_conv2d_pack_weight_f4s_f32')
+    elif f4:
         assert k == 3, 'F(4x4,3x3) weights are for 3x3 kernels'
         out = torch.empty(L.edvr_conv2d_packed_weight_f4_elems(co, ci), dtype=torch.float32, device=w.device)
         _lib.check(L.edvr_conv2d_pack_weight_f4_f32(_ptr(w), _ptr(out), co, ci, 1 if transpose_flip else 0, _stream()),
@@ -263,8 +269,22 @@ def set_f4(inference=None, training=None):
     return prev
 
 
+def amax(x, out=None):
+    """max |x| of a (n, c, h, w) tensor (plane-contiguous images) as a 1-element device tensor: conv2d's `x_amax`.  `out`: an
+    existing bound to fold this tensor into (max of both)."""
+    require_gpu(x)
+    x = _as_planes(x)
+    n, c, h, w = x.shape
+    if out is None:
+        out = torch.zeros(1, dtype=torch.float32, device=x.device)
+    _run('amax', lambda: _lib.check(_lib.lib().edvr_amax_f32(_ptr(x), _ptr(out), n, c * h * w, _img_stride(x), _stream()), 'edvr_amax_f32'),
+         0, _nb(x))
+    return out
+
+
 def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NONE, act_from=0, res1=None, res2=None,
-           out_mode=OUT_NCHW, out=None, algo=None, gate=None, gate_slope=0.0, y_scale=1.0, wpk_f4=None, abs_sum_channels=0):
+           out_mode=OUT_NCHW, out=None, algo=None, gate=None, gate_slope=0.0, y_scale=1.0, wpk_f4=None, abs_sum_channels=0,
+           wpk_f4s=None, x_amax=None):
     """y = y_scale * act(conv(cat(x1, x2)) + bias) + res1 + res2 on the fp32 MFMA kernel.
     algo: CONV_AUTO (default; module-level CONV_ALGO overrides it, used by tests), CONV_DIRECT, CONV_WINOGRAD or CONV_WINOGRAD_F4.
     wpk_f4: pack_conv_weight(w, f4=True) - allows the F(4x4,3x3) Winograd kernel (inference; ~1e-6 relative rounding error).
@@ -321,6 +341,14 @@ def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NON
     if wpk_f4 is not None:
         require_gpu(wpk_f4)
         d.wpk_f4 = _ptr(wpk_f4)
+    if wpk_f4s is not None:  # the split-operand F(4x4) kernel needs a bound of the input's magnitude next to its weights
+        require_gpu(wpk_f4s, dtypes=(torch.int32,))
+        if x_amax is None:
+            x_amax = amax(x1)
+            if x2 is not None:
+                amax(x2, out=x_amax)
+        require_gpu(x_amax)
+        d.wpk_f4s, d.x_amax = _ptr(wpk_f4s), _ptr(x_amax)
     d.algo = CONV_ALGO if algo is None else algo
     sums = None
     if abs_sum_channels > 0 and L.edvr_conv2d_abs_sum_supported(ctypes.byref(d)):

@@ -69,6 +69,8 @@ int edvr_check_device(void);
 #define EDVR_CONV_DIRECT 1
 #define EDVR_CONV_WINOGRAD 2
 #define EDVR_CONV_WINOGRAD_F4 3 /* F(4x4,3x3): needs edvr_conv2d_desc.wpk_f4; falls back like EDVR_CONV_WINOGRAD where it does not apply */
+#define EDVR_CONV_WINOGRAD_F4S 4 /* F(4x4,3x3) with split fp32 operands on the f16 matrix pipe: needs wpk_f4s and x_amax; falls back to
+                                  * EDVR_CONV_WINOGRAD_F4's chain where it does not apply */
 
 #define EDVR_OUT_NCHW 0
 #define EDVR_OUT_PIXEL_SHUFFLE2 1 /* y[n, co/4, 2h+(co%4)/2, 2w+co%2]  (nn.PixelShuffle(2)) */
@@ -127,6 +129,15 @@ typedef struct edvr_conv2d_desc {
                            * edvr_conv2d_abs_sum_supported; EDVR_ERR_UNSUPPORTED otherwise.  The sum is taken over conv + bias (+ the
                            * activation of channels >= act_from), BEFORE gate, y_scale and the residuals are applied. */
   int abs_sum_channels;
+  const void *wpk_f4s;    /* optional: the weights packed by edvr_conv2d_pack_weight_f4s_f32 (csrc/winograd_f4s.hip).  Together with
+                           * `x_amax` it ALLOWS the split-operand F(4x4,3x3) kernel: every fp32 operand travels as two f16 numbers
+                           * (hi + lo, 22 significant bits, after a power-of-two scaling), all four cross products are accumulated in
+                           * fp32 by v_mfma_f32_32x32x16_f16 - the fp32 kernel's arithmetic to within its own rounding level at 1/4 of
+                           * its matrix-pipe time.  EDVR_WINOGRAD_F4S=0 switches it off under EDVR_CONV_AUTO. */
+  const float *x_amax;    /* device pointer to ONE float >= max |x1|, |x2| (any upper bound: edvr_amax_f32, or a statistic the
+                           * producer of x already has).  Read by the split-operand kernel only, to place the transformed input in
+                           * the f16 range; a bound that is too SMALL overflows to infinities, one that is 2^k too large costs
+                           * accuracy only for elements below 2^-18 of it. */
 } edvr_conv2d_desc;
 
 size_t edvr_conv2d_packed_weight_elems(int co, int ci, int ks);
@@ -140,6 +151,15 @@ int edvr_conv2d_pack_weight_f32(const float *w, float *wpk, int co, int ci, int 
  * transpose_flip as in edvr_conv2d_pack_weight_f32 (data-gradient kernel). */
 size_t edvr_conv2d_packed_weight_f4_elems(int co, int ci);
 int edvr_conv2d_pack_weight_f4_f32(const float *w, float *wpk_f4, int co, int ci, int transpose_flip, edvr_stream_t stream);
+/* The same U for the split-operand kernel (EDVR_CONV_WINOGRAD_F4S): a 64-byte header (s_U = the power of two that puts max |w| in
+ * [2^14, 2^15), and 1 / s_U, taken from the weights by a one-workgroup pre-pass on the same stream) followed by one dword
+ * (f16 hi | f16 lo << 16) of U * s_U per element in that kernel's operand order.  edvr_conv2d_packed_weight_f4s_elems(co, ci) dwords,
+ * 16-byte aligned.  Replaces the same cuDNN choice as edvr_conv2d_pack_weight_f4_f32. */
+size_t edvr_conv2d_packed_weight_f4s_elems(int co, int ci);
+int edvr_conv2d_pack_weight_f4s_f32(const float *w, void *wpk_f4s, int co, int ci, int transpose_flip, edvr_stream_t stream);
+/* amax[0] = max(amax[0], max |x|) over n images of per_img contiguous floats, img_stride elements apart (the caller zeroes amax
+ * before the first call; several tensors may be folded into one bound).  Feeds edvr_conv2d_desc.x_amax. */
+int edvr_amax_f32(const float *x, float *amax, int n, int64_t per_img, int64_t img_stride, edvr_stream_t stream);
 /* Many weights in ONE launch (the training path repacks every conv weight after each optimizer step: ~480 tiny launches per
  * iteration otherwise).  `jobs`: DEVICE array of n_jobs records of edvr_pack_job_bytes() = 64 bytes { const float *w; float *wpk;
  * float *wpk_f4; int32 co, ci, ks, transpose_flip; int32 first_block, n_blocks; 16 bytes padding }: wpk / wpk_f4 as the two
