@@ -22,7 +22,7 @@ class ConvDesc(ctypes.Structure):
         ('bias', vp), ('co', i32), ('ks', i32), ('stride', i32), ('act', i32), ('act_from', i32), ('res1', vp),
         ('res2', vp), ('res1_img_stride', i64), ('res2_img_stride', i64), ('y', vp), ('y_img_stride', i64),
         ('out_mode', i32), ('algo', i32), ('gate', vp), ('gate_img_stride', i64), ('gate_slope', f32), ('y_scale', f32),
-        ('wpk_f4', vp), ('abs_sum', vp), ('abs_sum_channels', i32), ('wpk_f4s', vp), ('x_amax', vp),
+        ('wpk_f4', vp), ('abs_sum', vp), ('abs_sum_channels', i32), ('wpk_f4s', vp), ('x_amax', vp), ('y_amax', vp),
     ]
 
 
@@ -39,10 +39,11 @@ PROTOTYPES = {
     'edvr_conv2d_pack_weight_f4s_f32': (i32, [vp, vp, i32, i32, i32, vp]),
     'edvr_amax_f32': (i32, [vp, vp, i32, i64, i64, vp]),
     'edvr_pack_job_bytes': (sz, []),
-    'edvr_conv2d_pack_weights_multi': (i32, [vp, i32, i32, vp]),
+    'edvr_conv2d_pack_weights_multi': (i32, [vp, i32, i32, i32, vp]),
     'edvr_conv2d_f32': (i32, [ctypes.POINTER(ConvDesc), vp]),
     'edvr_conv2d_gate_supported': (i32, [ctypes.POINTER(ConvDesc)]),
     'edvr_conv2d_abs_sum_supported': (i32, [ctypes.POINTER(ConvDesc)]),
+    'edvr_conv2d_y_amax_supported': (i32, [ctypes.POINTER(ConvDesc)]),
     'edvr_conv2d_kernel_name': (i32, [ctypes.POINTER(ConvDesc), ctypes.c_char_p, sz]),
     'edvr_conv2d_executed_flops': (i32, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ctypes.c_double)]),
     'edvr_dcnv2_fwd_ws_bytes': (sz, [i32] * 12),

@@ -21,7 +21,9 @@ class ConvFn(Function):
         wpk = ops.pack_conv_weight(weight)
         y = ops.conv2d(x, wpk, bias.detach() if bias is not None else None, weight.shape[0], ks, x2=x2, x2_map=x2_map, stride=stride,
                        act=act, act_from=act_from, res1=res1, res2=res2, out_mode=out_mode, y_scale=y_scale,
-                       wpk_f4=ops.f4_weight(weight, ks) if stride == 1 else None)
+                       **(ops.f4_kwargs(weight, ks) if stride == 1 else {}))
+        if ops.F4S_TRAINING and ops.get_bound(y) is None:  # (kernels without the y_amax epilogue: bound from the weights' norms)
+            ops.linear_bound(y, weight, bias, (x, x2), (res1, res2), scale=y_scale, floor=1.0 if act == ops.ACT_SIGMOID else 0.0)
         if y_scale != 1.0 and act != ACT_NONE:
             raise NotImplementedError('y_scale together with a fused activation has no backward (not used by EDVR)')
         keep_y = act != ACT_NONE
@@ -59,11 +61,13 @@ class ConvFn(Function):
             z = ops.zero_stuff2(dz, x.shape[2], x.shape[3]) if stride == 2 else dz
             wt = ops.pack_conv_weight(weight, transpose_flip=True)
             dcat = ops.conv2d(z, wt, None, weight.shape[1], ks, y_scale=y_scale,  # data gradient = stride-1 conv with flipped W^T
-                              wpk_f4=ops.f4_weight(weight, ks, transpose_flip=True))
+                              **ops.f4_kwargs(weight, ks, transpose_flip=True))
+            if ops.F4S_TRAINING and ops.get_bound(dcat) is None:
+                ops.linear_bound(dcat, weight, None, (z,), transpose=True, scale=y_scale)
             if need[0]:
-                dx = dcat[:, :c1] if x2 is not None else dcat
+                dx = ops.carry_bound(dcat[:, :c1], dcat) if x2 is not None else dcat
             if x2 is not None and need[1]:
-                d2 = dcat[:, c1:]
+                d2 = ops.carry_bound(dcat[:, c1:], dcat)
                 if x2_map is not None:
                     div, mul, add = x2_map
                     assert div == mul, 'image map must address one frame per clip'
@@ -83,9 +87,9 @@ class ResBlockFn(Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, res_scale=1.0):
         c = w1.shape[0]
-        h = ops.conv2d(x, ops.pack_conv_weight(w1), b1.detach() if b1 is not None else None, c, 3, act=ACT_RELU, wpk_f4=ops.f4_weight(w1, 3))
+        h = ops.conv2d(x, ops.pack_conv_weight(w1), b1.detach() if b1 is not None else None, c, 3, act=ACT_RELU, **ops.f4_kwargs(w1, 3))
         y = ops.conv2d(h, ops.pack_conv_weight(w2), b2.detach() if b2 is not None else None, c, 3, res1=x, y_scale=res_scale,
-                       wpk_f4=ops.f4_weight(w2, 3))
+                       **ops.f4_kwargs(w2, 3))
         ctx.save_for_backward(x, h, w1, w2)
         ctx.has_bias = (b1 is not None, b2 is not None)
         ctx.res_scale = float(res_scale)
@@ -107,12 +111,12 @@ class ResBlockFn(Function):
                 db2.mul_(s)
         # d(pre-activation of conv1) = s * (W2^T * dy) gated by relu'(z1) = [h > 0]
         dz1 = ops.conv2d(dy, ops.pack_conv_weight(w2, transpose_flip=True), None, c, 3, gate=h, gate_slope=0.0, y_scale=s,
-                         wpk_f4=ops.f4_weight(w2, 3, transpose_flip=True))
+                         **ops.f4_kwargs(w2, 3, transpose_flip=True))
         if need[1] or (need[2] and ctx.has_bias[0]):
             dw1, db1 = ops.conv2d_wgrad(x, None, None, dz1, c, 3, 1, want_db=True)
         if need[0]:
             dx = ops.conv2d(dz1, ops.pack_conv_weight(w1, transpose_flip=True), None, c, 3, res1=dy,  # + identity branch
-                            wpk_f4=ops.f4_weight(w1, 3, transpose_flip=True))
+                            **ops.f4_kwargs(w1, 3, transpose_flip=True))
         return (dx, dw1 if need[1] else None, db1 if (need[2] and ctx.has_bias[0]) else None, dw2 if need[3] else None,
                 db2 if (need[4] and ctx.has_bias[1]) else None, None)
 
@@ -135,6 +139,8 @@ class DcnFromPackedFn(Function):
         split = 2 * om.shape[1] // 3
         out = ops.dcnv2_forward(x, om[:, :split], om[:, split:], weight, bias, stride, padding, dilation, groups, dg, act=act,
                                 halo_hint=hint)
+        if ops.F4S_TRAINING:  # (masks are sigmoid outputs, bilinear taps convex combinations of x and the zero padding)
+            ops.linear_bound(out, weight, bias, (x,))
         ctx.save_for_backward(x, om, weight, out if act != ACT_NONE else None)
         ctx.cfg = cfg
         ctx.with_bias = bias is not None

@@ -376,6 +376,10 @@ int conv2d_launch(const edvr_conv2d_desc &d, hipStream_t stream) {
     set_error("conv2d: abs_sum is an epilogue of the F(4x4) Winograd kernel's NCHW store only (ask edvr_conv2d_abs_sum_supported)");
     return EDVR_ERR_UNSUPPORTED;
   }
+  if (d.y_amax && (conv_small_eligible(d) || !winograd_f4s_eligible(d))) {
+    set_error("conv2d: y_amax is an epilogue of the split-operand F(4x4) Winograd kernel only (ask edvr_conv2d_y_amax_supported)");
+    return EDVR_ERR_UNSUPPORTED;
+  }
   if (!d.gate && !scaled && conv_small_eligible(d)) return conv_small_launch(d, stream);
   if (winograd_f4s_eligible(d)) return winograd_f4s_launch(d, stream);
   if (winograd_f4_eligible(d)) return winograd_f4_launch(d, stream);
@@ -456,6 +460,11 @@ int edvr_conv2d_executed_flops(const edvr_conv2d_desc *d, double *flops) {
 int edvr_conv2d_abs_sum_supported(const edvr_conv2d_desc *d) {
   if (!d) return 0;
   return (!edvr::conv_small_eligible(*d) && (edvr::winograd_f4_eligible(*d) || edvr::winograd_f4s_eligible(*d)) && d->out_mode == EDVR_OUT_NCHW) ? 1 : 0;  // (the PixelShuffle store has no such sum)
+}
+
+int edvr_conv2d_y_amax_supported(const edvr_conv2d_desc *d) {
+  if (!d) return 0;
+  return (!edvr::conv_small_eligible(*d) && edvr::winograd_f4s_eligible(*d)) ? 1 : 0;
 }
 
 int edvr_conv2d_gate_supported(const edvr_conv2d_desc *d) {

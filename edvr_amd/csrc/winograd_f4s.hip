@@ -37,7 +37,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float max_raw_s(float a, float b) {  // v_max_f32 without fmaxf()'s canonicalising pre-pass
   float o;
@@ -45,13 +44,6 @@ __device__ __forceinline__ float max_raw_s(float a, float b) {  // v_max_f32 wit
   return o;
 }
 
-// x * s = hi + lo in f16 (s a power of two): v_fma_mixlo_f16 + v_fma_mixhi_f16 - the residual x s - hi is exact in the fma
-__device__ __forceinline__ unsigned split_f16x2(float x, float s) {
-  const float xs = x * s;
-  const _Float16 hi = (_Float16)xs;
-  const _Float16 lo = (_Float16)(xs - (float)hi);
-  return __builtin_bit_cast(unsigned, f16x2{hi, lo});
-}
 // the same for six values at once, the six independent v_fma_mixlo_f16 before the six v_fma_mixhi_f16 that depend on them (left to
 // itself hipcc issues every pair back to back: a lone wave then waits out the dependent latency 36 times per patch)
 __device__ __forceinline__ void split6_f16x2(const float (&x)[6], float s, unsigned (&o)[6]) {
@@ -292,6 +284,8 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
       if (lane == 0 && asum_img >= 0 && s != 0.f) atomicAdd(d.abs_sum + asum_img, s);
       asum = 0.f;
     };
+    float amx = 0.f;  // y_amax epilogue: max |y| of everything this thread stores (rows below the image included: still a bound)
+    auto amax4 = [&](const f32x4 &v) { amx = fmaxf(fmaxf(fmaxf(amx, fabsf(v[0])), fmaxf(fabsf(v[1]), fabsf(v[2]))), fabsf(v[3])); };
     for (int item = item_first; item < item_end; item += xcd_wgs) {
       int e_co_blk, e_img, e_ty0, e_tx0;
       decode(item, e_co_blk, e_img, e_ty0, e_tx0);
@@ -385,6 +379,10 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
           }
           if (SHF) {
             prefetch(min(p + 1, 7));
+            if (d.y_amax) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) amax4(Y[i]);
+            }
             if ((p & 1) == 0) {
 #pragma unroll
               for (int i = 0; i < 4; ++i) Yprev[i] = Y[i];
@@ -415,6 +413,10 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
                 for (int jj = 0; jj < 4; ++jj) Y[i][jj] = __builtin_fmaf(Y[i][jj], a.ys, rr[i][jj]);
             }
             prefetch(min(p + 1, 7));
+            if (d.y_amax) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) amax4(Y[i]);
+            }
             if (co < d.co) {
               float *q = y + (int64_t)co * plane + pix;
 #pragma unroll
@@ -433,6 +435,7 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
                   if (d.abs_sum && co < d.abs_sum_channels) asum += fabsf(o);
                   if (gt) o *= gt[off + jj] > 0.f ? a.ys : a.ys_gs;
                   else if (r1) o = __builtin_fmaf(o, a.ys, r1[off + jj] + (r2 ? r2[off + jj] : 0.f));
+                  amx = fmaxf(amx, fabsf(o));
                   if (shuffle)
                     y[(int64_t)(co >> 2) * plane * 4 + (2 * (oy + i) + ((co >> 1) & 1)) * (2 * d.w) + 2 * (ox + jj) + (co & 1)] = o;
                   else
@@ -451,6 +454,11 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
       else column_pass(std::false_type{}, std::false_type{});
     }
     if (d.abs_sum) asum_flush();
+    if (d.y_amax) {
+#pragma unroll
+      for (int sh = 32; sh > 0; sh >>= 1) amx = fmaxf(amx, __shfl_xor(amx, sh));
+      if (lane == 0 && amx > 0.f) atomicMax(reinterpret_cast<unsigned *>(d.y_amax), __builtin_bit_cast(unsigned, amx));  // non-negative floats order as integers
+    }
     F4S_TRACE_FLUSH();
   } else {
     // =========================================================================================== multiplying waves
@@ -559,72 +567,44 @@ __global__ __launch_bounds__(1024) void winograd_f4s_weight_scale_kernel(const f
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
-    const int be = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 255u);
-    const int field = min(max(127 + 14 - (be - 127), 7), 200);  // m = f 2^k, f in [1, 2): m s_U = f 2^14
-    U[0] = (unsigned)field << 23;
-    U[1] = (unsigned)(254 - field) << 23;
+    const unsigned field = f4s_weight_scale_field(__builtin_bit_cast(unsigned, m));
+    U[0] = field << 23;
+    U[1] = (254u - field) << 23;
     for (int i = 2; i < 16; ++i) U[i] = 0u;
-  }
-}
-
-// element i = c * cop + o of [cip][cop]: U = G g G^T of the 3x3 kernel, scaled, split, in the operand order above
-__device__ __forceinline__ void pack_f4s_elem(const float *__restrict__ w, unsigned *__restrict__ U, int64_t i, int co, int ci, int cop, int cip,
-                                              int transpose_flip) {
-  const int o = (int)(i % cop), c = (int)(i / cop);
-  const float s_u = __builtin_bit_cast(float, U[0]);
-  float g[9];
-#pragma unroll
-  for (int t = 0; t < 9; ++t) g[t] = pack_src(w, co, ci, 9, o, c, t, transpose_flip);
-  auto G6 = [](float g0, float g1, float g2, float *o6) {  // rows of G: (1/4,0,0), (-1/6,-1/6,-1/6), (-1/6,1/6,-1/6), (1/24,1/12,1/6), (1/24,-1/12,1/6), (0,0,1)
-    const float e = (g0 + g2) * (-1.f / 6.f), f = g1 * (-1.f / 6.f);
-    const float p = g0 * (1.f / 24.f) + g2 * (1.f / 6.f), q2 = g1 * (1.f / 12.f);
-    o6[0] = g0 * 0.25f;
-    o6[1] = e + f;
-    o6[2] = e - f;
-    o6[3] = p + q2;
-    o6[4] = p - q2;
-    o6[5] = g2;
-  };
-  float tmp[6][3];  // G g
-#pragma unroll
-  for (int jx = 0; jx < 3; ++jx) {
-    float col[6];
-    G6(g[0 * 3 + jx], g[1 * 3 + jx], g[2 * 3 + jx], col);
-#pragma unroll
-    for (int r = 0; r < 6; ++r) tmp[r][jx] = col[r];
-  }
-  const int64_t blk0 = (((int64_t)(o >> 6) * (cip >> 3) + (c >> 3)) * 6) * 2 + ((o >> 5) & 1);  // + 2 r -> (co block, chunk, row r, co half)
-  const int ln = ((c >> 2) & 1) * 32 + (o & 31);
-#pragma unroll
-  for (int r = 0; r < 6; ++r) {  // (G g) G^T
-    float u[6];
-    G6(tmp[r][0], tmp[r][1], tmp[r][2], u);
-    unsigned *blk = U + 16 + (blk0 + 2 * r) * (6 * 256) + ln * 4 + (c & 3);
-#pragma unroll
-    for (int cc = 0; cc < 6; ++cc) blk[cc * 256] = split_f16x2(u[cc], s_u);
   }
 }
 
 __global__ void winograd_f4s_weight_kernel(const float *__restrict__ w, unsigned *__restrict__ U, int co, int ci, int cop, int cip, int transpose_flip) {
   const int64_t total = (int64_t)cip * cop;
+  const float s_u = __builtin_bit_cast(float, U[0]);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
-    pack_f4s_elem(w, U, i, co, ci, cop, cip, transpose_flip);
+    pack_f4s_elem(w, U, i, co, ci, cop, cip, transpose_flip, s_u);
 }
 
-// out[0] = max(out[0], max |x|) over n images of `per_img` contiguous elements (bit pattern compare: non-negative floats order as integers)
+// out[0] = max(out[0], max |x|) over n images of `per_img` contiguous elements (bit pattern compare: non-negative floats order as
+// integers).  16-byte loads, four in flight per thread; contiguous batches are folded into one long image by the launcher.
 __global__ __launch_bounds__(256) void amax_kernel(const float *__restrict__ x, unsigned *__restrict__ out, int n, int64_t per_img, int64_t img_stride) {
   float m = 0.f;
   const int64_t quads = per_img >> 2;
+  const int64_t step = (int64_t)gridDim.x * 256;
   for (int img = blockIdx.y; img < n; img += gridDim.y) {
     const float *p = x + (int64_t)img * img_stride;
     if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
-      for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < quads; i += (int64_t)gridDim.x * 256) {
-        const f32x4 v = reinterpret_cast<const f32x4 *>(p)[i];
+      const f32x4 *q = reinterpret_cast<const f32x4 *>(p);
+      int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+      for (; i + 3 * step < quads; i += 4 * step) {
+        const f32x4 a = q[i], b = q[i + step], c = q[i + 2 * step], e = q[i + 3 * step];
+        const f32x4 ab = {fmaxf(fabsf(a[0]), fabsf(b[0])), fmaxf(fabsf(a[1]), fabsf(b[1])), fmaxf(fabsf(a[2]), fabsf(b[2])), fmaxf(fabsf(a[3]), fabsf(b[3]))};
+        const f32x4 ce = {fmaxf(fabsf(c[0]), fabsf(e[0])), fmaxf(fabsf(c[1]), fabsf(e[1])), fmaxf(fabsf(c[2]), fabsf(e[2])), fmaxf(fabsf(c[3]), fabsf(e[3]))};
+        m = fmaxf(m, fmaxf(fmaxf(fmaxf(ab[0], ce[0]), fmaxf(ab[1], ce[1])), fmaxf(fmaxf(ab[2], ce[2]), fmaxf(ab[3], ce[3]))));
+      }
+      for (; i < quads; i += step) {
+        const f32x4 v = q[i];
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
       }
-      for (int64_t i = quads * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_img; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(p[i]));
+      for (int64_t t = quads * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; t < per_img; t += step) m = fmaxf(m, fabsf(p[t]));
     } else {
-      for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_img; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(p[i]));
+      for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < per_img; t += step) m = fmaxf(m, fabsf(p[t]));
     }
   }
 #pragma unroll
@@ -730,7 +710,11 @@ int edvr_conv2d_pack_weight_f4s_f32(const float *w, void *wpk_f4s, int co, int c
 
 int edvr_amax_f32(const float *x, float *amax, int n, int64_t per_img, int64_t img_stride, edvr_stream_t stream) {
   EDVR_REQUIRE(x && amax && n > 0 && per_img > 0, "amax: bad arguments");
-  const int bx = (int)std::min<int64_t>(edvr::cdiv64(per_img, 256 * 16), 1024);
+  if (img_stride == per_img || n == 1) {  // one long array
+    per_img *= n;
+    n = 1;
+  }
+  const int bx = (int)std::min<int64_t>(edvr::cdiv64(per_img, 256 * 16), 2048);
   const int by = std::min(n, std::max(1, 2048 / bx));
   hipLaunchKernelGGL(edvr::amax_kernel, dim3(bx, by), dim3(256), 0, edvr::as_stream(stream), x, reinterpret_cast<unsigned *>(amax), n, per_img,
                      img_stride);

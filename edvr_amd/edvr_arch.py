@@ -113,9 +113,11 @@ class TSAFusion(nn.Module):
 
     def forward(self, aligned_feat):
         b, t, c, h, w = aligned_feat.shape
-        emb_ref = F_.conv(self.temporal_attn1, aligned_feat[:, self.center_frame_idx])  # strided view, no clone
-        emb = F_.conv(self.temporal_attn2, aligned_feat.reshape(b * t, c, h, w)).view(b, t, -1, h, w)
-        mod = F_.tsa_temporal(emb, emb_ref, aligned_feat).view(b, t * c, h, w)
+        alias = F_.ops.carry_bound  # (a view of a tensor inherits its magnitude bound: the split-operand convs read it, ops.input_bound)
+        emb_ref = F_.conv(self.temporal_attn1, alias(aligned_feat[:, self.center_frame_idx], aligned_feat))  # strided view, no clone
+        emb = F_.conv(self.temporal_attn2, alias(aligned_feat.reshape(b * t, c, h, w), aligned_feat)).view(b, t, -1, h, w)
+        mod = F_.tsa_temporal(emb, emb_ref, aligned_feat)
+        mod = alias(mod.view(b, t * c, h, w), mod)
 
         feat = F_.conv(self.feat_fusion, mod, act=LRELU)
         attn = F_.conv(self.spatial_attn1, mod, act=LRELU)
@@ -241,6 +243,8 @@ class EDVR(nn.Module):
                 self._conv_meta = [(m.stride[0] == 1, m is not first) for m in convs]
             F_.ops.prepack_conv_weights(self._conv_weights, self._conv_meta)
         frames = x.view(b * t, c, h, w)
+        if F_.ops.F4S_INFERENCE or F_.ops.F4S_TRAINING:
+            F_.ops.input_bound(frames)  # max |input| (one pass over 3-channel frames): the first link of the chain of magnitude bounds
         if self.with_predeblur:
             f1 = F_.conv(self.conv_1x1, self.predeblur(frames))
             if self.hr_in:
@@ -261,11 +265,11 @@ class EDVR(nn.Module):
         finally:
             for m in dcns:
                 m.stats_sink = None
-        aligned = aligned.view(b, t, -1, h, w)
+        aligned = F_.ops.carry_bound(aligned.view(b, t, -1, h, w), aligned)
         taps = self.taps
         if taps is not None:
             taps['aligned'] = aligned
-        feat = self.fusion(aligned) if self.with_tsa else F_.conv(self.fusion, aligned.view(b, -1, h, w))
+        feat = self.fusion(aligned) if self.with_tsa else F_.conv(self.fusion, F_.ops.carry_bound(aligned.view(b, -1, h, w), aligned))
         if taps is not None:
             taps['fused'] = feat
         out = self.reconstruction(feat)

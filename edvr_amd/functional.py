@@ -43,11 +43,21 @@ def conv(m, x, *, x2=None, x2_map=None, act=ACT_NONE, act_from=0, res1=None, res
     # the F(4x4,3x3) Winograd weights let the C side pick that kernel where it is the fastest (2.25 instead of 4 multiplies per
     # output, rounding ~1e-6 of the output scale instead of ~2e-7; EDVR_WINOGRAD_F4=0 switches it off here,
     # EDVR_WINOGRAD_F4_TRAIN=0 in the training path above)
-    wf4 = ops.pack_conv_weight(m.weight, f4=True) if (ops.F4_INFERENCE and ks == 3 and stride == 1 and m.in_channels >= 32
-                                                      and m.out_channels >= 48) else None
+    f4 = ops.F4_INFERENCE and ks == 3 and stride == 1 and m.in_channels >= 32 and m.out_channels >= 48
+    # ... and the split-operand form of the same algorithm (csrc/winograd_f4s.hip: fp32 operands as f16 (hi, lo) pairs on the f16
+    # matrix pipe, all four cross products, fp32 accumulation - the fp32 kernel's accuracy at 1.3-1.5x its speed; the bound of the
+    # input's magnitude it needs travels with the tensors, ops.set_bound / input_bound); EDVR_WINOGRAD_F4S=0 keeps the fp32 kernel
+    f4s = f4 and ops.F4S_INFERENCE and x.shape[3] % 4 == 0
+    wf4 = ops.pack_conv_weight(m.weight, f4=True) if (f4 and not f4s) else None
+    wf4s = ops.pack_conv_weight(m.weight, f4s=True) if f4s else None
     bias = m.bias.detach() if m.bias is not None else None
-    return ops.conv2d(x, wpk, bias, m.out_channels, ks, x2=x2, x2_map=x2_map, stride=stride, act=act, act_from=act_from,
-                      res1=res1, res2=res2, out_mode=out_mode, y_scale=y_scale, wpk_f4=wf4, abs_sum_channels=abs_sum_channels)
+    r = ops.conv2d(x, wpk, bias, m.out_channels, ks, x2=x2, x2_map=x2_map, stride=stride, act=act, act_from=act_from,
+                   res1=res1, res2=res2, out_mode=out_mode, y_scale=y_scale, wpk_f4=wf4, abs_sum_channels=abs_sum_channels,
+                   wpk_f4s=wf4s)
+    y = r[0] if abs_sum_channels > 0 else r
+    if ops.F4S_INFERENCE and ops.get_bound(y) is None:  # a kernel without the y_amax epilogue: the bound from the weights' norms
+        ops.linear_bound(y, m.weight, m.bias, (x, x2), (res1, res2), scale=y_scale, floor=1.0 if act == ACT_SIGMOID else 0.0)
+    return r
 
 
 def offset_mask_conv_stats(conv_offset, feat):
@@ -124,7 +134,10 @@ def dcn_from_packed(m, x, om, act=ACT_NONE):
         return ag.DcnFromPackedFn.apply(x, om, m.weight, m.bias, (*cfg, act, hint, m))
     split = 2 * om.shape[1] // 3
     bias = m.bias.detach() if m.bias is not None else None
-    return ops.dcnv2_forward(x, om[:, :split], om[:, split:], m.weight.detach(), bias, *cfg, act=act, halo_hint=hint)
+    y = ops.dcnv2_forward(x, om[:, :split], om[:, split:], m.weight.detach(), bias, *cfg, act=act, halo_hint=hint)
+    if ops.F4S_INFERENCE:  # (masks are sigmoid outputs, bilinear taps convex combinations of x and the zero padding)
+        ops.linear_bound(y, m.weight, m.bias, (x,))
+    return y
 
 
 def upsample2x(x, scale=1.0):

@@ -130,6 +130,7 @@ def pack_conv_weight(weight, transpose_flip=False, f4=False, f4s=False):
     return out
 
 
+_PACK_CALLS = 0   # edvr_conv2d_pack_weights_multi's split_parity counter
 _PACK_TABLES = {}  # job signature -> (device table, total blocks): the table of a training iteration never changes
 
 
@@ -189,42 +190,56 @@ def prepack_conv_weights(weights, meta=None):
         for flip in ((False, True) if dgrad else (False,)):
             co, ci = (w.shape[1], w.shape[0]) if flip else (w.shape[0], w.shape[1])
             want_f4 = F4_TRAINING and k == 3 and ci >= 32 and co >= 48 and (flip or fwd_f4)  # = f4_weight()
+            # which layouts: the direct one always; of the two F(4x4) layouts the one the training convs will ask for (f4_kwargs)
+            kinds = [False] + ([2 if F4S_TRAINING else True] if want_f4 else [])
             outs = []
-            for f4 in ((False, True) if want_f4 else (False,)):
+            for f4 in kinds:
                 hit = ent[1].get((flip, f4))
                 if hit is not None and hit[0] == ver and hit[2] == w.data_ptr():
                     outs.append(None)  # current
                     continue
-                n = L.edvr_conv2d_packed_weight_f4_elems(co, ci) if f4 else L.edvr_conv2d_packed_weight_elems(co, ci, k)
-                buf = hit[1] if (hit is not None and hit[1].numel() == n and hit[1].device == w.device and _sole_owner(hit)) else \
-                    torch.empty(n, dtype=torch.float32, device=w.device)
+                if f4 == 2:
+                    n, dt = L.edvr_conv2d_packed_weight_f4s_elems(co, ci), torch.int32
+                else:
+                    n, dt = (L.edvr_conv2d_packed_weight_f4_elems(co, ci) if f4 else L.edvr_conv2d_packed_weight_elems(co, ci, k)), torch.float32
+                if hit is not None and hit[1].numel() == n and hit[1].dtype == dt and hit[1].device == w.device and _sole_owner(hit):
+                    buf = hit[1]
+                else:
+                    buf = torch.empty(n, dtype=dt, device=w.device)
+                    if f4 == 2:
+                        buf[:16].zero_()  # the header's max |w| slots start at zero (edvr_conv2d_pack_weights_multi)
                 outs.append(buf)
                 filled.append((ent, (flip, f4), ver, buf, w.data_ptr()))
             wpk = outs[0]
-            wf4 = outs[1] if want_f4 else None
-            if wpk is None and wf4 is None:
+            wf4 = outs[1] if (want_f4 and not F4S_TRAINING) else None
+            wf4s = outs[1] if (want_f4 and F4S_TRAINING) else None
+            if wpk is None and wf4 is None and wf4s is None:
                 continue
-            work = max((wpk.numel() if wpk is not None else 0), (wf4.numel() // 36 if wf4 is not None else 0))
+            wq = wf4 if wf4 is not None else wf4s
+            work = max((wpk.numel() if wpk is not None else 0), (wq.numel() // 36 if wq is not None else 0))
             jobs.append((w.data_ptr(), wpk.data_ptr() if wpk is not None else 0, wf4.data_ptr() if wf4 is not None else 0, co, ci, k,
-                         int(flip), max(1, min(64, (work + 255) // 256))))
+                         int(flip), max(1, min(64, (work + 255) // 256)), wf4s.data_ptr() if wf4s is not None else 0))
     if not jobs:
         return 0
     key = tuple(jobs)  # (device pointers inside: unique per device)
     tab = _PACK_TABLES.get(key)
     if tab is None:
         rec = np.zeros(len(jobs), dtype=np.dtype([('w', '<u8'), ('wpk', '<u8'), ('f4', '<u8'), ('co', '<i4'), ('ci', '<i4'), ('ks', '<i4'),
-                                                  ('flip', '<i4'), ('first', '<i4'), ('nb', '<i4'), ('pad', '<i4', (4,))]))
+                                                  ('flip', '<i4'), ('first', '<i4'), ('nb', '<i4'), ('f4s', '<u8'), ('pad', '<i4', (2,))]))
         assert rec.dtype.itemsize == L.edvr_pack_job_bytes()
         first = 0
-        for i, (pw, pk, pf, co, ci, k, flip, nb) in enumerate(jobs):
-            rec[i] = (pw, pk, pf, co, ci, k, flip, first, nb, (0, 0, 0, 0))
+        for i, (pw, pk, pf, co, ci, k, flip, nb, ps) in enumerate(jobs):
+            rec[i] = (pw, pk, pf, co, ci, k, flip, first, nb, ps, (0, 0))
             first += nb
         dev = filled[0][3].device
         tab = (torch.from_numpy(rec.view(np.uint8).copy()).to(dev), first)
         if len(_PACK_TABLES) > 8:
             _PACK_TABLES.clear()
         _PACK_TABLES[key] = tab
-    _lib.check(L.edvr_conv2d_pack_weights_multi(_ptr(tab[0]), len(jobs), tab[1], _stream()), 'edvr_conv2d_pack_weights_multi')
+    global _PACK_CALLS
+    _PACK_CALLS += 1
+    parity = _PACK_CALLS if any(j[8] for j in jobs) else -1
+    _lib.check(L.edvr_conv2d_pack_weights_multi(_ptr(tab[0]), len(jobs), tab[1], parity, _stream()), 'edvr_conv2d_pack_weights_multi')
     for ent, k2, ver, buf, ptr in filled:
         ent[1][k2] = (ver, buf, ptr)
     return len(jobs)
@@ -236,6 +251,19 @@ def f4_weight(weight, ks, transpose_flip=False):
         return None
     co, ci = (weight.shape[1], weight.shape[0]) if transpose_flip else (weight.shape[0], weight.shape[1])
     return pack_conv_weight(weight, transpose_flip=transpose_flip, f4=True) if (ci >= 32 and co >= 48) else None
+
+
+def f4_kwargs(weight, ks, transpose_flip=False):
+    """The F(4x4) weights a training-path conv2d() call should get: {'wpk_f4s': ...} (split-operand kernel), {'wpk_f4': ...} (fp32
+    kernel) or {} when the F(4x4) path is off / the layer too small."""
+    if not F4_TRAINING or ks != 3:
+        return {}
+    co, ci = (weight.shape[1], weight.shape[0]) if transpose_flip else (weight.shape[0], weight.shape[1])
+    if not (ci >= 32 and co >= 48):
+        return {}
+    if F4S_TRAINING:
+        return {'wpk_f4s': pack_conv_weight(weight, transpose_flip=transpose_flip, f4s=True)}
+    return {'wpk_f4': pack_conv_weight(weight, transpose_flip=transpose_flip, f4=True)}
 
 
 def invalidate_packed_weights():
@@ -251,6 +279,8 @@ DCN_HALO_TAPWIN = _lib.DCN_HALO_TAPWIN  # halo_hint of dcnv2_forward: per-tap sh
 LAUNCH_HOOK = None  # callable(kernel_name, algorithmic_flops, launch_fn, algorithmic_bytes) or None
 CONV_ALGO = CONV_AUTO  # default algorithm request of conv2d(); tests flip it to cover both kernels on every shape
 F4_INFERENCE = os.environ.get('EDVR_WINOGRAD_F4', '1') != '0'  # functional.conv hands the F(4x4,3x3) weights to no-grad convs
+F4S_INFERENCE = os.environ.get('EDVR_WINOGRAD_F4S', '1') != '0'  # functional.conv hands the split-operand F(4x4) weights (csrc/winograd_f4s.hip) to no-grad convs
+F4S_TRAINING = os.environ.get('EDVR_WINOGRAD_F4S_TRAIN', os.environ.get('EDVR_WINOGRAD_F4S', '1')) != '0'  # ... and to the forward / data-gradient convs of autograd.py
 F4_TRAINING = os.environ.get('EDVR_WINOGRAD_F4_TRAIN', '1') != '0'  # autograd.py: forward and data-gradient convs too (-11 % per iteration;
 #                                                                   the gradient parity tests hold at their 1e-5 bounds)
 
@@ -269,6 +299,130 @@ def set_f4(inference=None, training=None):
     return prev
 
 
+def set_f4s(inference=None, training=None):
+    """Switch the SPLIT-OPERAND form of the F(4x4,3x3) kernel (csrc/winograd_f4s.hip) on / off at run time for the no-grad path and
+    for the training path; with it off the fp32 F(4x4) kernel runs (set_f4).  Returns the previous pair.  EDVR_WINOGRAD_F4S /
+    EDVR_WINOGRAD_F4S_TRAIN give the initial values."""
+    global F4S_INFERENCE, F4S_TRAINING
+    prev = (F4S_INFERENCE, F4S_TRAINING)
+    if inference is not None:
+        F4S_INFERENCE = bool(inference)
+    if training is not None:
+        F4S_TRAINING = bool(training)
+    return prev
+
+
+class _AmaxArena:
+    """One-element device slots for the `y_amax` epilogue of the split-operand conv kernel: zeroed in blocks of 2048, each slot
+    handed out once (a slot captured by a hipGraph keeps accumulating maxima over replays: still a bound)."""
+
+    def __init__(self):
+        self.buf, self.i = None, 0
+
+    def slot(self, device):
+        if self.buf is None or self.i >= self.buf.numel() or self.buf.device != device:
+            self.buf, self.i = torch.zeros(2048, dtype=torch.float32, device=device), 0
+        self.i += 1
+        return self.buf[self.i - 1:self.i]
+
+
+_AMAX_ARENA = _AmaxArena()
+BOUND_CHECK = os.environ.get('EDVR_BOUND_CHECK', '0') == '1'  # verify every x_amax against the data (tests / debugging)
+BOUND_CHECK_LOG = []  # (shape, bound / true maximum) of every checked conv input
+AMAX_LOG = None  # a list: every reduction pass of input_bound() is recorded there (shape, calling functions)
+AMAX_PASSES = 0  # how often input_bound() had to run the reduction kernel (measurement: bench.py reports it per forward)
+
+
+def set_bound(t, bound, depth=0):
+    """Remember `bound` (1-element device tensor >= max |t|) on the tensor object; valid while t is not written again.
+    depth: 0 = measured (the split-operand kernel's y_amax epilogue, the reduction kernel), 1 = derived from a measured one through the
+    weights' norms (linear_bound) - typically 10-50x the true maximum, which the split costs nothing (it has 2^18 of slack); a SECOND
+    derivation on top would multiply the looseness (1e10 after a few layers), so it is refused and the consumer measures instead."""
+    t._edvr_amax = (bound, t._version, depth)
+
+
+def get_bound(t):
+    b = getattr(t, '_edvr_amax', None)
+    return b[0] if (b is not None and b[1] == t._version and b[0].device == t.device) else None
+
+
+def _bound_depth(t):
+    return t._edvr_amax[2]
+
+
+def carry_bound(dst, *srcs, scale=1.0):
+    """max |dst| <= scale * (sum of the sources' bounds) by construction of the op that made it (a gate, a convex combination, a
+    permutation, a sum): hand the bound on without looking at the data.  Nothing happens when a source has none."""
+    bs = [get_bound(t) for t in srcs]
+    if not bs or any(b is None for b in bs):
+        return dst
+    b = bs[0]
+    for o in bs[1:]:
+        b = b + o
+    set_bound(dst, b if scale == 1.0 else b * float(scale), max(_bound_depth(t) for t in srcs))
+    return dst
+
+
+_W_L1 = {}  # id(weight) -> (weakref, {transpose: (version, pointer, l1max)})
+
+
+def weight_l1max(weight, transpose=False):
+    """max over output channels of sum |w| (1-element device tensor), cached per parameter version: |conv(x, w)| <= that * max|x|.
+    transpose: of the data-gradient kernel (sums over the output-channel axis of w)."""
+    wid, ver = id(weight), weight._version
+    ent = _W_L1.get(wid)
+    if ent is None or ent[0]() is not weight:
+        ent = (weakref.ref(weight, lambda _r, wid=wid: _W_L1.pop(wid, None)), {})
+        _W_L1[wid] = ent
+    hit = ent[1].get(bool(transpose))
+    if hit is not None and hit[0] == ver and hit[1] == weight.data_ptr():
+        return hit[2]
+    w = weight.detach().abs()
+    l1 = w.sum(dim=(0, 2, 3) if transpose else (1, 2, 3)).max().reshape(1)
+    ent[1][bool(transpose)] = (ver, weight.data_ptr(), l1)
+    return l1
+
+
+def linear_bound(y, weight, bias, xs, extra=(), transpose=False, scale=1.0, floor=0.0):
+    """Bound of y = scale * act(conv / deformable conv of xs with `weight` + bias) + extra tensors, for kernels without the y_amax
+    epilogue: |y| <= |scale| (max_co sum|w| * max|x| + max|b|) + sum of the extras' bounds (1-Lipschitz activations through 0;
+    `floor` = 1 for a sigmoid epilogue; deformable sampling and masks in [0, 1] are convex combinations of the input).  A few
+    1-element torch ops; nothing happens when an input has no bound."""
+    srcs = [t for t in xs if t is not None] + [t for t in extra if t is not None]
+    bs = [get_bound(t) for t in srcs]
+    if any(b is None for b in bs) or any(_bound_depth(t) > 0 for t in xs if t is not None):
+        return y
+    nx = sum(1 for t in xs if t is not None)
+    bx = bs[0]
+    for o in bs[1:nx]:
+        bx = torch.maximum(bx, o)
+    b = weight_l1max(weight, transpose) * bx
+    if bias is not None:
+        b = b + bias.detach().abs().max()
+    if scale != 1.0:
+        b = b * abs(float(scale))
+    if floor:
+        b = b.clamp_min(float(floor))
+    for o in bs[nx:]:
+        b = b + o
+    set_bound(y, b, 1)
+    return y
+
+
+def input_bound(t_in, t_planes=None):
+    """max |t| as a 1-element device tensor: the bound its producer left on it (set_bound), else one pass of the reduction kernel."""
+    global AMAX_PASSES
+    b = get_bound(t_in)
+    if b is None:
+        AMAX_PASSES += 1
+        if AMAX_LOG is not None:  # measurement: who consumes a tensor whose producer left no bound
+            import traceback
+            AMAX_LOG.append((tuple(t_in.shape), [f.name for f in traceback.extract_stack()[-7:-2]]))
+        b = amax(t_in if t_planes is None else t_planes)
+        set_bound(t_in, b)
+    return b
+
+
 def amax(x, out=None):
     """max |x| of a (n, c, h, w) tensor (plane-contiguous images) as a 1-element device tensor: conv2d's `x_amax`.  `out`: an
     existing bound to fold this tensor into (max of both)."""
@@ -284,7 +438,7 @@ def amax(x, out=None):
 
 def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NONE, act_from=0, res1=None, res2=None,
            out_mode=OUT_NCHW, out=None, algo=None, gate=None, gate_slope=0.0, y_scale=1.0, wpk_f4=None, abs_sum_channels=0,
-           wpk_f4s=None, x_amax=None):
+           wpk_f4s=None, x_amax=None, want_y_amax=True):
     """y = y_scale * act(conv(cat(x1, x2)) + bias) + res1 + res2 on the fp32 MFMA kernel.
     algo: CONV_AUTO (default; module-level CONV_ALGO overrides it, used by tests), CONV_DIRECT, CONV_WINOGRAD or CONV_WINOGRAD_F4.
     wpk_f4: pack_conv_weight(w, f4=True) - allows the F(4x4,3x3) Winograd kernel (inference; ~1e-6 relative rounding error).
@@ -299,6 +453,7 @@ def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NON
     """
     require_gpu(x1, x2, wpk, bias, res1, res2)
     L = _lib.lib()
+    x1_in, x2_in, y_bound = x1, x2, None
     x1 = _as_planes(x1)
     n, c1, h, w = x1.shape
     d = _lib.ConvDesc()
@@ -341,15 +496,30 @@ def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NON
     if wpk_f4 is not None:
         require_gpu(wpk_f4)
         d.wpk_f4 = _ptr(wpk_f4)
-    if wpk_f4s is not None:  # the split-operand F(4x4) kernel needs a bound of the input's magnitude next to its weights
-        require_gpu(wpk_f4s, dtypes=(torch.int32,))
-        if x_amax is None:
-            x_amax = amax(x1)
-            if x2 is not None:
-                amax(x2, out=x_amax)
-        require_gpu(x_amax)
-        d.wpk_f4s, d.x_amax = _ptr(wpk_f4s), _ptr(x_amax)
     d.algo = CONV_ALGO if algo is None else algo
+    split = False
+    if wpk_f4s is not None:  # the split-operand F(4x4) kernel: its weights + a bound of the input's magnitude
+        require_gpu(wpk_f4s, dtypes=(torch.int32,))
+        d.wpk_f4s = _ptr(wpk_f4s)
+        d.x_amax = _ptr(wpk_f4s)  # (any non-null pointer: only asks whether the launch would run on that kernel)
+        split = bool(L.edvr_conv2d_y_amax_supported(ctypes.byref(d)))
+        if split:
+            if x_amax is None:
+                x_amax = input_bound(x1_in, x1)
+                if x2 is not None:
+                    x_amax = torch.maximum(x_amax, input_bound(x2_in, x2))
+            require_gpu(x_amax)
+            if BOUND_CHECK:  # debugging / tests: every bound that reaches the kernel is compared with the data (synchronises)
+                true = amax(x1).item() if x2 is None else max(amax(x1).item(), amax(x2).item())
+                if not (x_amax.item() >= true):
+                    raise AssertionError(f'magnitude bound {x_amax.item():.6g} < max |x| = {true:.6g} for a conv input of shape {tuple(x1.shape)}')
+                BOUND_CHECK_LOG.append((tuple(x1.shape), x_amax.item() / max(true, 1e-30)))
+            d.x_amax = _ptr(x_amax)
+            if want_y_amax:
+                y_bound = _AMAX_ARENA.slot(x1.device)
+                d.y_amax = _ptr(y_bound)
+        else:
+            d.wpk_f4s, d.x_amax = None, None
     sums = None
     if abs_sum_channels > 0 and L.edvr_conv2d_abs_sum_supported(ctypes.byref(d)):
         sums = torch.zeros(2, n, dtype=torch.float32, device=x1.device)
@@ -367,6 +537,10 @@ def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NON
         nbytes = 4.0 * (n * (c1 + d.c2) * h * w + n * co * ho * wo * (1 + (res1 is not None) + (res2 is not None) + (gate is not None))
                         + co * (c1 + d.c2) * ks * ks)
     _run(name, lambda: _lib.check(L.edvr_conv2d_f32(ctypes.byref(d), _stream()), 'edvr_conv2d_f32'), flops, nbytes, executed)
+    if y_bound is not None:
+        set_bound(out, y_bound)
+    elif hasattr(out, '_edvr_amax'):
+        del out._edvr_amax  # a caller-provided buffer rewritten by a kernel without the epilogue: its old bound is void
     if abs_sum_channels > 0:
         if sums is None:
             return out, abs_stats_per_image(out[:, :abs_sum_channels])
@@ -546,41 +720,47 @@ def tsa_temporal(emb, emb_ref, aligned, want_prob=False):
     """emb/aligned (b, t, c, h, w), emb_ref (b, c, h, w) -> aligned * sigmoid(<emb_t, emb_ref>) and optionally prob."""
     require_gpu(emb, emb_ref, aligned)
     b, t, c, h, w = aligned.shape
+    al_in = aligned
     emb, emb_ref, aligned = emb.contiguous(), emb_ref.contiguous(), aligned.contiguous()
     out = torch.empty_like(aligned)
     prob = torch.empty(b, t, h, w, dtype=torch.float32, device=aligned.device) if want_prob else None
     _run('tsa_temporal', lambda: _lib.check(_lib.lib().edvr_tsa_temporal_f32(_ptr(emb), _ptr(emb_ref), _ptr(aligned), _ptr(out), _ptr(prob), b, t, c, h * w,
                                                 _stream()),
                                        'edvr_tsa_temporal_f32'), 0, _nb(emb, emb_ref, aligned, out, prob))
+    carry_bound(out, al_in)  # aligned * sigmoid(.)
     return (out, prob) if want_prob else out
 
 
 def pool_maxavg(x):
     require_gpu(x)
-    x = x.contiguous()
+    x_in, x = x, x.contiguous()
     n, c, h, w = x.shape
     y = torch.empty(n, 2 * c, (h - 1) // 2 + 1, (w - 1) // 2 + 1, dtype=torch.float32, device=x.device)
     _run('pool_maxavg_3x3s2', lambda: _lib.check(_lib.lib().edvr_pool_maxavg_3x3s2_f32(_ptr(x), _ptr(y), n, c, h, w, _stream()),
                                        'edvr_pool_maxavg_3x3s2_f32'), 0, _nb(x, y))
-    return y
+    return carry_bound(y, x_in)
 
 
 def upsample2x(x, scale=1.0):
     require_gpu(x)
-    x = x.contiguous()
+    x_in, x = x, x.contiguous()
     n, c, h, w = x.shape
     y = torch.empty(n, c, 2 * h, 2 * w, dtype=torch.float32, device=x.device)
     _run('upsample2x', lambda: _lib.check(_lib.lib().edvr_upsample2x_f32(_ptr(x), _ptr(y), n * c, h, w, float(scale), _stream()),
                                        'edvr_upsample2x_f32'), 0, _nb(x, y))
-    return y
+    return carry_bound(y, x_in, scale=abs(scale))  # bilinear weights sum to one
 
 
 def tsa_combine(feat, attn, attn_add):
     require_gpu(feat, attn, attn_add)
+    f_in, a_in = feat, attn_add
     feat, attn, attn_add = feat.contiguous(), attn.contiguous(), attn_add.contiguous()
     y = torch.empty_like(feat)
     _run('tsa_combine', lambda: _lib.check(_lib.lib().edvr_tsa_combine_f32(_ptr(feat), _ptr(attn), _ptr(attn_add), _ptr(y), feat.numel(), _stream()),
                                        'edvr_tsa_combine_f32'), 0, _nb(feat, attn, attn_add, y))
+    bf, ba = get_bound(f_in), get_bound(a_in)
+    if bf is not None and ba is not None:
+        set_bound(y, bf * 2.0 + ba, max(_bound_depth(f_in), _bound_depth(a_in)))  # feat * sigmoid(attn) * 2 + attn_add
     return y
 
 
@@ -597,17 +777,19 @@ def upsample4x_add_(y, base):
 
 def add(a, b):
     require_gpu(a, b)
+    a_in, b_in = a, b
     a, b = a.contiguous(), b.contiguous()
     assert a.shape == b.shape
     y = torch.empty_like(a)
     _run('add', lambda: _lib.check(_lib.lib().edvr_add_f32(_ptr(a), _ptr(b), _ptr(y), a.numel(), _stream()),
                                        'edvr_add_f32'), 0, _nb(a, b, y))
-    return y
+    return carry_bound(y, a_in, b_in)
 
 
 def act_backward(dy, y, act, act_from=0, res1=None, res2=None):
     """dz = dy * act'(.) computed from the activation output; y = act(z) + res1 + res2 as the fused conv wrote it."""
     require_gpu(dy, y, res1, res2)
+    dy_in = dy
     dy, y = dy.contiguous(), y.contiguous()
     res1 = res1.contiguous() if res1 is not None else None
     res2 = res2.contiguous() if res2 is not None else None
@@ -616,7 +798,7 @@ def act_backward(dy, y, act, act_from=0, res1=None, res2=None):
     _run('act_bwd', lambda: _lib.check(_lib.lib().edvr_act_bwd_f32(_ptr(dy), _ptr(y), _ptr(res1), _ptr(res2), _ptr(dz), n, c, y[0, 0].numel(), act, act_from,
                                            _stream()),
                                        'edvr_act_bwd_f32'), 0, _nb(dy, y, res1, res2, dz))
-    return dz
+    return carry_bound(dz, dy_in)  # |act'| <= 1 for every epilogue activation
 
 
 def set_wgrad_algo(algo):
@@ -672,18 +854,18 @@ def channel_sum(x):
 
 def pixel_unshuffle2(x):
     require_gpu(x)
-    x = x.contiguous()
+    x_in, x = x, x.contiguous()
     n, c, h2, w2 = x.shape
     y = torch.empty(n, 4 * c, h2 // 2, w2 // 2, dtype=torch.float32, device=x.device)
     _run('pixel_unshuffle2', lambda: _lib.check(_lib.lib().edvr_pixel_unshuffle2_f32(_ptr(x), _ptr(y), n, c, h2 // 2, w2 // 2, _stream()),
                                        'edvr_pixel_unshuffle2_f32'), 0, _nb(x, y))
-    return y
+    return carry_bound(y, x_in)
 
 
 def pixel_unshuffle2_act_backward(dy, y, act):
     """unshuffle(dy * act'(y)): the gradient of PixelShuffle(2)(act(z)) w.r.t. z in one launch (y = the shuffled activation output)."""
     require_gpu(dy)
-    dy = dy.contiguous()
+    dy_in, dy = dy, dy.contiguous()
     n, c, h2, w2 = dy.shape
     if act != ACT_NONE:
         require_gpu(y)
@@ -694,17 +876,17 @@ def pixel_unshuffle2_act_backward(dy, y, act):
     _run('pixel_unshuffle2_act_bwd', lambda: _lib.check(_lib.lib().edvr_pixel_unshuffle2_act_bwd_f32(
         _ptr(dy), _ptr(y) if act != ACT_NONE else None, _ptr(dz), n, c, h2 // 2, w2 // 2, int(act), _stream()), 'edvr_pixel_unshuffle2_act_bwd_f32'),
         0, _nb(dy, dz) + (_nb(y) if act != ACT_NONE else 0.0))
-    return dz
+    return carry_bound(dz, dy_in)
 
 
 def zero_stuff2(dz, H, W):
     require_gpu(dz)
-    dz = dz.contiguous()
+    dz_in, dz = dz, dz.contiguous()
     n, c, ho, wo = dz.shape
     z = torch.empty(n, c, H, W, dtype=torch.float32, device=dz.device)
     _run('zero_stuff2', lambda: _lib.check(_lib.lib().edvr_zero_stuff2_f32(_ptr(dz), _ptr(z), n * c, H, W, ho, wo, _stream()),
                                        'edvr_zero_stuff2_f32'), 0, _nb(dz, z))
-    return z
+    return carry_bound(z, dz_in)
 
 
 def frame_reduce_add_(src, dst, t, center):
@@ -719,22 +901,23 @@ def frame_reduce_add_(src, dst, t, center):
 
 def upsample2x_backward(dy, scale=1.0):
     require_gpu(dy)
-    dy = dy.contiguous()
+    dy_in, dy = dy, dy.contiguous()
     n, c, h2, w2 = dy.shape
     dx = torch.empty(n, c, h2 // 2, w2 // 2, dtype=torch.float32, device=dy.device)
     _run('upsample2x_bwd', lambda: _lib.check(_lib.lib().edvr_upsample2x_bwd_f32(_ptr(dy), _ptr(dx), n * c, h2 // 2, w2 // 2, float(scale), _stream()),
                                        'edvr_upsample2x_bwd_f32'), 0, _nb(dy, dx))
-    return dx
+    return carry_bound(dx, dy_in, scale=4.0 * abs(scale))  # adjoint of the interpolation: the weights into one coarse pixel sum to 4
 
 
 def pool_maxavg_backward(x, dy):
     require_gpu(x, dy)
+    dy_in = dy
     x, dy = x.contiguous(), dy.contiguous()
     n, c, h, w = x.shape
     dx = torch.empty_like(x)
     _run('pool_maxavg_3x3s2_bwd', lambda: _lib.check(_lib.lib().edvr_pool_maxavg_3x3s2_bwd_f32(_ptr(x), _ptr(dy), _ptr(dx), n, c, h, w, _stream()),
                                        'edvr_pool_maxavg_3x3s2_bwd_f32'), 0, _nb(x, dy, dx))
-    return dx
+    return carry_bound(dx, dy_in, scale=8.0)  # a pixel sits in at most 4 windows of each of the two pooled halves
 
 
 def tsa_temporal_backward(emb, emb_ref, aligned, dout):

@@ -138,6 +138,9 @@ typedef struct edvr_conv2d_desc {
                            * producer of x already has).  Read by the split-operand kernel only, to place the transformed input in
                            * the f16 range; a bound that is too SMALL overflows to infinities, one that is 2^k too large costs
                            * accuracy only for elements below 2^-18 of it. */
+  float *y_amax;          /* optional, split-operand kernel only (EDVR_ERR_UNSUPPORTED elsewhere: ask edvr_conv2d_y_amax_supported): y_amax[0] =
+                           * max(y_amax[0], max |y|) over everything the launch stores (residuals / gate applied), with one atomic per
+                           * wave at the end - the `x_amax` of the next conv of a chain for free.  The caller zeroes it (or folds bounds). */
 } edvr_conv2d_desc;
 
 size_t edvr_conv2d_packed_weight_elems(int co, int ci, int ks);
@@ -162,18 +165,22 @@ int edvr_conv2d_pack_weight_f4s_f32(const float *w, void *wpk_f4s, int co, int c
 int edvr_amax_f32(const float *x, float *amax, int n, int64_t per_img, int64_t img_stride, edvr_stream_t stream);
 /* Many weights in ONE launch (the training path repacks every conv weight after each optimizer step: ~480 tiny launches per
  * iteration otherwise).  `jobs`: DEVICE array of n_jobs records of edvr_pack_job_bytes() = 64 bytes { const float *w; float *wpk;
- * float *wpk_f4; int32 co, ci, ks, transpose_flip; int32 first_block, n_blocks; 16 bytes padding }: wpk / wpk_f4 as the two
- * functions above fill them (either may be NULL), transpose_flip as above; job j owns the workgroups [first_block, first_block +
+ * float *wpk_f4; int32 co, ci, ks, transpose_flip; int32 first_block, n_blocks; void *wpk_f4s; 8 bytes padding }: wpk / wpk_f4 /
+ * wpk_f4s as the three functions above fill them (any may be NULL; the 16 header dwords of a wpk_f4s buffer must be zero before
+ * its FIRST use here), transpose_flip as above; job j owns the workgroups [first_block, first_block +
  * n_blocks) of the launch (ascending, contiguous from 0; any n_blocks >= 1 - 256 elements per workgroup and pass), total_blocks =
- * their sum.  Results are bit-identical to the per-tensor functions. */
+ * their sum.  Results are bit-identical to the per-tensor functions.  split_parity: -1 when no job has a wpk_f4s; else a counter the
+ * caller increments per call (its low bit selects which header slot collects max |w| this time: one extra launch, no memset). */
 size_t edvr_pack_job_bytes(void);
-int edvr_conv2d_pack_weights_multi(const void *jobs, int n_jobs, int total_blocks, edvr_stream_t stream);
+int edvr_conv2d_pack_weights_multi(const void *jobs, int n_jobs, int total_blocks, int split_parity, edvr_stream_t stream);
 int edvr_conv2d_f32(const edvr_conv2d_desc *d, edvr_stream_t stream);
 /* 1 if `d` with a `gate` (and no residuals) would run in a Winograd kernel's fused epilogue (that kernel applies under d->algo,
  * the sizes and the EDVR_CONV_WINOGRAD environment switch), else 0 (edvr_conv2d_f32 still accepts the gate on the direct
  * kernel - correct, slower).  Callers that fuse an activation backward into a data-gradient conv ask first and keep the
  * two-launch form otherwise.  Pointers of `d` need not be set. */
 int edvr_conv2d_gate_supported(const edvr_conv2d_desc *d);
+/* 1 if edvr_conv2d_f32 would run `d` on the split-operand kernel, whose epilogue takes `y_amax`, else 0. */
+int edvr_conv2d_y_amax_supported(const edvr_conv2d_desc *d);
 /* 1 if edvr_conv2d_f32 would run `d` on a kernel whose epilogue takes `abs_sum` (the F(4x4) Winograd kernel), else 0. */
 int edvr_conv2d_abs_sum_supported(const edvr_conv2d_desc *d);
 /* Name of the kernel template instantiation edvr_conv2d_f32 would launch for `d` (as rocprofv3 prints it),

@@ -34,6 +34,15 @@ PATCHES = {
                  '          asm volatile("v_mov_b32 %0, %4\\n\\tv_mov_b32 %1, %4\\n\\tv_mov_b32 %2, %4\\n\\tv_mov_b32 %3, %4\\n\\t; %5 %6 %7 %8"')],
     # staging waves: no split / no V writes (transform kept alive)
     'novw': [('      unsigned pk[6];\n      split6_f16x2(t, s_v, pk);\n#pragma unroll\n      for (int c = 0; c < 6; ++c) dst[c * 32] = pk[c];', '      asm volatile("" ::"v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]), "v"(t[4]), "v"(t[5]), "v"(dst));')],
+    # cache-policy experiments: nt on the input DMA / on the output stores / on the weight loads
+    'dmant': [('(lvoid *)(Rw + 1 + i * 256), 16, dma_off[i], 0, 0, 0);', '(lvoid *)(Rw + 1 + i * 256), 16, dma_off[i], 0, 0, 2);')],
+    'stnt': [('                if (i < rows_in) *reinterpret_cast<f32x4 *>(q + i * d.w) = Y[i];', '                if (i < rows_in) __builtin_nontemporal_store(Y[i], reinterpret_cast<f32x4 *>(q + i * d.w));')],
+    'unt': [('__builtin_amdgcn_raw_buffer_load_b128(u_rsrc, voff, soff + c * 1024, 0)', '__builtin_amdgcn_raw_buffer_load_b128(u_rsrc, voff, soff + c * 1024, 2)')],
+    # every XCD works on ONE 64-channel block of the weights (its L2 holds half / a quarter of U); the input is then read by two / four L2s
+    'xcdco': [('  const int span = (a.items + n_xcd - 1) / n_xcd;\n  const int item_end = min(a.items, (xcd + 1) * span);\n  const int item_first = xcd * span + xcd_rank;',
+               '  const bool cbfix = n_xcd == 8 && (co_blocks == 2 || co_blocks == 4 || co_blocks == 8);\n  const int cb_fixed = cbfix ? xcd % co_blocks : -1;\n  const int n_grp = cbfix ? 8 / co_blocks : n_xcd, grp = cbfix ? xcd / co_blocks : xcd;\n  const int v_items = cbfix ? a.items / co_blocks : a.items;\n  const int span = (v_items + n_grp - 1) / n_grp;\n  const int item_end = min(v_items, (grp + 1) * span);\n  const int item_first = grp * span + xcd_rank;'),
+              ('    co_blk = __builtin_amdgcn_readfirstlane((item % co_blocks) * 64);\n    const int tile_blk = __builtin_amdgcn_readfirstlane((item / co_blocks) % (a.tiles_x * a.tiles_y));\n    img = __builtin_amdgcn_readfirstlane(item / (co_blocks * a.tiles_x * a.tiles_y));',
+               '    const int cbd = cb_fixed >= 0 ? 1 : co_blocks;\n    co_blk = __builtin_amdgcn_readfirstlane((cb_fixed >= 0 ? cb_fixed : item % co_blocks) * 64);\n    const int tile_blk = __builtin_amdgcn_readfirstlane((item / cbd) % (a.tiles_x * a.tiles_y));\n    img = __builtin_amdgcn_readfirstlane(item / (cbd * a.tiles_x * a.tiles_y));')],
     'nosplit': [('      split6_f16x2(t, s_v, pk);', '      for (int c = 0; c < 6; ++c) pk[c] = __builtin_bit_cast(unsigned, t[c]);')],
 }
 

@@ -81,16 +81,30 @@ def _kernels_of(fn):
 
 def test_default_paths_run_the_f4_kernel(gpu):
     """No silent fallback: with default settings the 3x3 convs of a no-grad forward AND of a training step (forward + data
-    gradient) run on conv3x3_winograd_f4_kernel where it applies (here: the 32x48 level of EDVR-L / 7 frames)."""
+    gradient) run on the split-operand F(4x4) kernel where it applies (here: the 32x48 level of EDVR-L / 7 frames), on the fp32
+    F(4x4) kernel with that form switched off - and the bound of the input magnitude travels with the tensors: only a few inputs
+    (outputs of kernels without the epilogue) need the reduction pass."""
+    from edvr_amd import ops
     net, x, _ = build('L_T7')
     net = net.to(gpu)
     xg = x.to(gpu)
     with torch.no_grad():
         infer = _kernels_of(lambda: net(xg))
-    assert infer.count('conv3x3_winograd_f4_kernel') >= 10, sorted(set(infer))
-    net.train()
+    n_split = infer.count('conv3x3_winograd_f4s_kernel')
+    assert n_split >= 10 and infer.count('conv3x3_winograd_f4_kernel') == 0, sorted(set(infer))
+    assert infer.count('amax') <= n_split // 2, (infer.count('amax'), n_split)
+    prev = ops.set_f4s(inference=False, training=False)
+    try:
+        with torch.no_grad():
+            infer32 = _kernels_of(lambda: net(xg))
+        assert infer32.count('conv3x3_winograd_f4_kernel') == n_split and 'conv3x3_winograd_f4s_kernel' not in infer32
+        net.train()
+        train32 = _kernels_of(lambda: net(xg).sum().backward())
+        assert train32.count('conv3x3_winograd_f4_kernel') >= 20, sorted(set(train32))  # forward + data gradient
+    finally:
+        ops.set_f4s(*prev)
     train = _kernels_of(lambda: net(xg).sum().backward())
-    assert train.count('conv3x3_winograd_f4_kernel') >= 20, sorted(set(train))  # forward + data gradient
+    assert train.count('conv3x3_winograd_f4s_kernel') == train32.count('conv3x3_winograd_f4_kernel'), sorted(set(train))
 
 
 def test_f4_switch_off(gpu):
@@ -192,3 +206,27 @@ def test_pending_offset_statistics_do_not_live_in_the_module(gpu, caplog):
         assert len([r for r in caplog.records if 'larger than 50' in r.getMessage()]) == x.shape[1]
         cas = net.pcd_align.cas_dcnpack
         assert cas.last_offset_absmean > 50 and cas.last_offset_rough is not None and cas.last_offset_rough < 0.45
+
+
+@pytest.mark.parametrize('cfg', ['M_T5', 'L_T7'])
+def test_magnitude_bounds_reaching_the_split_kernel_are_bounds(gpu, cfg):
+    """Every `x_amax` the split-operand conv kernel is given - measured by a producer's epilogue, derived through a layer's weight
+    norms, carried through a gate / interpolation / pooling - is compared with the data (ops.BOUND_CHECK): never below max |x| (an
+    overflow to infinity otherwise), and never more than 2^12 above it (the f16 pair keeps full accuracy down to 2^-18 of the bound)."""
+    from edvr_amd import ops
+    net, x, _ = build(cfg)
+    net = net.to(gpu)
+    xg = x.to(gpu)
+    ops.BOUND_CHECK, ops.BOUND_CHECK_LOG[:] = True, []
+    try:
+        with torch.no_grad():
+            y = net(xg)
+        n_infer = len(ops.BOUND_CHECK_LOG)
+        net.train()
+        net(xg).sum().backward()
+    finally:
+        ops.BOUND_CHECK = False
+    assert torch.isfinite(y).all()
+    assert n_infer >= 10 and len(ops.BOUND_CHECK_LOG) >= 3 * n_infer
+    worst = max(r for _, r in ops.BOUND_CHECK_LOG)
+    assert worst < 4096.0, sorted(ops.BOUND_CHECK_LOG, key=lambda r: -r[1])[:5]
