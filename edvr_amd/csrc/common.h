@@ -82,6 +82,12 @@ int winograd_wgrad_launch(const float *x1, const float *x2, const float *dz, flo
                           int64_t x1_img_stride, int64_t x2_img_stride, int x2_div, int x2_mul, int x2_add, int64_t dz_img_stride,
                           int splits, int want_db, hipStream_t stream);  // want_db: also [splits][co] partial sums of dz after the dW partials
 
+// winograd_wgrad_s.hip: the same kernel with split fp32 operands on the f16 matrix pipe (needs bounds of both tensors' magnitudes)
+bool winograd_wgrad_split_enabled();
+int winograd_wgrad_split_launch(const float *x1, const float *x2, const float *dz, float *ws, int c1, int c2, int n, int h, int w, int co,
+                                int64_t x1_img_stride, int64_t x2_img_stride, int x2_div, int x2_mul, int x2_add, int64_t dz_img_stride,
+                                int splits, int want_db, const float *x_amax, const float *dz_amax, hipStream_t stream);
+
 // dcn.hip: geometry of one DCN call, shared with dcn_any.hip
 struct DcnShape {
   int B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, Ho, Wo;  // stride / pad / dil: along h

@@ -309,9 +309,10 @@ size_t edvr_conv2d_wgrad_ws_bytes(int n, int ci, int h, int w, int co, int ks, i
   return std::max(std::max(std::max(wino, small), gemm), (size_t)edvr::wgrad_splits(tiles, units) * co * ci * ks * ks * sizeof(float));  // any algorithm
 }
 
-int edvr_conv2d_wgrad_f32(const float *x1, const float *x2, const float *dz, float *dw, int c1, int c2, int n, int h, int w, int co,
-                          int ks, int stride, int64_t x1_img_stride, int64_t x2_img_stride, int x2_div, int x2_mul, int x2_add,
-                          int64_t dz_img_stride, int accumulate, float *dbias, void *ws, size_t ws_bytes, edvr_stream_t stream_) {
+static int wgrad_impl(const float *x1, const float *x2, const float *dz, float *dw, int c1, int c2, int n, int h, int w, int co,
+                      int ks, int stride, int64_t x1_img_stride, int64_t x2_img_stride, int x2_div, int x2_mul, int x2_add,
+                      int64_t dz_img_stride, int accumulate, float *dbias, void *ws, size_t ws_bytes, const float *x_amax, const float *dz_amax,
+                      edvr_stream_t stream_) {
   using namespace edvr;
   EDVR_REQUIRE(x1 && dz && dw && ws, "wgrad: null pointer");
   EDVR_REQUIRE((x2 != nullptr) == (c2 > 0), "wgrad: x2/c2 mismatch");
@@ -361,8 +362,12 @@ int edvr_conv2d_wgrad_f32(const float *x1, const float *x2, const float *dz, flo
   }
   int wsplits = 0;
   if (winograd_wgrad_plan(n, c1, c2, h, w, co, ks, stride, &wsplits) && ws_bytes >= winograd_wgrad_ws_bytes(co, ci, wsplits)) {
-    int rc = winograd_wgrad_launch(x1, x2, dz, a.ws, c1, c2, n, h, w, co, x1_img_stride, x2_img_stride, x2_div, x2_mul, x2_add,
-                                   dz_img_stride, wsplits, dbias != nullptr, stream);
+    // the split-operand form of the same kernel (winograd_wgrad_s.hip) when the caller knows bounds of both tensors' magnitudes
+    int rc = (x_amax && dz_amax && winograd_wgrad_split_enabled())
+                 ? winograd_wgrad_split_launch(x1, x2, dz, a.ws, c1, c2, n, h, w, co, x1_img_stride, x2_img_stride, x2_div, x2_mul, x2_add,
+                                               dz_img_stride, wsplits, dbias != nullptr, x_amax, dz_amax, stream)
+                 : winograd_wgrad_launch(x1, x2, dz, a.ws, c1, c2, n, h, w, co, x1_img_stride, x2_img_stride, x2_div, x2_mul, x2_add,
+                                         dz_img_stride, wsplits, dbias != nullptr, stream);
     if (rc) return rc;
     const int64_t total = (int64_t)co * ci * 9;  // the bias gradient rides on the same two launches (its partials follow dW's)
     return reduce_partials_launch(a.ws, dw, total, wsplits, accumulate, stream, dbias ? a.ws + (int64_t)wsplits * total : nullptr, dbias, co,
@@ -385,6 +390,28 @@ int edvr_conv2d_wgrad_f32(const float *x1, const float *x2, const float *dz, flo
   if (rc || !dbias) return rc;
   // direct kernel: the bias gradient is a separate pass over dz (the workspace is free again)
   return edvr_channel_sum_f32(dz, dbias, n, co, (int64_t)a.ho * a.wo, dz_img_stride, ws, ws_bytes, stream_);
+}
+
+int edvr_conv2d_wgrad_f32(const float *x1, const float *x2, const float *dz, float *dw, int c1, int c2, int n, int h, int w, int co,
+                          int ks, int stride, int64_t x1_img_stride, int64_t x2_img_stride, int x2_div, int x2_mul, int x2_add,
+                          int64_t dz_img_stride, int accumulate, float *dbias, void *ws, size_t ws_bytes, edvr_stream_t stream) {
+  return wgrad_impl(x1, x2, dz, dw, c1, c2, n, h, w, co, ks, stride, x1_img_stride, x2_img_stride, x2_div, x2_mul, x2_add, dz_img_stride,
+                    accumulate, dbias, ws, ws_bytes, nullptr, nullptr, stream);
+}
+
+int edvr_conv2d_wgrad_split_f32(const float *x1, const float *x2, const float *dz, float *dw, int c1, int c2, int n, int h, int w, int co,
+                                int ks, int stride, int64_t x1_img_stride, int64_t x2_img_stride, int x2_div, int x2_mul, int x2_add,
+                                int64_t dz_img_stride, int accumulate, float *dbias, void *ws, size_t ws_bytes, const float *x_amax,
+                                const float *dz_amax, edvr_stream_t stream) {
+  EDVR_REQUIRE(x_amax && dz_amax, "wgrad_split: null magnitude bound");
+  return wgrad_impl(x1, x2, dz, dw, c1, c2, n, h, w, co, ks, stride, x1_img_stride, x2_img_stride, x2_div, x2_mul, x2_add, dz_img_stride,
+                    accumulate, dbias, ws, ws_bytes, x_amax, dz_amax, stream);
+}
+
+int edvr_conv2d_wgrad_split_applies(int n, int c1, int c2, int h, int w, int co, int ks, int stride) {
+  int splits = 0, ssplits = 0;
+  if (edvr::winograd_wgrad_get_algo() == EDVR_CONV_AUTO && edvr::wgrad_small_plan(n, c1, c2, h, w, co, ks, stride, &ssplits)) return 0;
+  return (edvr::winograd_wgrad_split_enabled() && edvr::winograd_wgrad_plan(n, c1, c2, h, w, co, ks, stride, &splits)) ? 1 : 0;
 }
 
 int edvr_conv2d_wgrad_kernel_name(int n, int c1, int c2, int h, int w, int co, int ks, int stride, char *buf, size_t buf_len) {

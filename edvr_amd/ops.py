@@ -815,6 +815,7 @@ def conv2d_wgrad(x1, x2, x2_map, dz, co, ks, stride, want_db=False):
     in the same two launches."""
     require_gpu(x1, x2, dz)
     L = _lib.lib()
+    x1_in, x2_in, dz_in = x1, x2, dz
     x1, dz = _as_planes(x1), _as_planes(dz)
     n, c1, h, w = x1.shape
     c2 = 0
@@ -827,16 +828,27 @@ def conv2d_wgrad(x1, x2, x2_map, dz, co, ks, stride, want_db=False):
     ws = workspace(nbytes, x1.device)
     db = torch.empty(co, dtype=torch.float32, device=x1.device) if want_db else None
     name = 'conv2d_wgrad'
+    # the split-operand form of the Winograd-domain kernel needs bounds of both operands' magnitudes (they travel with the tensors)
+    split = F4S_TRAINING and bool(L.edvr_conv2d_wgrad_split_applies(n, c1, c2, h, w, co, ks, stride))
     if LAUNCH_HOOK is not None:
         buf = ctypes.create_string_buffer(96)
         L.edvr_conv2d_wgrad_kernel_name(n, c1, c2, h, w, co, ks, stride, buf, 96)
         name = buf.value.decode()
+        if split and name == 'conv3x3_winograd_wgrad_kernel':
+            name = 'conv3x3_winograd_wgrad_split_kernel'
     pad = ks // 2
     ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
-    _run(name, lambda: _lib.check(L.edvr_conv2d_wgrad_f32(
-        _ptr(x1), _ptr(x2), _ptr(dz), _ptr(dw), c1, c2, n, h, w, co, ks, stride, _img_stride(x1), _img_stride(x2) if x2 is not None else 0,
-        div, mul, add, _img_stride(dz), 0, _ptr(db), _ptr(ws), nbytes, _stream()), 'edvr_conv2d_wgrad_f32'),
-        2.0 * n * ho * wo * co * (c1 + c2) * ks * ks, _nb(x1, dz, dw) + (4.0 * n * c2 * h * w if x2 is not None else 0.0))
+    common = (_ptr(x1), _ptr(x2), _ptr(dz), _ptr(dw), c1, c2, n, h, w, co, ks, stride, _img_stride(x1), _img_stride(x2) if x2 is not None else 0,
+              div, mul, add, _img_stride(dz), 0, _ptr(db), _ptr(ws), nbytes)
+    if split:
+        bx = input_bound(x1_in, x1)
+        if x2 is not None:
+            bx = torch.maximum(bx, input_bound(x2_in, x2))
+        bz = input_bound(dz_in, dz)
+        launch = lambda: _lib.check(L.edvr_conv2d_wgrad_split_f32(*common, _ptr(bx), _ptr(bz), _stream()), 'edvr_conv2d_wgrad_split_f32')
+    else:
+        launch = lambda: _lib.check(L.edvr_conv2d_wgrad_f32(*common, _stream()), 'edvr_conv2d_wgrad_f32')
+    _run(name, launch, 2.0 * n * ho * wo * co * (c1 + c2) * ks * ks, _nb(x1, dz, dw) + (4.0 * n * c2 * h * w if x2 is not None else 0.0))
     return (dw, db) if want_db else dw
 
 
