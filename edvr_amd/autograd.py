@@ -152,7 +152,7 @@ class DcnFromPackedFn(Function):
         x, om, weight, out = ctx.saved_tensors
         stride, padding, dilation, groups, dg, act, _, module = ctx.cfg
         from .functional import scatter_hint_from_stats
-        scatter = scatter_hint_from_stats(getattr(module, 'last_offset_absmean', None), getattr(module, 'last_offset_rough', None))  # statistics of THIS forward
+        scatter = scatter_hint_from_stats(getattr(module, 'last_offset_absmean', None), getattr(module, 'last_offset_rough', None))  # latest statistics that have ARRIVED (this forward's only under EDVR_DCN_HINT_WAIT=1)
         if act != ACT_NONE:
             dy = ops.act_backward(dy, out, act)
         split = 2 * om.shape[1] // 3

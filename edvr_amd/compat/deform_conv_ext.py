@@ -62,9 +62,16 @@ def _out_view(output, input, weight, offset):
     """The caller's `output` buffer as the (B, Co, Ho, Wo) tensor the kernels write in place (the reference resizes / views it,
     deform_conv_cuda.cpp:530-536); a buffer of another size or layout is replaced like `output.resize_` would."""
     shape = (input.shape[0], weight.shape[0], offset.shape[2], offset.shape[3])
-    if output.numel() != shape[0] * shape[1] * shape[2] * shape[3] or not output.is_contiguous():
+    if output.numel() != shape[0] * shape[1] * shape[2] * shape[3]:
         output.resize_(shape)
+    if not output.is_contiguous():  # a viewable but strided buffer of the right size: compute into a temporary, copy back (_finish_out)
+        return torch.empty(shape, dtype=output.dtype, device=output.device)
     return output.view(shape)
+
+
+def _finish_out(tmp, output):
+    if tmp.data_ptr() != output.data_ptr():
+        output.view_as(tmp).copy_(tmp)
 
 
 def _check(input, weight, kh, kw, group):
@@ -83,8 +90,10 @@ def _check(input, weight, kh, kw, group):
 def modulated_deform_conv_forward(input, weight, bias, ones, offset, mask, output, columns, kernel_h, kernel_w, stride_h, stride_w,
                                   pad_h, pad_w, dilation_h, dilation_w, group, deformable_group, with_bias):
     _check(input, weight, kernel_h, kernel_w, group)
+    out = _out_view(output, input, weight, offset)
     ops.dcnv2_forward(input, offset, mask, weight, bias if with_bias else None, (stride_h, stride_w), (pad_h, pad_w),
-                      (dilation_h, dilation_w), group, deformable_group, out=_out_view(output, input, weight, offset))
+                      (dilation_h, dilation_w), group, deformable_group, out=out)
+    _finish_out(out, output)
     _note_offsets(offset)
 
 
@@ -113,8 +122,10 @@ def modulated_deform_conv_backward(input, weight, bias, ones, offset, mask, colu
 def deform_conv_forward(input, weight, offset, output, columns, ones, kW, kH, dW, dH, padW, padH, dilationW, dilationH, group,
                         deformable_group, im2col_step):
     _check(input, weight, kH, kW, group)
-    ops.dcnv1_forward(input, offset, weight, (dH, dW), (padH, padW), (dilationH, dilationW), group, deformable_group,
-                      out=_out_view(output, input, weight, offset))
+    _DW_MEMO.clear()  # (a d(weight) kept for a backward_parameters call that never came - weights without gradient - is dropped here)
+    out = _out_view(output, input, weight, offset)
+    ops.dcnv1_forward(input, offset, weight, (dH, dW), (padH, padW), (dilationH, dilationW), group, deformable_group, out=out)
+    _finish_out(out, output)
     return 1  # the reference returns 1 on success (deform_conv_cuda.cpp:242)
 
 

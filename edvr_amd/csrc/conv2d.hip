@@ -275,11 +275,7 @@ __global__ __launch_bounds__(256, EDVR_CONV_MINWAVES) void conv2d_mfma_kernel(co
   } else if (r1) {
     EDVR_STORE_LOOP({ y[o] = v + r1[o]; })
   } else {
-#ifdef EDVR_EXP_NOSTORE
-    EDVR_STORE_LOOP({ if (v == 12345.678f) y[o] = v; })  /* ablation only: keeps the accumulators live */
-#else
     EDVR_STORE_LOOP({ y[o] = v; })
-#endif
   }
 #undef EDVR_STORE_LOOP
 }

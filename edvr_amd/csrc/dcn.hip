@@ -419,30 +419,19 @@ __global__ __launch_bounds__(256) void dcn_bwd_coord_tile_kernel(const float *__
             const float v01 = t.w01 * tt, v11 = t.w11 * tt;
             const float l01 = lane_prev_f(v01), l11 = lane_prev_f(v11);
             const float v00 = t.w00 * tt + (mg.take00 ? l01 : 0.f), v10 = t.w10 * tt + (mg.take10 ? l11 : 0.f);
-#ifdef DCNB_EXP_NOLDSATOM
-            if (tt == 12345.f) {  /* ablation only */
-#else
             if (inwin) {
-#endif
               float *wc = w00 + (cc0 + u) * (LH * LWP);
               if (ok00) atomicAdd(wc, v00);  // LDS: ds_add_f32
               if (ok01 && !mg.give01) atomicAdd(wc + 1, v01);
               if (ok10) atomicAdd(wc + LWP, v10);
               if (ok11 && !mg.give11) atomicAdd(wc + LWP + 1, v11);
-#ifdef DCNB_EXP_NOLDSATOM
-            } else if (!inwin) {
-#else
             } else {
-#endif
               float *gq = gp + u * plane;
               if (ok00) unsafeAtomicAdd(gq + t.o00, v00);
               if (ok01 && !mg.give01) unsafeAtomicAdd(gq + t.o01, v01);
               if (ok10) unsafeAtomicAdd(gq + t.o10, v10);
               if (ok11 && !mg.give11) unsafeAtomicAdd(gq + t.o11, v11);
             }
-#ifdef DCNB_EXP_NOCOLWRITE
-            if (val == 12345.f)  /* ablation only */
-#endif
             cp[(int64_t)u * K * P] = val * m;  // forward column, consumed by the dW GEMM
           }
         }
@@ -462,9 +451,6 @@ __global__ __launch_bounds__(256) void dcn_bwd_coord_tile_kernel(const float *__
     const int cc = i / (LH * LW), rem = i - cc * (LH * LW), ly = rem / LW, lx = rem - ly * LW;
     const float v = win[cc * (LH * LWP) + ly * LWP + lx];
     const int gy = wy0 + ly, gx = wx0 + lx;
-#ifdef DCNB_EXP_NOFLUSH
-    if (v == 12345.f)  /* ablation only */
-#endif
     if (v != 0.f && gy >= 0 && gy < s.H && gx >= 0 && gx < s.W) unsafeAtomicAdd(gg + (int64_t)cc * plane + gy * s.W + gx, v);
   }
 }

@@ -150,9 +150,7 @@ __global__ __launch_bounds__(BF_NT) void dcn_bwd_fused_kernel(const DcnBwdFusedA
 #pragma unroll
     for (int s = 0; s < NS; ++s) dyr[s] = bload(dy_rsrc, 2 * s + half < a.Co ? dy_voff : OOB, 2 * s * P * 4);
   };
-#ifndef BF_DY_STREAM
   load_dy();
-#endif
 
   // ---- x window of one deformable group -> LDS (as dcn_fused.hip: positions outside the image fail the range check -> 0)
   constexpr int NT = BF_NT, NXK = (CHS + NT - 1) / NT;
@@ -208,9 +206,6 @@ __global__ __launch_bounds__(BF_NT) void dcn_bwd_fused_kernel(const DcnBwdFusedA
   auto step = [&](auto TPC, int g) {
     constexpr int TP = decltype(TPC)::value;
     const int i = g * BF_TP + TP;
-#ifdef BF_DY_STREAM
-    load_dy();
-#endif
     // LDS-only barrier: slab i is in LDS (every wave waited for its own pieces after the MFMAs of the step before), nobody reads
     // slab i - 1 or updates accumulator rows of the step before any more
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -223,15 +218,8 @@ __global__ __launch_bounds__(BF_NT) void dcn_bwd_fused_kernel(const DcnBwdFusedA
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#ifdef BF_EXP_NOMFMA /* ablation (wrong results): no matrix-core work, accumulators = some live registers */
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = dyr[r + TP];
-#pragma unroll
-    for (int s = 0; s < 0; s += 4) {
-#else
 #pragma unroll
     for (int s = 0; s < NS; s += 4) {
-#endif
       const f32x4 av = *reinterpret_cast<const f32x4 *>(slab + abase + s);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], dyr[s + 0], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], dyr[s + 1], acc, 0, 0, 0);
@@ -281,14 +269,8 @@ __global__ __launch_bounds__(BF_NT) void dcn_bwd_fused_kernel(const DcnBwdFusedA
     float *pk0 = pw + (half ? 3 : 0) * PC + pcol - 1, *pk1 = pw + (half ? 2 : 1) * PC + pcol - 1;  // column pass b at [b]
     float *pun = pw + ti * PC + pcol - 1;  // unmerged steps: block row a (0..2 = -1..+1) at [a * PC], rows ti .. ti + 2
 
-#ifdef BF_EXP_NOCONS /* ablation (wrong results): the consumer of the accumulators is skipped */
-    for (int r = 0; r < 16; ++r) s_m += acc[r];
-#pragma unroll
-    for (int c4 = 0; c4 < 0; c4 += CG) {
-#else
 #pragma unroll
     for (int c4 = 0; c4 < CPG; c4 += CG) {
-#endif
       float tt[CG];
 #pragma unroll
       for (int u = 0; u < CG; ++u) {
@@ -301,11 +283,8 @@ __global__ __launch_bounds__(BF_NT) void dcn_bwd_fused_kernel(const DcnBwdFusedA
         s_y += d * (hw * (a10 - a00) + lw * (a11 - a01));
         s_x += d * (hh * (a01 - a00) + lh * (a11 - a10));
         tt[u] = d * o_m;
-#ifndef BF_EXP_NOCOL /* ablation (wrong dW): no column stores */
         bstore(val * o_m, col_rsrc, v1, (g * CPG + c) * 9 * P * 4);  // forward column (row c * 9 + t), consumed by the dW GEMM
-#endif
       }
-#ifndef BF_EXP_NOSCAT /* ablation (wrong dX): no accumulator updates */
       if constexpr (TP < 3) {
         float r0[CG], r1[CG], gift[CG];
 #pragma unroll
@@ -356,9 +335,7 @@ __global__ __launch_bounds__(BF_NT) void dcn_bwd_fused_kernel(const DcnBwdFusedA
           asm volatile("" ::: "memory");  // ... and the second half-wave's turn reads what the first one wrote
         }
       }
-#endif
     }
-#ifndef BF_EXP_NOSLOW /* ablation (wrong results beyond sub-pixel offsets): no cold paths */
     if (__any(mid)) {  // inside the window but not sub-pixel: dX by device atomics (four per channel, nothing waits for them)
       if (mid) {
         const bool r0 = fhi >= 0, r1 = fhi + 1 <= a.H - 1, c0 = fwi >= 0, c1 = fwi + 1 <= a.W - 1;  // corners inside the image (.cu:481-491)
@@ -402,7 +379,6 @@ __global__ __launch_bounds__(BF_NT) void dcn_bwd_fused_kernel(const DcnBwdFusedA
         }
       }
     }
-#endif
     bstore(s_m, dmsk_rsrc, v1, g * 9 * P * 4);
     bstore(s_y * o_m, doff_rsrc, v2, g * 18 * P * 4);
     bstore(s_x * o_m, doff_rsrc, v2, (g * 18 + 1) * P * 4);

@@ -181,11 +181,7 @@ __global__ __launch_bounds__(256, 2) void dcn_fused_fwd_kernel(const DcnFusedArg
       w11[t] = lh * lw * mm;
       const int ry = (int)fh - hy0, rx = (int)fw - wx0;
       const bool inside = ry >= 0 && ry <= IH - 2 && rx >= 0 && rx <= IW - 2;
-#ifdef DCNF_EXP_NOGATHER  /* ablation (wrong results): every lane reads its regular, conflict-free position */
-      taddr[t] = half * CHS + (oy - hy0 + t / 3 - 1) * RS + (ox - wx0 + t % 3 - 1);
-#else
       taddr[t] = half * CHS + (inside ? ry * RS + rx : 0);
-#endif
       if (valid && !inside) slow |= 1u << t; else slow &= ~(1u << t);
     }
     unsigned any = 0;

@@ -297,15 +297,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_kernel(const WinoArgs
     // Row pass (M A)[row][.] = (m0 + m1 + m2, m1 - m2 - m3) of the row to send (tiles 0-3), one accumulator tile at a
     // time: hipcc moves a tile out of the accumulator file as a whole 16-register tuple, so walking channel by channel
     // (8 tiles live at once) needs 128 VGPRs and spilled ~150 registers to scratch per item.
-#ifdef WINO_EXP_NOEPI  /* ablation only: no output transform / exchange / stores; accumulators kept alive without instructions */
-#pragma unroll
-    for (int xi = 0; xi < 8; ++xi) asm volatile("" ::"v"(acc[xi]));
-    load_begin(CK);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) load_col(c);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) load_u(g);
-#else
     // bias now, residuals right after the row pass (when the accumulators are dead): their latency hides behind the
     // transform and the exchange instead of being exposed once per batch of stores
     float bias_r[16];
@@ -342,9 +333,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_kernel(const WinoArgs
     WINO_ROWPASS(0, true)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {  // (scalar LDS writes: 64-bit pairs made hipcc spill the sums to form register tuples)
-#ifdef WINO_EXP_NOXCHG
-      if (sum[r][0] == 12345.f)  /* ablation only */
-#endif
       {
         xsend[(2 * r) * 64 + lane] = sum[r][0];
         xsend[(2 * r + 1) * 64 + lane] = sum[r][1];
@@ -374,25 +362,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_kernel(const WinoArgs
     // y_scale rides on instructions the residual / gate variants already issue (add -> fma, gate select picks between two
     // constants): bit-identical results for y_scale = 1, no cost; the other variants do not take a scale (winograd_eligible)
     const float ys = a.ys, ys_gs = a.ys_gs;
-#ifndef WINO_EXP_NOXCHG
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
     float mine[16][2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-#ifdef WINO_EXP_NOXCHG
-      mine[r][0] = sgn * sum[r][0];
-      mine[r][1] = sgn * sum[r][1];
-#else
       mine[r][0] = sgn * sum[r][0] + xrecv[(2 * r) * 64 + lane];
       mine[r][1] = sgn * sum[r][1] + xrecv[(2 * r + 1) * 64 + lane];
-#endif
     }
     __builtin_amdgcn_sched_barrier(0);
     // second barrier: pair 1 is overwritten by the first iteration of the next item
-#ifndef WINO_EXP_NOXCHG
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
     load_begin(CK);  // chunk 1 of the next item (geometry already switched)
 #pragma unroll
     for (int c = 0; c < 4; ++c) load_col(c);
@@ -444,9 +423,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_kernel(const WinoArgs
               if (INT || (co < d.co && oy < d.h && ox + xx < d.w))
                 y[(co >> 2) * plane * 4 + (2 * oy + ((co >> 1) & 1)) * (2 * d.w) + 2 * (ox + xx) + (co & 1)] = o[xx];
           } else if (INT) {  // 16 lanes x 8 B = one 128-B line per row
-#ifdef WINO_EXP_NOSTORE
-            if (o[0] == 12345.f)  /* ablation only */
-#endif
             *reinterpret_cast<f32x2 *>(y + co * plane + oy * d.w + ox) = f32x2{o[0], o[1]};
           } else {
 #pragma unroll
@@ -471,7 +447,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_kernel(const WinoArgs
     } else {
       if (interior) emit(F{}, F{}, F{}, T{}); else emit(F{}, F{}, F{}, F{});
     }
-#endif  // WINO_EXP_NOEPI
 #pragma unroll
     for (int xi = 0; xi < 8; ++xi)
 #pragma unroll

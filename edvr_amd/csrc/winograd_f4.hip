@@ -56,40 +56,11 @@ struct WinoF4Args {
   float ys, ys_gs;                                // y_scale (0 -> 1) and y_scale * gate_slope
 };
 
-#ifdef F4_EXP_NOEPI /* ablation: no output transform / stores */
-#define F4_EPI_PHASES 0
-#else
 #define F4_EPI_PHASES 8
-#endif
 #define F4_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-#ifdef F4_EXP_TRACE /* measurement build: cycle stamps of workgroup 0 (arrival at / release from every barrier, per wave) */
-__device__ long long f4_trace[16 * 2 * 512];
-__device__ long long f4_trace_p[4 * 4 * 512];  // producers: after the DMA wait, after the patch reads, after the DMA issue, after the transforms
-#define F4_PSTAMP(i)                                                                                         \
-  do {                                                                                                      \
-    if (blockIdx.x == 0 && f4_slot < 512 && (threadIdx.x & 63) == 0)                                        \
-      f4_trace_p[(f4_slot * 4 + (threadIdx.x >> 6)) * 4 + (i)] = __builtin_readcyclecounter();              \
-  } while (0)
-#define F4_STAMP(slot)                                                                                          \
-  do {                                                                                                          \
-    if (blockIdx.x == 0 && (slot) < 512 && (threadIdx.x & 63) == 0)                                            \
-      f4_trace[((slot) * 16 + (threadIdx.x >> 6)) * 2 + f4_tr_ph] = __builtin_readcyclecounter();              \
-  } while (0)
-#define F4_BARRIER_T()   \
-  do {                   \
-    int f4_tr_ph = 0;    \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-    F4_STAMP(f4_slot);   \
-    asm volatile("s_barrier" ::: "memory"); \
-    f4_tr_ph = 1;        \
-    F4_STAMP(f4_slot);   \
-    ++f4_slot;           \
-  } while (0)
-#else
 #define F4_BARRIER_T() F4_LDS_BARRIER()
 #define F4_PSTAMP(i)
-#endif
 
 // TXL: log2 of the tiles per block row.  4: blocks of 2 x 16 tiles = 8 x 64 output pixels; 3: 4 x 8 tiles = 16 x 32 pixels, for
 // images whose width wastes much of a 64-pixel block (160 wide: 17 %, 80 wide: 37 %) and for 32-wide pyramid levels.
@@ -109,11 +80,7 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
 
   const edvr_conv2d_desc &d = a.d;
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, j = lane & 31;
-#ifdef F4_EXP_PRODLAST /* experiment: the staging waves are the LAST four hardware waves of the workgroup instead of the first */
-  const int wave = __builtin_amdgcn_readfirstlane(((tid >> 6) + 4) & 15);
-#else
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#endif
   const int hw = d.h * d.w, plane_bytes = hw * 4;
   const int co_blocks = (d.co + 63) / 64;
   const int n_chunks = a.ci / CK;
@@ -133,9 +100,6 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
   const int item_end = min(a.items, (xcd + 1) * span);
   const int item_first = xcd * span + xcd_rank;
   if (item_first >= item_end) return;
-#ifdef F4_EXP_TRACE
-  int f4_slot = 0;
-#endif
   auto decode = [&](int item, int &co_blk, int &img, int &ty0, int &tx0) {
     co_blk = __builtin_amdgcn_readfirstlane((item % co_blocks) * 64);
     const int tile_blk = __builtin_amdgcn_readfirstlane((item / co_blocks) % (a.tiles_x * a.tiles_y));
@@ -188,9 +152,6 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
       ld_rsrc = uniform_rsrc(pl, nvalid >= 2 ? 2 * plane_bytes : (nvalid == 1 ? plane_bytes : 0));
     };
     auto dma_issue = [&]() {
-#ifdef F4_EXP_NODMA /* ablation (wrong results): no input fetch at all */
-      return;
-#endif
 #pragma unroll
       for (int i = 0; i < 6; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(ld_rsrc, (lvoid *)(Rw + 1 + i * 256), 16, dma_off[i], 0, 0, 0);
     };
@@ -209,13 +170,8 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
     // paired the way the packed transform wants them (no moves).
     const float *patch = Rw + ((half * RROWS + 4 * p_ty) * RPIECES + p_tx) * 4 + 4;  // patch row r, column c: patch[r * 4 RPIECES + c]
     auto read_patch = [&]() {
-#ifndef F4_EXP_NOWAIT /* ablation (wrong results): do not wait for the DMA */
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the requested chunk is in the region
-#endif
       F4_PSTAMP(0);
-#ifdef F4_EXP_NOPREAD /* ablation (wrong results): no patch reads */
-      return;
-#endif
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
         const f32x4 m = *reinterpret_cast<const f32x4 *>(patch + r * (4 * RPIECES));
@@ -227,10 +183,6 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
       F4_PSTAMP(1);
     };
     auto transform_cols = [&](int cp) {  // 1-D input transform B^T (Lavin & Gray), 12 operations (a * b + c contracts to an fma)
-#ifdef F4_EXP_NOXFORM /* ablation (wrong results): no transform arithmetic */
-      for (int r = 0; r < 6; ++r) tp[r][cp] = pp[r][cp];
-      return;
-#endif
       const f32x2 d0 = pp[0][cp], d1 = pp[1][cp], d2 = pp[2][cp], d3 = pp[3][cp], d4 = pp[4][cp], d5 = pp[5][cp];
       const f32x2 p_ = d4 - 4.f * d2, q_ = d3 - 4.f * d1, r_ = d4 - d2, s_ = d3 - d1;
       tp[0][cp] = 4.f * d0 + (d4 - 5.f * d2);
@@ -242,17 +194,6 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
     };
     auto commit_row = [&](float *Vd, int r) {  // positions (r, 0..5) of (B^T d) B
       const f32x2 P0 = tp[r][0], P1 = tp[r][1], P2 = tp[r][2];
-#ifdef F4_EXP_NOVW /* ablation (wrong results): no V writes (the values are kept alive) */
-      asm volatile("" ::"v"(P0), "v"(P1), "v"(P2));
-      return;
-#endif
-#ifdef F4_EXP_NOXFORM
-      {
-        float *dst = Vd + ((2 * wave + half) * 36 + r * 6) * 32 + j;
-        dst[0 * 32] = P0[0]; dst[1 * 32] = P0[1]; dst[2 * 32] = P1[0]; dst[3 * 32] = P1[1]; dst[4 * 32] = P2[0]; dst[5 * 32] = P2[1];
-        return;
-      }
-#endif
       const f32x2 lo1 = __builtin_shufflevector(P1, P1, 0, 0), hi1 = __builtin_shufflevector(P1, P1, 1, 1);  // d2, d3
       const f32x2 lo2 = __builtin_shufflevector(P2, P2, 0, 0), hi0 = __builtin_shufflevector(P0, P0, 1, 1);  // d4, d1
       const f32x2 t05 = 4.f * P0 + (P2 - 5.f * P1);
@@ -316,7 +257,6 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
         // the region holds chunk k + 1 (chunk 0 of the next item at the end): patches -> registers, request chunk k + 2,
         // transform into the idle stage
         float *Vd = smem + (par ^ 1) * VSLAB;
-#ifndef F4_EXP_NOPROD  /* ablation: the producers only keep the barrier count */
         read_patch();
         advance();
         load_begin(l_k * CK);
@@ -327,7 +267,6 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
 #pragma unroll
         for (int r = 0; r < 6; ++r) commit_row(Vd, r);
         F4_PSTAMP(3);
-#endif
         F4_BARRIER_T();
         par ^= 1;
       }
@@ -496,15 +435,9 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
       a2[set] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(u_rsrc, voff2, soff, 0));
     };
     auto load_a4 = [&](int set, int t) {
-#ifdef F4_EXP_NOULOAD /* ablation (wrong results): the weights are fetched once per item, not per k-step */
-      return;
-#endif
       a4[set] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, voff4, u_base + t * (12 * 1536), 0));
     };
     auto load_a2 = [&](int set, int t) {
-#ifdef F4_EXP_NOULOAD
-      return;
-#endif
       a2[set] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(u_rsrc, voff2, u_base + t * (12 * 1536), 0));
     };
     int co_blk, img_, ty_, tx_;
@@ -538,37 +471,6 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
 #pragma unroll
             for (int c = 0; c < 3; ++c) bv[nxt][c] = Vs[(2 * cpn * 36 + 3 * hn + c) * 32];
           }
-#ifdef F4_EXP_NOMFMA  /* ablation: operands fetched, no MFMA */
-          asm volatile("" ::"v"(bv[cur][0]), "v"(bv[cur][1]), "v"(bv[cur][2]), "v"(a4[set]), "v"(a2[set]));
-          if (hi) load_a(set, min(4 * k + cp + 2, n_steps - 1));
-          __builtin_amdgcn_sched_barrier(0);
-          continue;
-#endif
-#ifdef F4_EXP_MFMA16 /* ablation (wrong results): every 16-pass MFMA as two 8-pass v_mfma_f32_16x16x4_f32 - same matrix-pipe time,
-                        twice the issue slots in between.  Does the staging wave get further? */
-          {
-            auto two = [&](f32x16 &A, float a_, float b_) {
-              f32x4 q0 = {A[0], A[1], A[2], A[3]}, q1 = {A[4], A[5], A[6], A[7]};
-              q0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b_, q0, 0, 0, 0);
-              q1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b_, q1, 0, 0, 0);
-              A[0] = q0[0]; A[1] = q0[1]; A[2] = q0[2]; A[3] = q0[3];
-              A[4] = q1[0]; A[5] = q1[1]; A[6] = q1[2]; A[7] = q1[3];
-            };
-            if (!hi) {
-#pragma unroll
-              for (int c = 0; c < 3; ++c) two(acc[c], a4[set][c], bv[cur][c]);
-            } else {
-              two(acc[3], a4[set][3], bv[cur][0]);
-              const int t_next = min(4 * k + cp + 2, n_steps - 1);
-              load_a4(set, t_next);
-              two(acc[4], a2[set][0], bv[cur][1]);
-              two(acc[5], a2[set][1], bv[cur][2]);
-              load_a2(set, t_next);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            continue;
-          }
-#endif
           if (!hi) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[set][c], bv[cur][c], acc[c], 0, 0, 0);
@@ -580,9 +482,6 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
             acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[set][1], bv[cur][2], acc[5], 0, 0, 0);
             load_a2(set, t_next);
           }
-#ifdef F4_EXP_SLEEP /* experiment: a consumer yields the issue port after every group of three MFMAs */
-          __builtin_amdgcn_s_sleep(F4_EXP_SLEEP);
-#endif
           __builtin_amdgcn_sched_barrier(0);
         }
         F4_BARRIER_T();
@@ -595,10 +494,6 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4_kernel(const Wino
         load_a(0, 0);
         load_a(1, 1);
       }
-#ifdef F4_EXP_NOEPI
-#pragma unroll
-      for (int c = 0; c < 6; ++c) asm volatile("" ::"v"(acc[c]));  // keep the MFMAs alive
-#endif
       // ---- row pass T = M A (6 -> 4) and hand-over to the producers: 8 phases of two accumulator registers (8 output channels
       //      over the two channel halves), alternating halves of the exchange area
 #pragma unroll
@@ -722,10 +617,6 @@ int winograd_f4_pack(const float *w, float *U, int co, int ci, int transpose_fli
 
 extern "C" {
 
-#ifdef F4_EXP_TRACE
-int edvr_f4_trace_read(long long *host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(edvr::f4_trace), sizeof(long long) * n); }
-int edvr_f4_trace_read_p(long long *host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(edvr::f4_trace_p), sizeof(long long) * n); }
-#endif
 
 size_t edvr_conv2d_packed_weight_f4_elems(int co, int ci) { return (size_t)((co + 63) / 64 * 64) * ((ci + 7) / 8 * 8) * 36; }
 

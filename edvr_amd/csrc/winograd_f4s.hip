@@ -524,10 +524,15 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
         par ^= 1;
       }
       u_base = u_next;
-      // ---- row pass T = M A (6 -> 4) and hand-over to the staging waves: 8 phases of two accumulator registers
+      // ---- row pass T = M A (6 -> 4) and hand-over to the staging waves: 8 phases of two accumulator registers.  The store address
+      //      is derived HERE from an opaque copy of the lane index: hoisted out of the item loop it stays live across the chunk loop,
+      //      whose 96 + 24 + 4 registers leave no room for it (it was spilled and reloaded once per item)
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));
+      float *const Xw = Xs + ((row * 8 + wm * 4 + (lane_e >> 5) * 2) * 32 + (lane_e & 31)) * 4;
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
-        float *Xb = Xs + (p & 1) * (XSZ / 2);
+        float *Xb = Xw + (p & 1) * (XSZ / 2);
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
           const int r = (p & 3) + 4 * (2 * (p >> 2) + rr);
@@ -538,8 +543,7 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
           T[1] = __builtin_fmaf(2.f, d2, d1);
           T[2] = __builtin_fmaf(4.f, s2, s1);
           T[3] = __builtin_fmaf(8.f, d2, d1) + m5;
-          const int cl8 = wm * 4 + half * 2 + rr;
-          *reinterpret_cast<f32x4 *>(Xb + ((row * 8 + cl8) * 32 + j) * 4) = T;
+          *reinterpret_cast<f32x4 *>(Xb + rr * 32 * 4) = T;
         }
         F4S_BARRIER();
       }

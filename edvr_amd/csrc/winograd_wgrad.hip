@@ -155,10 +155,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
   // row) load columns 1..4 instead and move them up one place: their offset stays >= 0 (a negative one would have to rely on how
   // the range check wraps); at the right border and at the end of the image the dwords past num_records come back as 0.
   auto load_row = [&](int r) {
-#ifdef WW_EXP_NOLOAD
-#pragma unroll
-    for (int c = 0; c < 4; ++c) pr[r * 4 + c] = (rowok[r] && colok[c]) ? 1.f : 0.f;  /* ablation only */
-#else
     const bool shl = !colok[0];
     const int off = rel[r] + win_off + (shl ? 4 : 0);
     const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrow_rsrc, (rowok[r] && colok[1]) ? off : OOB, 0, 0));
@@ -166,7 +162,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
     pr[r * 4 + 1] = shl ? v[0] : v[1];
     pr[r * 4 + 2] = shl ? v[1] : v[2];
     pr[r * 4 + 3] = colok[3] ? (shl ? v[2] : v[3]) : 0.f;
-#endif
   };
   auto load_dy = [&](auto SET) {
     constexpr int S = decltype(SET)::value;
@@ -184,9 +179,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
   auto commit_v_row = [&](float *Vs, int r) {  // positions xi = 4r .. 4r+3 of B^T (d B): B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]
     float *dst = Vs + t * TS + chl * CS + r * 4;
     const float *ra = tt + (r == 0 ? 0 : r == 1 ? 1 : r == 2 ? 2 : 1) * 4, *rb = tt + (r == 0 ? 2 : r == 1 ? 2 : r == 2 ? 1 : 3) * 4;
-#ifdef WW_EXP_NOCOMMIT
-    if (ra[0] == 12345.f)  /* ablation only */
-#endif
     {
       f32x4 v;
 #pragma unroll
@@ -247,10 +239,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd_wgrad_kernel(const Wi
     // geometry of the NEXT iteration's loads, here rather than at the top of the iteration: the scalar chain (pointer
     // arithmetic, resource words, validity masks) then runs under the MFMAs of the last group instead of in front of an idle
     // matrix pipe right after the barrier (ablation: 8 % of the kernel)
-#ifndef WW_EXP_NOGEOM
     advance();
     geometry();
-#endif
     // LDS-only barrier: the loads just issued target registers and need no cross-wave ordering
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };

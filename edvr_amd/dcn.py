@@ -146,17 +146,13 @@ class DeformConvFunction(Function):
 
     @staticmethod
     def _output_size(input, weight, padding, dilation, stride):
-        channels = weight.size(0)
-        output_size = (input.size(0), channels)
-        for d in range(input.dim() - 2):
-            in_size = input.size(d + 2)
-            pad = padding[d]
-            kernel = dilation[d] * (weight.size(d + 2) - 1) + 1
-            stride_ = stride[d]
-            output_size += ((in_size + (2 * pad) - kernel) // stride_ + 1, )
-        if not all(map(lambda s: s > 0, output_size)):
-            raise ValueError('convolution input is too small (output would be ' f'{"x".join(map(str, output_size))})')
-        return output_size
+        """(N, Co, Ho, Wo) of the op - same name, arguments and error as the reference's helper (deform_conv.py:94-108)."""
+        spatial = tuple((int(i) + 2 * p - (d * (int(k) - 1) + 1)) // s + 1
+                        for i, k, p, d, s in zip(input.shape[2:], weight.shape[2:], padding, dilation, stride))
+        shape = (int(input.shape[0]), int(weight.shape[0])) + spatial
+        if min(shape) <= 0:
+            raise ValueError('convolution input is too small (output would be ' + 'x'.join(str(v) for v in shape) + ')')
+        return shape
 
 
 deform_conv = DeformConvFunction.apply
@@ -189,17 +185,15 @@ class DeformConv(nn.Module):
         self.weight.uniform_(-stdv, stdv)
 
     def forward(self, x, offset):
-        # the reference pads inputs smaller than the kernel (deform_conv.py:234-250); same shim, same crop
-        input_pad = (x.size(2) < self.kernel_size[0] or x.size(3) < self.kernel_size[1])
-        if input_pad:
-            pad_h = max(self.kernel_size[0] - x.size(2), 0)
-            pad_w = max(self.kernel_size[1] - x.size(3), 0)
-            x = torch.nn.functional.pad(x, (0, pad_w, 0, pad_h), 'constant', 0).contiguous()
-            offset = torch.nn.functional.pad(offset, (0, pad_w, 0, pad_h), 'constant', 0).contiguous()
-        out = deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups, self.deformable_groups)
-        if input_pad:
-            out = out[:, :, :out.size(2) - pad_h, :out.size(3) - pad_w].contiguous()
-        return out
+        # An input smaller than the kernel is grown with zeros at the bottom / right up to the kernel size, the offsets alike, and the
+        # output cropped back by the same amount - the behaviour of the reference's workaround (deform_conv.py:234-250)
+        grow_h, grow_w = max(self.kernel_size[0] - x.shape[2], 0), max(self.kernel_size[1] - x.shape[3], 0)
+        if grow_h or grow_w:
+            x, offset = (torch.nn.functional.pad(t, (0, grow_w, 0, grow_h)).contiguous() for t in (x, offset))
+        y = deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups, self.deformable_groups)
+        if grow_h or grow_w:
+            y = y[:, :, :y.shape[2] - grow_h, :y.shape[3] - grow_w].contiguous()
+        return y
 
 
 class DeformConvPack(DeformConv):

@@ -80,7 +80,19 @@ def offset_mask_conv(conv_offset, feat):
     return conv(conv_offset, feat, act=ACT_SIGMOID, act_from=2 * co // 3)
 
 
-def halo_hint_from_stats(absmean, rough):
+def tapwin_takes(x, m):
+    """Does the tap-window kernel (csrc/dcn_tapwin.hip) take this layer?  (W % 4 == 0, W >= 32, 8 or 16 channels per deformable
+    group, at most 8 groups, the EDVR signature.)"""
+    c, w, dg = x.shape[1], x.shape[3], m.deformable_groups
+    return (w % 4 == 0 and w >= 32 and dg <= 8 and c % dg == 0 and c // dg in (8, 16) and tuple(m.kernel_size) == (3, 3)
+            and _one(m.stride) == 1 and _one(m.padding) == 1 and _one(m.dilation) == 1 and m.groups == 1)
+
+
+def _one(v):
+    return v if isinstance(v, int) else (v[0] if v[0] == v[1] else -1)
+
+
+def halo_hint_from_stats(absmean, rough, tapwin_ok=True):
     """Kernel class of the fused DCNv2 forward from the statistics of the PREVIOUS call of the same layer (a performance hint only):
     `absmean` = mean |offset|, `rough` = mean |horizontal neighbour difference| (None = unknown).  The kernel whose staged windows
     follow every tap's displacement (csrc/dcn_tapwin.hip, EDVR_DCN_HALO_TAPWIN) is the default: on a spatially smooth field - what
@@ -91,6 +103,8 @@ def halo_hint_from_stats(absmean, rough):
     TF/s at sigma 1), and white noise of tens of pixels (every tap of every lane through the fix-up pass: the column-buffer path,
     19 vs 17.5 TF/s at sigma 64).  Layers the tap-window kernel does not take (widths not a multiple of 4, other group sizes) fall
     back to the zero-centred halo inside the C entry point."""
+    if not tapwin_ok:  # the C side would fall back to R = 7 whatever the offsets: pick the halo class by magnitude (R = 3 stages half as much)
+        return 3 if (absmean is None or absmean < 1.2) else (7 if absmean < 3.0 else -1)
     if absmean is None:
         return ops.DCN_HALO_TAPWIN
     if rough is None:  # rows that are not 16-byte groups: the tap-window kernel does not take those anyway -> halo classes by magnitude
@@ -128,7 +142,7 @@ def scatter_hint_from_absmean(absmean):
 def dcn_from_packed(m, x, om, act=ACT_NONE):
     """Modulated deformable conv of module `m` (weight/bias/geometry) with offsets+masks packed in `om`."""
     cfg = (m.stride, m.padding, m.dilation, m.groups, m.deformable_groups)
-    hint = halo_hint_from_stats(getattr(m, 'last_offset_absmean', None), getattr(m, 'last_offset_rough', None))
+    hint = halo_hint_from_stats(getattr(m, 'last_offset_absmean', None), getattr(m, 'last_offset_rough', None), tapwin_takes(x, m))
     if _needs_grad(x, om, m.weight, m.bias):
         from . import autograd as ag
         return ag.DcnFromPackedFn.apply(x, om, m.weight, m.bias, (*cfg, act, hint, m))

@@ -275,6 +275,7 @@ def invalidate_packed_weights():
 
 # ------------------------------------------------------------------------------------------------ conv
 DCN_SCATTER_AUTO, DCN_SCATTER_DEVICE, DCN_SCATTER_LDS, DCN_SCATTER_STRIP = 0, 1, 2, 3  # include/edvr_amd.h EDVR_DCN_SCATTER_*
+_SCATTER_NAMES = {0: '[auto]', 1: '[device atomics]', 2: '[lds window]', 3: '[strip / fused]'}  # measurement label of dcnv2_backward's dX strategy
 DCN_HALO_TAPWIN = _lib.DCN_HALO_TAPWIN  # halo_hint of dcnv2_forward: per-tap shifted windows (csrc/dcn_tapwin.hip)
 LAUNCH_HOOK = None  # callable(kernel_name, algorithmic_flops, launch_fn, algorithmic_bytes) or None
 CONV_ALGO = CONV_AUTO  # default algorithm request of conv2d(); tests flip it to cover both kernels on every shape
@@ -544,11 +545,13 @@ def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NON
     if abs_sum_channels > 0:
         if sums is None:
             return out, abs_stats_per_image(out[:, :abs_sum_channels])
-        # the epilogue took the sums of |y|; the roughness statistic is ESTIMATED from the first image (a 30 MB pass on the L1 layer,
-        # ~10 us) and scaled to the batch - one more accumulator in the F(4x4) kernel's staging waves spills (128 registers) and
-        # slows every layer of the network by 4 %
-        r = abs_stats_per_image(out[:1, :abs_sum_channels])
-        sums[1, :1] = r[1] * float(n)
+        # the epilogue took the sums of |y|; the roughness statistic (row 1) is an ESTIMATE from up to four images spread over the batch
+        # (one pass over ~4 x 30 MB on the L1 layer), each scaled to stand for its neighbours - one more accumulator in the F(4x4)
+        # kernels' staging waves spills (128 registers) and slows every layer of the network by 4 %
+        step = max(1, n // 4)
+        sel = out[::step, :abs_sum_channels]
+        r = abs_stats_per_image(sel)
+        sums[1, ::step] = r[1] * (float(n) / sel.shape[0])
         return out, sums
     return out
 
@@ -708,7 +711,7 @@ def dcnv2_backward(x, offset, mask, weight, dy, with_bias, stride, pad, dil, gro
         return dx, doff, dmsk, dw, db
     nbytes = L.edvr_dcnv2_bwd_ws_bytes(*dims)
     ws = workspace(nbytes, x.device)
-    _run('dcnv2_bwd', lambda: _lib.check(L.edvr_dcnv2_bwd_f32(_ptr(x), _ptr(offset), _ptr(mask), _ptr(weight), _ptr(dy), _ptr(dx), _ptr(doff), _ptr(dmsk),
+    _run('dcnv2_bwd' + _SCATTER_NAMES.get(int(scatter_hint), ''), lambda: _lib.check(L.edvr_dcnv2_bwd_f32(_ptr(x), _ptr(offset), _ptr(mask), _ptr(weight), _ptr(dy), _ptr(dx), _ptr(doff), _ptr(dmsk),
                                     _ptr(dw), _ptr(db), *dims, _bstride(offset), _bstride(mask), _bstride(doff), _bstride(dmsk),
                                     int(scatter_hint), _ptr(ws), nbytes, _stream()),
                                        'edvr_dcnv2_bwd_f32'), 4.0 * dy.numel() * weight[0].numel(), _nb(x, offset, mask, weight, dy, dx, doff, dmsk, dw))

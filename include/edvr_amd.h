@@ -204,7 +204,10 @@ int edvr_conv2d_executed_flops(const edvr_conv2d_desc *d, double *flops);
  * (0 = contiguous), so channel-sliced views of one conv_offset output can be passed without a copy.
  * act: EDVR_ACT_* applied to y in the GEMM epilogue (EDVR_ACT_NONE = the reference op; PCDAlignment
  * follows two of its four DCNs with LeakyReLU, edvr_arch.py:103-104,116).
- * halo_hint: performance hint only (results are identical for every value).  The EDVR signature (3x3, stride 1, pad 1,
+ * halo_hint: performance hint only: every class computes the same operator, but their summation orders (and the tap-window class's
+ * explicit fma chains) differ, so results agree to fp32 rounding (<= 2e-5 of the output scale, tests/test_gpu_dcn.py), not bit for bit.  The
+ * Python layer picks the class from statistics of earlier calls that arrive asynchronously; EDVR_DCN_HINT_WAIT=1 makes that choice (and so
+ * the bits) reproducible at the price of one host synchronisation per forward.  The EDVR signature (3x3, stride 1, pad 1,
  * dil 1, groups 1, (C/dg) % 8 == 0) runs a fused kernel that stages an input halo of R pixels around each tile in LDS
  * and falls back to global gathers for taps that leave it: 0 or 3 -> R = 3 (|offset| mostly < 3), 7 -> R = 7,
  * -1 -> skip the fused kernel (generic column-buffer path; always used for other signatures).

@@ -3,6 +3,8 @@ global-memory slow path, the column-buffer fallback, the backward's scatter stra
 50` warning path.  Two families of offset fields:
 
   white   every offset element ~ N(0, sigma^2) independently (sigma = 0: the integer grid): no locality at all beyond sigma;
+  piecewise  two rigidly moving regions (object boundaries): per-tap constants, a jump of 4 / 8 px across diagonal boundaries that cross
+          every 8 x 32 tile - the tap-window kernels' fix-up paths;
   smooth  what a (trained) conv_offset produces: a per-channel constant ~ N(0, sigma^2) (the bias: each of the dg x 9 taps has its
           own displacement), a low-frequency motion component (N(0, 0.5^2) on a 16-px grid, bilinearly interpolated) and a white
           residual of 0.15 px (the size of the spatial part of bench.py's synthetic network).
@@ -42,6 +44,12 @@ def field(kind, sigma, B, H, W, g):
     if kind == 'white':
         off = torch.randn(B, 144, H, W, device=dev, generator=g) * sigma
         return off.round() if sigma == 0.0 else off
+    if kind == 'piecewise':  # two rigid regions: per-tap constants ~ N(0, 3^2), + a jump of `sigma` px on every other 24-px diagonal stripe
+        base = torch.randn(1, 144, 1, 1, device=dev, generator=g) * 3.0
+        step = (torch.rand(1, 144, 1, 1, device=dev, generator=g) * 2 - 1) * sigma
+        yy, xx = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing='ij')
+        side = (((xx + yy) // 24) % 2).float().view(1, 1, H, W)
+        return (base + side * step + torch.randn(B, 144, H, W, device=dev, generator=g) * 0.05).contiguous()
     bias = torch.randn(1, 144, 1, 1, device=dev, generator=g) * sigma
     coarse = torch.randn(B, 144, (H + 15) // 16 + 1, (W + 15) // 16 + 1, device=dev, generator=g) * 0.5
     low = F.interpolate(coarse, scale_factor=16, mode='bilinear', align_corners=False)[:, :, :H, :W]
@@ -50,9 +58,9 @@ def field(kind, sigma, B, H, W, g):
 
 HALO = {3: 'halo 3', 7: 'halo 7', ops.DCN_HALO_TAPWIN: 'tap windows', -1: 'columns+GEMM'}
 SCAT = {ops.DCN_SCATTER_STRIP: 'strip/fused', ops.DCN_SCATTER_DEVICE: 'device atomics', ops.DCN_SCATTER_LDS: 'LDS window'}
-FIELDS = [('white', s) for s in (0.0, 0.5, 1.0, 4.0, 16.0, 64.0)] + [('smooth', s) for s in (0.5, 2.0, 4.0, 10.0)]
+FIELDS = [('white', s) for s in (0.0, 0.5, 1.0, 4.0, 16.0, 64.0)] + [('smooth', s) for s in (0.5, 2.0, 4.0, 10.0)] + [('piecewise', s) for s in (4.0, 8.0)]
 if QUICK:
-    FIELDS = [('white', 0.5), ('white', 4.0), ('smooth', 0.5), ('smooth', 4.0), ('smooth', 10.0)]
+    FIELDS = [('white', 0.5), ('white', 4.0), ('smooth', 0.5), ('smooth', 4.0), ('smooth', 10.0), ('piecewise', 4.0), ('piecewise', 8.0)]
 for kind, sigma in FIELDS:
     g = torch.Generator(device=dev).manual_seed(int(sigma * 10) + (1000 if kind == 'smooth' else 1))
     # forward: the L1 layer of the 180x320 workloads (20 images); backward: the L1 layer of the training step (160 images of 64x64)

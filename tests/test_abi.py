@@ -73,22 +73,34 @@ def test_product_never_imports_the_oracle():
                 assert 'liboracle' not in txt and 'libdcn_ref' not in txt, f
 
 
-def test_hot_kernels_do_not_spill():
-    """hipcc's resource report for the two kernels that carry the inference step: no scratch.  The F(4x4) kernel runs at exactly its
-    128-register budget (16 waves per workgroup): round 4 added ONE accumulator to its staging waves (a roughness sum next to
-    abs_sum), the allocator spilled 8 bytes per lane and every layer of the network got 4 % slower - invisible in every parity
-    test.  This is the guard."""
+# Scratch (register spills) hipcc reports per kernel, bytes per lane.  Everything not listed must be ZERO; a listed kernel may not
+# exceed its entry.  The hot kernels of the step are at zero except the split-operand F(4x4) kernel, whose five dwords are written
+# before and read after the chunk loop, once per item of ~40 k cycles (wave-uniform state parked in vector registers that the loop's
+# 96 accumulator + 24 weight + 4 operand registers leave no room for); the others are second-line kernels (fallback classes).
+SCRATCH_ALLOWED = {
+    'conv3x3_winograd_f4s_kernelILi3E': 20, 'conv3x3_winograd_f4s_kernelILi4E': 20,
+    'dcn_bwd_fused_kernel': 40,
+    'dcn_fused_fwd_kernelILi4ELi7E': 80, 'dcn_fused_fwd_kernelILi4ELi3E': 64, 'dcn_fused_fwd_kernelILi3ELi7E': 64, 'dcn_fused_fwd_kernelILi3ELi3E': 48,
+    'conv2d_wgrad_kernelILi3ELi1ELi1E': 104, 'conv2d_wgrad_kernelILi3ELi2ELi2E': 172,
+}
+
+
+def test_kernels_do_not_spill_beyond_the_allow_list():
+    """hipcc's resource report for EVERY __global__ of csrc/: no scratch outside SCRATCH_ALLOWED, and no growth inside it.  Round 4
+    added ONE accumulator to the F(4x4) kernel's staging waves (a roughness sum next to abs_sum), the allocator spilled 8 bytes per
+    lane and every layer of the network got 4 % slower - invisible in every parity test.  This is the guard."""
     import re
     import shutil
     import subprocess
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     if not os.path.exists(hipcc):
         pytest.skip('hipcc not available')
-    root = os.path.join(os.path.dirname(__file__), '..')
-    for src, kernels in (('winograd_f4.hip', ('conv3x3_winograd_f4_kernelILi3E', 'conv3x3_winograd_f4_kernelILi4E')),
-                         ('dcn_tapwin.hip', ('dcn_tapwin_fwd_kernelILi4ELi16E', 'dcn_tapwin_fwd_kernelILi2ELi8E'))):
-        r = subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-ffp-contract=fast', '-c',
-                            os.path.join(root, 'edvr_amd', 'csrc', src), '-o', os.devnull, '-Rpass-analysis=kernel-resource-usage'],
+    csrc = os.path.join(ROOT, 'edvr_amd', 'csrc')
+    from edvr_amd.build import FLAGS, SOURCES
+
+    def report(src):
+        r = subprocess.run([hipcc] + FLAGS + ['-c', os.path.join(csrc, src), '-o', os.devnull, '-Rpass-analysis=kernel-resource-usage'],
                            capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         cur, seen = None, {}
@@ -99,6 +111,20 @@ def test_hot_kernels_do_not_spill():
             m = re.search(r'ScratchSize \[bytes/lane\]: (\d+)', line)
             if m and cur:
                 seen[cur] = int(m.group(1))
-        for k in kernels:
-            hits = [v for name, v in seen.items() if k in name]
-            assert hits and max(hits) == 0, (src, k, seen)
+        return seen
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        seen = {}
+        for rep in ex.map(report, SOURCES):
+            seen.update(rep)
+    assert len(seen) > 60, len(seen)  # (every translation unit reported)
+    bad = {}
+    for name, nbytes in seen.items():
+        limit = max([v for k, v in SCRATCH_ALLOWED.items() if k in name] or [0])
+        if nbytes > limit:
+            bad[name] = (nbytes, limit)
+    assert not bad, bad
+    for hot in ('conv3x3_winograd_f4_kernelILi3E', 'conv3x3_winograd_f4_kernelILi4E', 'dcn_tapwin_fwd_kernelILi4ELi16E', 'dcn_tapwin_fwd_kernelILi2ELi8E',
+                'conv3x3_winograd_wgrad_kernel', 'conv3x3_winograd_wgrad_split_kernel', 'conv3x3_winograd_kernel'):
+        hits = [v for k, v in seen.items() if hot in k]
+        assert hits and max(hits) == 0, (hot, hits)

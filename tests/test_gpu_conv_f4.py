@@ -182,9 +182,17 @@ def test_f4_abs_sum_epilogue(gpu, shape):
     want_diff = (y4[..., 1:] - y4[..., :-1]).abs().sum((1, 2, 3, 4))  # the three neighbour pairs inside every 4-pixel row piece
     assert tuple(sums.shape) == (2, n)
     assert ((sums[0].double() - want).abs() / want).max().item() < 1e-5
-    # the roughness row is an ESTIMATE from the first image scaled to the batch (ops.conv2d: an accumulator for it inside the F(4x4)
-    # kernel's staging waves would spill): row 1 = [n * diff(image 0), 0, ...]
-    assert abs(sums[1, 0].double().item() - n * want_diff[0].item()) / (n * want_diff[0].item()) < 1e-5 and (sums[1, 1:] == 0).all()
+    # the roughness row is an ESTIMATE from up to four images spread over the batch, each scaled to stand for its neighbours
+    # (ops.conv2d: an accumulator for it inside the F(4x4) kernels' staging waves would spill): images 0, step, 2 step, ... carry
+    # diff(image) * n / (number of sampled images), the others 0
+    step = max(1, n // 4)
+    picked = list(range(0, n, step))
+    for i in range(n):
+        if i in picked:
+            exp = want_diff[i].item() * n / len(picked)
+            assert abs(sums[1, i].double().item() - exp) / exp < 1e-5
+        else:
+            assert sums[1, i].item() == 0
     y2, sums2 = ops.conv2d(x, wpk, b, co, 3, algo=ops.CONV_DIRECT, abs_sum_channels=nch, **kw)  # no such epilogue: separate kernel
     assert ((sums2[0].double() - y2[:, :nch].double().abs().sum((1, 2, 3))).abs() / want).max().item() < 1e-5
     y24 = y2[:, :nch].double().view(n, nch, h, w // 4, 4)

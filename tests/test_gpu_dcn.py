@@ -198,6 +198,44 @@ def _smooth_field(B, dg, H, W, sigma, g, noise=0.15, low=0.5, outliers=0):
     return off.contiguous()
 
 
+def _piecewise_field(B, dg, H, W, jump, g, noise=0.05):
+    """Two rigidly moving regions: per-(group, tap, dy | dx) constants ~ N(0, 3^2) on one side of a DIAGONAL boundary, the same plus
+    a common motion difference of `jump` pixels (random direction per plane) on the other.  The boundary x + y = const crosses every
+    8 x 32 tile of the image, so every workgroup of the tap-window kernels sees taps whose cells split between two windows."""
+    base = torch.randn(1, dg * 18, 1, 1, generator=g) * 3.0
+    step = (torch.rand(1, dg * 18, 1, 1, generator=g) * 2 - 1) * jump
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing='ij')
+    side = (((xx + yy) // 24) % 2).float().view(1, 1, H, W)  # stripes of width 24 along the diagonal: boundaries in every tile
+    return (base + side * step + torch.randn(B, dg * 18, H, W, generator=g) * noise).contiguous()
+
+
+@pytest.mark.parametrize('jump', [4.0, 8.0])
+@pytest.mark.parametrize('geom', [(2, 128, 40, 96, 128, 8), (1, 64, 24, 64, 64, 8)])
+def test_tap_window_kernel_on_piecewise_constant_motion(gpu, geom, jump):
+    """Object boundaries: a piecewise-constant field with jumps of 4 / 8 px along diagonals through every tile -
+    the per-lane fix-up pass of the tap-window forward and, in the backward, the LDS-window scatter's slow path.  Forward against the
+    C oracle, and all five gradients of the backward (whatever dX strategy the statistics pick, and every forced one) against it."""
+    from edvr_amd import ops
+    from oracle import dcn_oracle as O
+    B, C, H, W, Co, dg = geom
+    g = torch.Generator().manual_seed(int(jump) * 100 + C)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(Co, C, 3, 3, generator=g) * 0.1
+    b = torch.randn(Co, generator=g)
+    off = _piecewise_field(B, dg, H, W, jump, g)
+    m = torch.rand(B, dg * 9, H, W, generator=g)
+    ref = O.c_forward(x.double(), off.double(), m.double(), w.double(), b.double(), 1, 1, 1, 1, dg)
+    dev = [t.to(gpu) for t in (x, off, m, w, b)]
+    y = ops.dcnv2_forward(*dev, 1, 1, 1, 1, dg, halo_hint=ops.DCN_HALO_TAPWIN)
+    assert _rel(y, ref) < FWD_RTOL
+    dy = torch.randn(B, Co, H, W, generator=g)
+    gref = O.c_backward(x.double(), off.double(), m.double(), w.double(), dy.double(), True, 1, 1, 1, 1, dg)
+    for scatter in (ops.DCN_SCATTER_AUTO, ops.DCN_SCATTER_LDS, ops.DCN_SCATTER_DEVICE):
+        got = ops.dcnv2_backward(dev[0], dev[1], dev[2], dev[3], dy.to(gpu), True, 1, 1, 1, 1, dg, scatter_hint=scatter)
+        for name, a_, r_ in zip(('dx', 'doffset', 'dmask', 'dw', 'db'), got, gref):
+            assert _rel(a_, r_) < BWD_RTOL, (name, scatter, _rel(a_, r_))
+
+
 TAPWIN_CASES = [
     # B, C, H, W, Co, dg, sigma, outliers, act
     (2, 128, 21, 64, 128, 8, 4.0, 0, 0),    # EDVR-L geometry, ragged tile rows, multi-pixel smooth field
