@@ -48,6 +48,8 @@ PROTOTYPES = {
     'edvr_conv2d_executed_flops': (i32, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ctypes.c_double)]),
     'edvr_dcnv2_fwd_ws_bytes': (sz, [i32] * 12),
     'edvr_dcnv2_fwd_f32': (i32, [vp] * 6 + [i32] * 12 + [i64, i64, i32, i32, vp, sz, vp]),
+    'edvr_dcnv2_fwd_split_f32': (i32, [vp] * 6 + [i32] * 12 + [i64, i64, i32, i32, vp, sz, vp, vp]),
+    'edvr_dcnv2_fwd_split_applies': (i32, [vp] + [i32] * 13),
     'edvr_dcnv2_fwd_kernel_name': (i32, [vp] + [i32] * 13 + [ctypes.c_char_p, sz]),
     'edvr_dcnv2_bwd_ws_bytes': (sz, [i32] * 12),
     'edvr_dcnv2_any_ws_bytes': (sz, [i32] * 13),

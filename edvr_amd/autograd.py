@@ -137,8 +137,9 @@ class DcnFromPackedFn(Function):
     def forward(ctx, x, om, weight, bias, cfg):
         stride, padding, dilation, groups, dg, act, hint, _ = cfg
         split = 2 * om.shape[1] // 3
+        xb = ops.input_bound(x) if (ops.F4S_TRAINING and hint == ops.DCN_HALO_TAPWIN) else None  # (sigmoid masks: a bound of |x| does)
         out = ops.dcnv2_forward(x, om[:, :split], om[:, split:], weight, bias, stride, padding, dilation, groups, dg, act=act,
-                                halo_hint=hint)
+                                halo_hint=hint, xm_bound=xb)
         if ops.F4S_TRAINING:  # (masks are sigmoid outputs, bilinear taps convex combinations of x and the zero padding)
             ops.linear_bound(out, weight, bias, (x,))
         ctx.save_for_backward(x, om, weight, out if act != ACT_NONE else None)

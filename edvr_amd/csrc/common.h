@@ -111,6 +111,12 @@ bool dcn_tapwin_supported(int C, int Co, int H, int W, int kh, int kw, int strid
 int dcn_tapwin_forward(const float *x, const float *offset, const float *mask, const float *wpk, const float *bias, float *y, int B, int C,
                        int H, int W, int Co, int dg, int64_t off_bs, int64_t msk_bs, int act, hipStream_t stream);
 
+// dcn_tapwin_s.hip: the tap-window kernel with split fp32 operands on the f16 matrix pipe; packs its own weights into `wpk`
+bool dcn_tapwin_split_enabled();
+int dcn_tapwin_split_forward(const float *x, const float *offset, const float *mask, const float *weight, unsigned *wpk, const float *bias, float *y,
+                             int B, int C, int H, int W, int Co, int dg, int64_t off_bs, int64_t msk_bs, int act, const float *xm_amax,
+                             hipStream_t stream);
+
 // dcn_bwd_fused.hip: DCNv2 backward (dX, dOffset, dMask, forward columns) for the EDVR signature without the dcol buffer
 bool dcn_bwd_fused_supported(const DcnShape &s);
 size_t dcn_bwd_fused_wbk_elems(int dg);  // floats of the re-ordered W^T the kernel streams (workspace)

@@ -684,10 +684,10 @@ size_t edvr_dcnv2_bwd_ws_bytes(int B, int C, int H, int W, int Co, int kh, int k
   return edvr::bwd_ws(s).total;
 }
 
-int edvr_dcnv2_fwd_f32(const float *x, const float *offset, const float *mask, const float *weight, const float *bias,
-                       float *y, int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil, int groups,
-                       int dg, int64_t offset_bstride, int64_t mask_bstride, int act, int halo_hint, void *ws, size_t ws_bytes,
-                       edvr_stream_t stream_) {
+static int dcnv2_fwd_impl(const float *x, const float *offset, const float *mask, const float *weight, const float *bias,
+                          float *y, int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil, int groups,
+                          int dg, int64_t offset_bstride, int64_t mask_bstride, int act, int halo_hint, void *ws, size_t ws_bytes,
+                          const float *xm_amax, edvr_stream_t stream_) {
   using namespace edvr;
   EDVR_REQUIRE(x && offset && mask && weight && y, "dcnv2_fwd: null pointer");
   DcnShape s;
@@ -703,6 +703,11 @@ int edvr_dcnv2_fwd_f32(const float *x, const float *offset, const float *mask, c
   const int64_t P = (int64_t)s.Ho * s.Wo;
   float *col = reinterpret_cast<float *>(static_cast<char *>(ws) + wsz.col);
   float *wpk = reinterpret_cast<float *>(static_cast<char *>(ws) + wsz.wpk);
+  if (use_fused(s) && halo_hint == EDVR_DCN_HALO_TAPWIN && xm_amax && dcn_tapwin_split_enabled() &&
+      dcn_tapwin_supported(C, Co, H, W, kh, kw, s.stride, s.pad, s.dil, groups, dg) && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+    // the tap-window kernel with split fp32 operands on the f16 matrix pipe (dcn_tapwin_s.hip): its own weight layout in the same workspace
+    return dcn_tapwin_split_forward(x, offset, mask, weight, reinterpret_cast<unsigned *>(wpk), bias, y, B, C, H, W, Co, dg, s.off_bs, s.msk_bs, act,
+                                    xm_amax, stream);
   if (use_fused(s) && halo_hint >= 0) {
     rc = dcn_fused_pack(weight, wpk, Co, C, stream);
     if (rc) return rc;
@@ -743,6 +748,32 @@ int edvr_dcnv2_fwd_f32(const float *x, const float *offset, const float *mask, c
     if (rc) return rc;
   }
   return EDVR_OK;
+}
+
+int edvr_dcnv2_fwd_f32(const float *x, const float *offset, const float *mask, const float *weight, const float *bias,
+                       float *y, int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil, int groups,
+                       int dg, int64_t offset_bstride, int64_t mask_bstride, int act, int halo_hint, void *ws, size_t ws_bytes,
+                       edvr_stream_t stream) {
+  return dcnv2_fwd_impl(x, offset, mask, weight, bias, y, B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, offset_bstride, mask_bstride, act,
+                        halo_hint, ws, ws_bytes, nullptr, stream);
+}
+
+int edvr_dcnv2_fwd_split_f32(const float *x, const float *offset, const float *mask, const float *weight, const float *bias,
+                             float *y, int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil, int groups,
+                             int dg, int64_t offset_bstride, int64_t mask_bstride, int act, int halo_hint, void *ws, size_t ws_bytes,
+                             const float *xm_amax, edvr_stream_t stream) {
+  EDVR_REQUIRE(xm_amax != nullptr, "dcnv2_fwd_split: null magnitude bound");
+  return dcnv2_fwd_impl(x, offset, mask, weight, bias, y, B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, offset_bstride, mask_bstride, act,
+                        halo_hint, ws, ws_bytes, xm_amax, stream);
+}
+
+int edvr_dcnv2_fwd_split_applies(const float *x, int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil, int groups,
+                                 int dg, int halo_hint) {
+  using namespace edvr;
+  DcnShape s;
+  if (dcn_fill_shape(s, B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, 0, 0)) return 0;
+  return (use_fused(s) && halo_hint == EDVR_DCN_HALO_TAPWIN && dcn_tapwin_split_enabled() &&
+          dcn_tapwin_supported(C, Co, H, W, kh, kw, s.stride, s.pad, s.dil, groups, dg) && (reinterpret_cast<uintptr_t>(x) & 15) == 0) ? 1 : 0;
 }
 
 int edvr_dcnv2_fwd_kernel_name(const float *x, int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil, int groups,

@@ -148,8 +148,11 @@ def dcn_from_packed(m, x, om, act=ACT_NONE):
         return ag.DcnFromPackedFn.apply(x, om, m.weight, m.bias, (*cfg, act, hint, m))
     split = 2 * om.shape[1] // 3
     bias = m.bias.detach() if m.bias is not None else None
-    y = ops.dcnv2_forward(x, om[:, :split], om[:, split:], m.weight.detach(), bias, *cfg, act=act, halo_hint=hint)
-    if ops.F4S_INFERENCE:  # (masks are sigmoid outputs, bilinear taps convex combinations of x and the zero padding)
+    # masks are sigmoid outputs and bilinear taps convex combinations of x and the zero padding: a bound of |x| bounds the columns
+    # (-> the split-operand tap-window kernel) and, through the weights' norms, the output
+    xb = ops.input_bound(x) if (ops.F4S_INFERENCE and hint == ops.DCN_HALO_TAPWIN and tapwin_takes(x, m)) else None
+    y = ops.dcnv2_forward(x, om[:, :split], om[:, split:], m.weight.detach(), bias, *cfg, act=act, halo_hint=hint, xm_bound=xb)
+    if ops.F4S_INFERENCE:
         ops.linear_bound(y, m.weight, m.bias, (x,))
     return y
 

@@ -639,9 +639,11 @@ def _bstride(t):
     return t.stride(0) if t.shape[0] > 1 else 0
 
 
-def dcnv2_forward(x, offset, mask, weight, bias, stride, pad, dil, groups, dg, act=ACT_NONE, halo_hint=0, out=None):
+def dcnv2_forward(x, offset, mask, weight, bias, stride, pad, dil, groups, dg, act=ACT_NONE, halo_hint=0, out=None, xm_bound=None):
     """out: optional preallocated (B, Co, Ho, Wo) contiguous tensor the kernels write in place (the reference's `output` argument,
-    deform_conv_cuda.cpp:530-568)."""
+    deform_conv_cuda.cpp:530-568).
+    xm_bound: 1-element device tensor >= max |x| * max(1, max |mask|) (for sigmoid masks: a bound of |x|, `input_bound(x)`): allows the
+    split-operand form of the tap-window kernel (csrc/dcn_tapwin_s.hip) where that kernel applies; None = the fp32 kernels."""
     dt = require_gpu(x, offset, mask, weight, bias, dtypes=tuple(DCN_DTYPES))
     L = _lib.lib()
     if not x.is_contiguous() or not weight.is_contiguous():
@@ -677,13 +679,18 @@ def dcnv2_forward(x, offset, mask, weight, bias, stride, pad, dil, groups, dg, a
     nbytes = L.edvr_dcnv2_fwd_ws_bytes(*dims)
     ws = workspace(nbytes, x.device)
     name = 'dcnv2_fwd'
+    split = xm_bound is not None and bool(L.edvr_dcnv2_fwd_split_applies(_ptr(x), *dims, int(halo_hint)))
     if LAUNCH_HOOK is not None:  # measurement only (bench.py): which kernel class this call runs on
         buf = ctypes.create_string_buffer(64)
         if L.edvr_dcnv2_fwd_kernel_name(_ptr(x), *dims, int(halo_hint), buf, 64) == 0:
-            name = f'dcnv2_fwd[{buf.value.decode()}]'
-    _run(name, lambda: _lib.check(L.edvr_dcnv2_fwd_f32(_ptr(x), _ptr(offset), _ptr(mask), _ptr(weight), _ptr(bias), _ptr(y), *dims,
-                                    _bstride(offset), _bstride(mask), act, halo_hint, _ptr(ws), nbytes, _stream()),
-                                       'edvr_dcnv2_fwd_f32'), 2.0 * B * Co * Ho * Wo * weight.shape[1] * kh * kw, _nb(x, offset, mask, weight, y))
+            name = f'dcnv2_fwd[{"dcn_tapwin_split_fwd_kernel" if split else buf.value.decode()}]'
+    common = (_ptr(x), _ptr(offset), _ptr(mask), _ptr(weight), _ptr(bias), _ptr(y), *dims, _bstride(offset), _bstride(mask), act, halo_hint, _ptr(ws), nbytes)
+    if split:
+        require_gpu(xm_bound)
+        launch = lambda: _lib.check(L.edvr_dcnv2_fwd_split_f32(*common, _ptr(xm_bound), _stream()), 'edvr_dcnv2_fwd_split_f32')
+    else:
+        launch = lambda: _lib.check(L.edvr_dcnv2_fwd_f32(*common, _stream()), 'edvr_dcnv2_fwd_f32')
+    _run(name, launch, 2.0 * B * Co * Ho * Wo * weight.shape[1] * kh * kw, _nb(x, offset, mask, weight, y))
     return y
 
 

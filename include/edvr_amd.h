@@ -223,6 +223,18 @@ int edvr_dcnv2_fwd_f32(const float *x, const float *offset, const float *mask, c
                        int pad, int dil, int groups, int dg, int64_t offset_bstride, int64_t mask_bstride, int act,
                        int halo_hint, void *ws, size_t ws_bytes, edvr_stream_t stream);
 
+/* edvr_dcnv2_fwd_f32 with split fp32 operands on the f16 matrix pipe where the tap-window kernel applies (halo_hint EDVR_DCN_HALO_TAPWIN and
+ * its constraints; csrc/dcn_tapwin_s.hip: weights and sampled columns as f16 (hi, lo) pairs, all four cross products, fp32 accumulation -
+ * the fp32 kernel's result to within fp32 rounding at a quarter of its matrix-pipe time); identical to edvr_dcnv2_fwd_f32 everywhere
+ * else.  xm_amax: device pointer to ONE float >= max |x| * max(1, max |mask|) (an upper bound; DCNv2Pack's masks are sigmoid outputs, so a
+ * bound of |x| does).  edvr_dcnv2_fwd_split_applies: 1 if that kernel would run.  EDVR_DCN_SPLIT=0 switches it off.  Replaces the same
+ * reference code as edvr_dcnv2_fwd_f32 (deform_conv_cuda.cpp:490-569, deform_conv_cuda_kernel.cu:570-633). */
+int edvr_dcnv2_fwd_split_f32(const float *x, const float *offset, const float *mask, const float *weight, const float *bias,
+                             float *y, int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil, int groups,
+                             int dg, int64_t offset_bstride, int64_t mask_bstride, int act, int halo_hint, void *ws, size_t ws_bytes,
+                             const float *xm_amax, edvr_stream_t stream);
+int edvr_dcnv2_fwd_split_applies(const float *x, int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil, int groups,
+                                 int dg, int halo_hint);
 /* Name of the kernel edvr_dcnv2_fwd_f32 would launch for these arguments (as rocprofv3 prints it): dcn_tapwin_fwd_kernel,
  * dcn_fused_fwd_kernel or dcn_im2col_kernel (+ the conv kernel of its GEMM).  Measurement aid only. */
 int edvr_dcnv2_fwd_kernel_name(const float *x, int B, int C, int H, int W, int Co, int kh, int kw, int stride, int pad, int dil,

@@ -230,9 +230,14 @@ def test_tap_window_kernel_on_piecewise_constant_motion(gpu, geom, jump):
     assert _rel(y, ref) < FWD_RTOL
     dy = torch.randn(B, Co, H, W, generator=g)
     gref = O.c_backward(x.double(), off.double(), m.double(), w.double(), dy.double(), True, 1, 1, 1, 1, dg)
+    g32 = O.c_backward(x, off, m, w, dy, True, 1, 1, 1, 1, dg)  # (taps whose fp32 position rounds across an integer: excluded, as above)
     for scatter in (ops.DCN_SCATTER_AUTO, ops.DCN_SCATTER_LDS, ops.DCN_SCATTER_DEVICE):
         got = ops.dcnv2_backward(dev[0], dev[1], dev[2], dev[3], dy.to(gpu), True, 1, 1, 1, 1, dg, scatter_hint=scatter)
-        for name, a_, r_ in zip(('dx', 'doffset', 'dmask', 'dw', 'db'), got, gref):
+        for name, a_, r_, r32 in zip(('dx', 'doffset', 'dmask', 'dw', 'db'), got, gref, g32):
+            if name == 'doffset':
+                flip = (r32.double() - r_).abs() > 1e-3 * r_.abs().max()
+                assert flip.sum().item() <= 4, 'fp32 floor flips should be rare'
+                a_, r_ = a_.double().cpu().masked_fill(flip, 0.), r_.masked_fill(flip, 0.)
             assert _rel(a_, r_) < BWD_RTOL, (name, scatter, _rel(a_, r_))
 
 
@@ -336,3 +341,51 @@ def test_offset_statistics_kernels(gpu):
     assert F_.halo_hint_from_stats(3.0, 0.1) == ops.DCN_HALO_TAPWIN and F_.halo_hint_from_stats(51.0, 72.0) == -1
     assert F_.halo_hint_from_stats(None, None) == ops.DCN_HALO_TAPWIN and F_.halo_hint_from_stats(0.8, 1.1) == 7
     assert F_.scatter_hint_from_stats(3.0, 0.1) == ops.DCN_SCATTER_LDS and F_.scatter_hint_from_stats(0.2, 0.1) == ops.DCN_SCATTER_STRIP
+
+
+@pytest.mark.parametrize('case', TAPWIN_CASES)
+def test_split_tap_window_kernel_matches_oracle(gpu, case):
+    """csrc/dcn_tapwin_s.hip (weights and sampled columns as f16 (hi, lo) pairs on the f16 matrix pipe, all four cross products) on the
+    tap-window kernel's own cases, at the SAME tolerance against the C oracle in fp64, and not the less accurate of the two."""
+    from edvr_amd import ops
+    from oracle import dcn_oracle as O
+    B, C, H, W, Co, dg, sigma, outliers, act = case
+    g = torch.Generator().manual_seed(1000 + TAPWIN_CASES.index(case))
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(Co, C, 3, 3, generator=g) * 0.1
+    b = torch.randn(Co, generator=g)
+    off = _smooth_field(B, dg, H, W, sigma, g, outliers=outliers)
+    m = torch.rand(B, dg * 9, H, W, generator=g)
+    ref = O.c_forward(x.double(), off.double(), m.double(), w.double(), b.double(), 1, 1, 1, 1, dg)
+    if act == 2:
+        ref = torch.nn.functional.leaky_relu(ref, 0.1)
+    elif act == 1:
+        ref = torch.relu(ref)
+    dev = [t.to(gpu) for t in (x, off, m, w, b)]
+    bound = ops.amax(dev[0])
+    names = []
+    ops.LAUNCH_HOOK = lambda name, flops, launch, nbytes, executed=None: (names.append(name), launch())
+    try:
+        y = ops.dcnv2_forward(*dev, 1, 1, 1, 1, dg, act=act, halo_hint=ops.DCN_HALO_TAPWIN, xm_bound=bound)
+    finally:
+        ops.LAUNCH_HOOK = None
+    y32 = ops.dcnv2_forward(*dev, 1, 1, 1, 1, dg, act=act, halo_hint=ops.DCN_HALO_TAPWIN)
+    if dg <= 8:
+        assert names == ['dcnv2_fwd[dcn_tapwin_split_fwd_kernel]'], names
+    assert _rel(y, ref) < FWD_RTOL, _rel(y, ref)
+    assert _rel(y, ref) < 1.5 * _rel(y32, ref) + 2e-7, (_rel(y, ref), _rel(y32, ref))
+
+
+@pytest.mark.parametrize('scale', [1e-20, 1e-3, 1.0, 1e4, 1e20])
+def test_split_tap_window_kernel_is_scale_invariant(gpu, scale):
+    from edvr_amd import ops
+    from oracle import dcn_oracle as O
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(1, 128, 16, 64, generator=g) * scale
+    w = torch.randn(128, 128, 3, 3, generator=g) * 0.1
+    off = _piecewise_field(1, 8, 16, 64, 6.0, g)
+    m = torch.rand(1, 72, 16, 64, generator=g)
+    ref = O.c_forward(x.double(), off.double(), m.double(), w.double(), None, 1, 1, 1, 1, 8)
+    dev = [t.to(gpu) for t in (x, off, m, w)]
+    y = ops.dcnv2_forward(*dev, None, 1, 1, 1, 1, 8, halo_hint=ops.DCN_HALO_TAPWIN, xm_bound=ops.amax(dev[0]))
+    assert torch.isfinite(y).all() and _rel(y, ref) < FWD_RTOL, _rel(y, ref)
