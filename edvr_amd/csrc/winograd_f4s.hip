@@ -356,26 +356,36 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
           const float b = bias_s[co - e_co_blk];
           const float sl = co >= d.act_from ? slope : 1.f;
           f32x4 Y[4];
+          // A^T along the rows (6 -> 4) on PACKED fp32 pairs of columns (the matrix pipe is idle during the output pass, and the lone
+          // staging wave of a SIMD pays per instruction, not per lane-operation); the operand scales leave in the bias fma
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {  // A^T along the rows (6 -> 4); the operand scales leave in the bias fma
-            const float s1 = T[1][jj] + T[2][jj], d1 = T[1][jj] - T[2][jj], s2 = T[3][jj] + T[4][jj], d2 = T[3][jj] - T[4][jj];
-            Y[0][jj] = __builtin_fmaf(T[0][jj] + s1 + s2, unscale, b);
-            Y[1][jj] = __builtin_fmaf(__builtin_fmaf(2.f, d2, d1), unscale, b);
-            Y[2][jj] = __builtin_fmaf(__builtin_fmaf(4.f, s2, s1), unscale, b);
-            Y[3][jj] = __builtin_fmaf(__builtin_fmaf(8.f, d2, d1) + T[5][jj], unscale, b);
-          }
-          if (sig) {
-            if (co >= d.act_from) {
-#pragma unroll
-              for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) Y[i][jj] = __builtin_amdgcn_rcpf(1.f + __expf(-Y[i][jj]));
+          for (int jp = 0; jp < 2; ++jp) {
+            auto col2 = [&](int r) { return f32x2{T[r][2 * jp], T[r][2 * jp + 1]}; };
+            const f32x2 t0 = col2(0), t1 = col2(1), t2 = col2(2), t3 = col2(3), t4 = col2(4), t5 = col2(5);
+            const f32x2 s1 = t1 + t2, d1 = t1 - t2, s2 = t3 + t4, d2 = t3 - t4;
+            const f32x2 us = f32x2{unscale, unscale}, bb = f32x2{b, b};
+            f32x2 y0 = (t0 + s1 + s2) * us + bb;
+            f32x2 y1 = (2.f * d2 + d1) * us + bb;
+            f32x2 y2 = (4.f * s2 + s1) * us + bb;
+            f32x2 y3 = (8.f * d2 + d1 + t5) * us + bb;
+            if (!sig) {  // none / relu / lrelu = max(v, slope * v): one packed multiply + two v_max_f32 per pair
+              const f32x2 sl2 = f32x2{sl, sl};
+              const f32x2 z0 = y0 * sl2, z1 = y1 * sl2, z2 = y2 * sl2, z3 = y3 * sl2;
+              y0 = f32x2{max_raw_s(y0[0], z0[0]), max_raw_s(y0[1], z0[1])};
+              y1 = f32x2{max_raw_s(y1[0], z1[0]), max_raw_s(y1[1], z1[1])};
+              y2 = f32x2{max_raw_s(y2[0], z2[0]), max_raw_s(y2[1], z2[1])};
+              y3 = f32x2{max_raw_s(y3[0], z3[0]), max_raw_s(y3[1], z3[1])};
             }
-          } else {
+            Y[0][2 * jp] = y0[0]; Y[0][2 * jp + 1] = y0[1];
+            Y[1][2 * jp] = y1[0]; Y[1][2 * jp + 1] = y1[1];
+            Y[2][2 * jp] = y2[0]; Y[2][2 * jp + 1] = y2[1];
+            Y[3][2 * jp] = y3[0]; Y[3][2 * jp + 1] = y3[1];
+          }
+          if (sig && co >= d.act_from) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-              for (int jj = 0; jj < 4; ++jj) Y[i][jj] = max_raw_s(Y[i][jj], sl * Y[i][jj]);
+              for (int jj = 0; jj < 4; ++jj) Y[i][jj] = __builtin_amdgcn_rcpf(1.f + __expf(-Y[i][jj]));
           }
           if (SHF) {
             prefetch(min(p + 1, 7));
