@@ -363,7 +363,7 @@ def test_edvr_parameter_gradients_with_multi_pixel_offsets(gpu, name, hint_wait,
 
     monkeypatch.setattr(ops, 'LAUNCH_HOOK', hook)
     _followed_gradient_check(gpu, name, bias_sigma=4.0)
-    assert any('dcn_tapwin_fwd_kernel' in n for n in launches), sorted(set(launches))
+    assert any('dcn_tapwin' in n for n in launches), sorted(set(launches))  # (fp32 or split-operand form of the tap-window kernel)
 
 
 def _followed_gradient_check(gpu, name, bias_sigma=0.5):
