@@ -92,7 +92,9 @@ WINOGRAD = ('conv3x3_winograd_kernel', 'conv3x3_winograd_wgrad_kernel')  # execu
 WINOGRAD_F4 = ('conv3x3_winograd_f4_kernel',)  # F(4x4,3x3): 36 instead of 144 multiplies per 4x4 tile
 # the split-operand forms (fp32 operands as f16 (hi, lo) pairs on the f16 matrix pipe, 4 cross products, fp32 accumulate): the matrix
 # pipe is no longer what bounds them - the table carries their algorithmic HBM rate AND their share of the f16 matrix peak
-SPLIT_KERNELS = ('conv3x3_winograd_f4s_kernel', 'conv3x3_winograd_wgrad_split_kernel')
+SPLIT_KERNELS = ('conv3x3_winograd_f4s_kernel', 'conv3x3_winograd_wgrad_split_kernel', 'dcnv2_fwd[dcn_tapwin_split_fwd_kernel]')
+# multiplies the algorithm saves against the direct one (F(4x4): 4, F(2x2): 2.25, the DCN GEMM: none); each remaining fp32 product = 4 f16 ones
+SPLIT_SAVING = {'conv3x3_winograd_f4s_kernel': 4.0, 'conv3x3_winograd_wgrad_split_kernel': 2.25, 'dcnv2_fwd[dcn_tapwin_split_fwd_kernel]': 1.0}
 DTYPE = ('f32 (3x3 / stride-1 convs and their weight gradients multiply SPLIT fp32 operands - f16 (hi, lo) pairs, all four cross products - on '
          'the f16 matrix pipe with fp32 accumulation: the fp32 result to within fp32 rounding; everything else fp32 MFMA / VALU).  '
          '`fp32_mfma` beside it = the same run with those kernels on the fp32 matrix pipe')
@@ -171,10 +173,9 @@ def _is_split(name):
 
 def _executed(name, flops):
     """Padding-free executed flops from the algorithmic count: what the algorithm needs on exactly-fitting tiles."""
-    if name.startswith('conv3x3_winograd_f4s_kernel'):
-        return flops  # F(4x4) issues 1/4 of the multiplies, each as 4 f16 cross products
-    if name.startswith('conv3x3_winograd_wgrad_split_kernel'):
-        return flops / 2.25 * 4.0
+    for k, saving in SPLIT_SAVING.items():
+        if name.startswith(k):
+            return flops / saving * 4.0  # f16 flops: every fp32 product the algorithm needs = four f16 cross products
     if name.startswith(WINOGRAD_F4):
         return flops / 4.0
     return flops / 2.25 if name.startswith(WINOGRAD) else flops
@@ -194,7 +195,7 @@ def kernel_table(per, steps, step_seconds):
             row.update(bound='hbm', hbm_gbps=round(gbps, 1), frac_of_hbm_peak=round(gbps / PEAK_HBM_GBPS, 4),
                        f16_mfma_tflops_issued=round(executed / secs / 1e12, 2), frac_of_f16_mfma_peak=round(executed / secs / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
                        tflops_algorithmic=round(flops / secs / 1e12, 2),
-                       equivalent_fp32_mfma_frac=round(flops / (4.0 if 'f4s' in name else 2.25) / secs / 1e12 / PEAK_F32_MFMA_TFLOPS, 4))
+                       equivalent_fp32_mfma_frac=round(flops / [v for k, v in SPLIT_SAVING.items() if name.startswith(k)][0] / secs / 1e12 / PEAK_F32_MFMA_TFLOPS, 4))
         elif _is_mfma(name) and flops > 0:
             ex, useful = executed / secs / 1e12, _executed(name, flops) / secs / 1e12
             # frac_of_mfma_peak counts the USEFUL matrix-core flops (no padded tiles / channels); the issued ones are beside it
@@ -246,7 +247,7 @@ def split_roofline_object(per, name, steps, step_seconds, workload, default_batc
         'f16_mfma': {'tflops_issued': round(executed / secs / 1e12, 2), 'peak': PEAK_F16_MFMA_TFLOPS, 'frac': round(executed / secs / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
                      'what': 'v_mfma_f32_32x32x16_f16 issues x 32768 flops (padding included): four f16 cross products per fp32 product of '
                              'F(4x4) - the fp32 kernel needs 4x this pipe time on a pipe 16x slower'},
-        'equivalent_fp32_mfma_frac': round(flops / 4.0 / secs / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+        'equivalent_fp32_mfma_frac': round(flops / [v for k, v in SPLIT_SAVING.items() if name.startswith(k)][0] / secs / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
         'limiter': 'neither roofline: per 8-channel chunk a CU takes in 74 KB of weights (no reuse inside a CU: 36 accumulators per output '
                    'fill the register file at 64 channels x 32 tiles) + 25 KB of input rows from L2; measured 22-25 B/clk/CU with the texture '
                    'addresser busy 63 % of the time and the staging / multiplying waves stalled on it (profiles/r5)',

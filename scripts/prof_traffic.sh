@@ -7,8 +7,8 @@ OUT=$R/gpurun_out/$NAME
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -o b -- python $R/bench.py --no-cpu-baseline --no-stock-baseline --no-train-leg --no-batch4 --no-target-4k --no-trained-like --no-configs --no-roofline --steps 1 --warmup 1 "$@" > $OUT/$c.log 2>&1
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/calib_$c -o c -- python $R/scripts/traffic_calib.py > $OUT/calib_$c.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -o b -- python $R/bench.py --no-cpu-baseline --no-stock-baseline --no-train-leg --no-batch4 --no-target-4k --no-trained-like --no-configs --no-fp32-leg --no-roofline --steps 1 --warmup 1 "$@" > $OUT/$c.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/calib_$c -o c -- python $R/scripts/traffic_calib.py > $OUT/calib_$c.log 2>&1
 done
 F=$(ls $OUT/FETCH_SIZE/*counter_collection.csv); W=$(ls $OUT/WRITE_SIZE/*counter_collection.csv)
 CF=$(ls $OUT/calib_FETCH_SIZE/*counter_collection.csv); CW=$(ls $OUT/calib_WRITE_SIZE/*counter_collection.csv)
