@@ -66,6 +66,8 @@ PROTOTYPES = {
     'edvr_dcnv1_bwd_ws_bytes': (sz, [i32] * 12),
     'edvr_dcnv1_bwd_f32': (i32, [vp] * 7 + [i32] * 12 + [i64, i64, i32, vp, sz, vp]),
     'edvr_dcnv2_bwd_f32': (i32, [vp] * 10 + [i32] * 12 + [i64, i64, i64, i64, i32, vp, sz, vp]),
+    'edvr_dcnv2_bwd_split_f32': (i32, [vp] * 10 + [i32] * 12 + [i64, i64, i64, i64, i32, vp, sz, vp, vp, vp]),
+    'edvr_dcnv2_bwd_split_applies': (i32, []),
     'edvr_tsa_temporal_f32': (i32, [vp] * 5 + [i32] * 4 + [vp]),
     'edvr_pool_maxavg_3x3s2_f32': (i32, [vp, vp, i32, i32, i32, i32, vp]),
     'edvr_upsample2x_f32': (i32, [vp, vp, i32, i32, i32, f32, vp]),

@@ -145,6 +145,7 @@ class DcnFromPackedFn(Function):
         ctx.save_for_backward(x, om, weight, out if act != ACT_NONE else None)
         ctx.cfg = cfg
         ctx.with_bias = bias is not None
+        ctx.xm_bound = (xb if xb is not None else ops.get_bound(x)) if ops.F4S_TRAINING else None  # for the split dW product of the backward
         return out
 
     @staticmethod
@@ -158,8 +159,10 @@ class DcnFromPackedFn(Function):
             dy = ops.act_backward(dy, out, act)
         split = 2 * om.shape[1] // 3
         dom = torch.empty_like(om)
+        xb = ctx.xm_bound
         dx, _, _, dw, db = ops.dcnv2_backward(x, om[:, :split], om[:, split:], weight, dy, ctx.with_bias, stride, padding, dilation,
-                                              groups, dg, doffset=dom[:, :split], dmask=dom[:, split:], scatter_hint=scatter)
+                                              groups, dg, doffset=dom[:, :split], dmask=dom[:, split:], scatter_hint=scatter,
+                                              xm_bound=xb, dy_bound=ops.input_bound(dy) if xb is not None else None)
         return dx, dom, dw, db, None
 
 

@@ -37,6 +37,11 @@ int gemm_nt_launch(const float *A, const float *B, float *C, int M, int N, int64
 size_t gemm_nt_ws_elems_b(int M, int N, int64_t K, int nb);
 int gemm_nt_batched(const float *A, const float *B, float *C, int M, int N, int64_t K, int64_t lda, int64_t ldb, int nb, int64_t a_bs,
                     int64_t b_bs, bool accumulate, float *ws, hipStream_t stream);
+// gemm_nt_s.hip: the same product with split fp32 operands on the f16 matrix pipe (same splits / workspace); a_amax / b_amax = device
+// pointers to one float >= max |A| / max |B|.  gemm_nt_split_enabled: EDVR_GEMM_SPLIT != 0
+bool gemm_nt_split_enabled();
+int gemm_nt_split_batched(const float *A, const float *B, float *C, int M, int N, int64_t K, int64_t lda, int64_t ldb, int nb, int64_t a_bs,
+                          int64_t b_bs, bool accumulate, float *ws, const float *a_amax, const float *b_amax, hipStream_t stream);
 
 // winograd.hip: F(2x2,3x3) path of the 3x3 / stride-1 convolution.  U (transformed weights, [ci_pad][16][round_up(co,64)])
 // follows the direct packed layout inside the buffer edvr_conv2d_pack_weight_f32 fills.

@@ -793,11 +793,13 @@ int edvr_dcnv2_fwd_kernel_name(const float *x, int B, int C, int H, int W, int C
   return EDVR_OK;
 }
 
-int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, const float *weight, const float *dy, float *dx,
-                       float *doffset, float *dmask, float *dweight, float *dbias, int B, int C, int H, int W, int Co, int kh,
-                       int kw, int stride, int pad, int dil, int groups, int dg, int64_t offset_bstride, int64_t mask_bstride,
-                       int64_t doffset_bstride, int64_t dmask_bstride, int scatter_hint, void *ws, size_t ws_bytes,
-                       edvr_stream_t stream_) {
+// xm_amax / dy_amax (both or neither): device pointers to ONE float >= max |x| * max(1, max |mask|) and >= max |dy| - the dW product
+// then runs in its split-operand form (gemm_nt_s.hip)
+static int dcnv2_bwd_impl(const float *x, const float *offset, const float *mask, const float *weight, const float *dy, float *dx,
+                          float *doffset, float *dmask, float *dweight, float *dbias, int B, int C, int H, int W, int Co, int kh,
+                          int kw, int stride, int pad, int dil, int groups, int dg, int64_t offset_bstride, int64_t mask_bstride,
+                          int64_t doffset_bstride, int64_t dmask_bstride, int scatter_hint, void *ws, size_t ws_bytes,
+                          const float *xm_amax, const float *dy_amax, edvr_stream_t stream_) {
   using namespace edvr;
   EDVR_REQUIRE(x && offset && mask && weight && dy && dx && doffset && dmask && dweight, "dcnv2_bwd: null pointer");
   DcnShape s;
@@ -882,8 +884,11 @@ int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, c
   }
   // 3. dW[g] = sum_{b,p} dY[b, g] col[b, g]^T ; db = sum dY
   for (int g = 0; g < groups; ++g) {
-    rc = gemm_nt_batched(dy + (int64_t)g * cog * P, col + (int64_t)g * cig * K * P, dweight + (size_t)g * cog * cig * K, cog, cig * K, P,
-                         P, P, B, (int64_t)Co * P, (int64_t)C * K * P, false, gws, stream);
+    rc = (xm_amax && dy_amax && gemm_nt_split_enabled())
+             ? gemm_nt_split_batched(dy + (int64_t)g * cog * P, col + (int64_t)g * cig * K * P, dweight + (size_t)g * cog * cig * K, cog, cig * K,
+                                     P, P, P, B, (int64_t)Co * P, (int64_t)C * K * P, false, gws, dy_amax, xm_amax, stream)
+             : gemm_nt_batched(dy + (int64_t)g * cog * P, col + (int64_t)g * cig * K * P, dweight + (size_t)g * cog * cig * K, cog, cig * K, P,
+                               P, P, B, (int64_t)Co * P, (int64_t)C * K * P, false, gws, stream);
     if (rc) return rc;
   }
   if (dbias) {  // db = sum over (image, pixel) of dY: the conv layers' bias-gradient kernel (gws is free again here)
@@ -892,6 +897,27 @@ int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, c
   }
   return EDVR_OK;
 }
+
+int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, const float *weight, const float *dy, float *dx,
+                       float *doffset, float *dmask, float *dweight, float *dbias, int B, int C, int H, int W, int Co, int kh,
+                       int kw, int stride, int pad, int dil, int groups, int dg, int64_t offset_bstride, int64_t mask_bstride,
+                       int64_t doffset_bstride, int64_t dmask_bstride, int scatter_hint, void *ws, size_t ws_bytes,
+                       edvr_stream_t stream) {
+  return dcnv2_bwd_impl(x, offset, mask, weight, dy, dx, doffset, dmask, dweight, dbias, B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg,
+                        offset_bstride, mask_bstride, doffset_bstride, dmask_bstride, scatter_hint, ws, ws_bytes, nullptr, nullptr, stream);
+}
+
+int edvr_dcnv2_bwd_split_f32(const float *x, const float *offset, const float *mask, const float *weight, const float *dy, float *dx,
+                             float *doffset, float *dmask, float *dweight, float *dbias, int B, int C, int H, int W, int Co, int kh,
+                             int kw, int stride, int pad, int dil, int groups, int dg, int64_t offset_bstride, int64_t mask_bstride,
+                             int64_t doffset_bstride, int64_t dmask_bstride, int scatter_hint, void *ws, size_t ws_bytes,
+                             const float *xm_amax, const float *dy_amax, edvr_stream_t stream) {
+  EDVR_REQUIRE(xm_amax && dy_amax, "dcnv2_bwd_split: null magnitude bound");
+  return dcnv2_bwd_impl(x, offset, mask, weight, dy, dx, doffset, dmask, dweight, dbias, B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg,
+                        offset_bstride, mask_bstride, doffset_bstride, dmask_bstride, scatter_hint, ws, ws_bytes, xm_amax, dy_amax, stream);
+}
+
+int edvr_dcnv2_bwd_split_applies(void) { return edvr::gemm_nt_split_enabled() ? 1 : 0; }
 
 
 // ------------------------------------------------------------------------------------------------ DCNv1 (DeformConv)

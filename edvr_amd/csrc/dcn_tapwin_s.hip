@@ -6,9 +6,11 @@
 // (hi, lo) pairs (winograd_f4s.hip) and all four cross products are accumulated in fp32 by v_mfma_f32_32x32x16_f16.
 //   * weights: packed once per call as [channel quad][tap][co'][4 channels] dwords (hi | lo << 16) of w * s_W behind a 64-byte header
 //     (s_W from max |w|): a lane's A operand - four channels x (hi, lo) of its output channel - is ONE ds_read_b128 of the slab;
-//   * columns: the lane samples the FOUR channels 8 kg + 4 half + i of a K-group for its pixel (bilinear weights x mask x s_X, four
+//   * columns: the lane samples the FOUR channels 8 kg + 2 i + half of a K-group for its pixel (bilinear weights x mask x s_X, four
 //     FMAs per sample as before), splits them (2 instructions each) -> the B operand; the second MFMA of a pair takes B rotated by
-//     16 bits ((lo, hi): the cross terms).  s_X from `xm_amax`, an upper bound of max |x| * max(1, max |mask|).
+//     16 bits ((lo, hi): the cross terms).  s_X from `xm_amax`, an upper bound of max |x| * max(1, max |mask|).  (Interleaved, not
+//     4 half + i: the half-waves of a gather are then ONE channel = 480 floats = 32 banks apart and use disjoint halves of the 64
+//     LDS banks; four channels apart (0 mod 64) every cell read was a two-way conflict - 54 % of the LDS-active cycles.)
 // Per step and wave 32 MFMAs of 32 cycles where the fp32 kernel issues 64 of 64: a quarter of the matrix-pipe time.
 #include <type_traits>
 
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void dcn_tapwin_split_fwd_kernel(const DcnT
     st.bw[s][1] = hm * lw;
     st.bw[s][2] = lm * hw;
     st.bw[s][3] = lm * lw;
-    st.addr[s] = 4 * half * CHS + (inside ? ry * IW + rx : 0);  // this lane samples channels 8 kg + 4 half + (0..3)
+    st.addr[s] = half * CHS + (inside ? ry * IW + rx : 0);  // this lane samples channels 8 kg + 2 (0..3) + half
     st.slow = (s ? st.slow : 0u) | ((valid && !inside) ? 1u << s : 0u);
   };
   auto state_any = [&](St &st) { st.slow_any = __builtin_amdgcn_readfirstlane(__any(st.slow != 0) ? 1 : 0); };
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void dcn_tapwin_split_fwd_kernel(const DcnT
         asm volatile("" : "+v"(co));  // (one base register per sub-tile: the channel offsets stay immediates)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          lds_cf *cell = (lds_cf *)(size_t)(co + (kg * 8 + i) * (CHS * 4));
+          lds_cf *cell = (lds_cf *)(size_t)(co + (kg * 8 + 2 * i) * (CHS * 4));
           c[s][i][0] = cell[0];
           c[s][i][1] = cell[1];
           c[s][i][2] = cell[IW];
@@ -310,8 +312,8 @@ __global__ __launch_bounds__(256, 2) void dcn_tapwin_split_fwd_kernel(const DcnT
                            s1 * __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, o1, so, 0)) +
                            s2 * __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, o2, so, 0)) +
                            s3 * __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, o3, so, 0));
-          const int c = 2 * q + half;  // this lane's channel of the pair: quad c >> 2, slot c & 3
-          const unsigned *ap = wb + (((c >> 2) * MB + j * MT) * 4 + (c & 3));
+          // this lane's channel of the pair, 2 q + half = 8 kg + 2 i + half: quad 2 kg + half, slot i
+          const unsigned *ap = wb + (((2 * (q >> 2) + half) * MB + j * MT) * 4 + (q & 3));
 #pragma unroll
           for (int m2 = 0; m2 < MT; ++m2) {
             const f16x2t pr = __builtin_bit_cast(f16x2t, ap[m2 * 4]);
@@ -482,7 +484,7 @@ __global__ void dcn_tapwin_split_pack_kernel(const float *__restrict__ w, unsign
     const int r = pos - start, j = r / mt, m = r - j * mt, co = start + m * 32 + j;
     const bool live = mt > 0 && j < 32 && co < Co;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) wpk[16 + i * 4 + q] = live ? split_f16x2(w[((int64_t)co * C + 4 * c4 + q) * 9 + t], s_w) : 0u;
+    for (int q = 0; q < 4; ++q) wpk[16 + i * 4 + q] = live ? split_f16x2(w[((int64_t)co * C + 8 * (c4 >> 1) + 2 * q + (c4 & 1)) * 9 + t], s_w) : 0u;  // quad 2 kg + half, slot q = channel 8 kg + 2 q + half
   }
 }
 

@@ -355,8 +355,12 @@ static int wgrad_impl(const float *x1, const float *x2, const float *dz, float *
     // 1x1: dW[co, ci] = sum over images and pixels of dz[co, p] x[ci, p] is the K-contiguous "NT" product the DCN backward uses
     // for its dW (128 x 128 tiles, 4 accumulator tiles per wave, 98 TF/s); the strip kernel below has ONE tile per wave and two
     // barriers per 32 MFMAs for a 1x1 kernel (40 TF/s)
-    int rc = gemm_nt_batched(dz, x1, dw, co, ci, (int64_t)h * w, (int64_t)h * w, (int64_t)h * w, n, dz_img_stride, x1_img_stride, accumulate != 0,
-                             a.ws, stream);
+    // (with bounds of both tensors: its split-operand form, gemm_nt_s.hip)
+    int rc = (x_amax && dz_amax && gemm_nt_split_enabled())
+                 ? gemm_nt_split_batched(dz, x1, dw, co, ci, (int64_t)h * w, (int64_t)h * w, (int64_t)h * w, n, dz_img_stride, x1_img_stride,
+                                         accumulate != 0, a.ws, dz_amax, x_amax, stream)
+                 : gemm_nt_batched(dz, x1, dw, co, ci, (int64_t)h * w, (int64_t)h * w, (int64_t)h * w, n, dz_img_stride, x1_img_stride,
+                                   accumulate != 0, a.ws, stream);
     if (rc || !dbias) return rc;
     return edvr_channel_sum_f32(dz, dbias, n, co, (int64_t)a.ho * a.wo, dz_img_stride, ws, ws_bytes, stream_);
   }
@@ -411,6 +415,7 @@ int edvr_conv2d_wgrad_split_f32(const float *x1, const float *x2, const float *d
 int edvr_conv2d_wgrad_split_applies(int n, int c1, int c2, int h, int w, int co, int ks, int stride) {
   int splits = 0, ssplits = 0;
   if (edvr::winograd_wgrad_get_algo() == EDVR_CONV_AUTO && edvr::wgrad_small_plan(n, c1, c2, h, w, co, ks, stride, &ssplits)) return 0;
+  if (ks == 1 && c2 == 0 && edvr::winograd_wgrad_get_algo() == EDVR_CONV_AUTO) return edvr::gemm_nt_split_enabled() ? 1 : 0;  // the 1x1 GEMM
   return (edvr::winograd_wgrad_split_enabled() && edvr::winograd_wgrad_plan(n, c1, c2, h, w, co, ks, stride, &splits)) ? 1 : 0;
 }
 

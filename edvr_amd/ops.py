@@ -695,9 +695,11 @@ def dcnv2_forward(x, offset, mask, weight, bias, stride, pad, dil, groups, dg, a
 
 
 def dcnv2_backward(x, offset, mask, weight, dy, with_bias, stride, pad, dil, groups, dg, doffset=None, dmask=None,
-                   scatter_hint=0):
+                   scatter_hint=0, xm_bound=None, dy_bound=None):
     """Returns (dx, doffset, dmask, dweight, dbias).  `doffset` / `dmask` may be preallocated channel slices of one
-    buffer (image-strided views): the kernels write them in place."""
+    buffer (image-strided views): the kernels write them in place.
+    xm_bound / dy_bound (both or neither): 1-element device tensors >= max |x| * max(1, max |mask|) and >= max |dy| - the dW product
+    then runs in its split-operand form (csrc/gemm_nt_s.hip)."""
     dt = require_gpu(x, offset, mask, weight, dy, dtypes=tuple(DCN_DTYPES))
     L = _lib.lib()
     offset, mask = _as_planes(offset), _as_planes(mask)
@@ -718,10 +720,15 @@ def dcnv2_backward(x, offset, mask, weight, dy, with_bias, stride, pad, dil, gro
         return dx, doff, dmsk, dw, db
     nbytes = L.edvr_dcnv2_bwd_ws_bytes(*dims)
     ws = workspace(nbytes, x.device)
-    _run('dcnv2_bwd' + _SCATTER_NAMES.get(int(scatter_hint), ''), lambda: _lib.check(L.edvr_dcnv2_bwd_f32(_ptr(x), _ptr(offset), _ptr(mask), _ptr(weight), _ptr(dy), _ptr(dx), _ptr(doff), _ptr(dmsk),
-                                    _ptr(dw), _ptr(db), *dims, _bstride(offset), _bstride(mask), _bstride(doff), _bstride(dmsk),
-                                    int(scatter_hint), _ptr(ws), nbytes, _stream()),
-                                       'edvr_dcnv2_bwd_f32'), 4.0 * dy.numel() * weight[0].numel(), _nb(x, offset, mask, weight, dy, dx, doff, dmsk, dw))
+    common = (_ptr(x), _ptr(offset), _ptr(mask), _ptr(weight), _ptr(dy), _ptr(dx), _ptr(doff), _ptr(dmsk), _ptr(dw), _ptr(db), *dims,
+              _bstride(offset), _bstride(mask), _bstride(doff), _bstride(dmsk), int(scatter_hint), _ptr(ws), nbytes)
+    if xm_bound is not None and dy_bound is not None and L.edvr_dcnv2_bwd_split_applies():
+        require_gpu(xm_bound, dy_bound)
+        launch = lambda: _lib.check(L.edvr_dcnv2_bwd_split_f32(*common, _ptr(xm_bound), _ptr(dy_bound), _stream()), 'edvr_dcnv2_bwd_split_f32')
+    else:
+        launch = lambda: _lib.check(L.edvr_dcnv2_bwd_f32(*common, _stream()), 'edvr_dcnv2_bwd_f32')
+    _run('dcnv2_bwd' + _SCATTER_NAMES.get(int(scatter_hint), ''), launch, 4.0 * dy.numel() * weight[0].numel(),
+         _nb(x, offset, mask, weight, dy, dx, doff, dmsk, dw))
     return dx, doff, dmsk, dw, db
 
 
@@ -850,11 +857,17 @@ def conv2d_wgrad(x1, x2, x2_map, dz, co, ks, stride, want_db=False):
     ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
     common = (_ptr(x1), _ptr(x2), _ptr(dz), _ptr(dw), c1, c2, n, h, w, co, ks, stride, _img_stride(x1), _img_stride(x2) if x2 is not None else 0,
               div, mul, add, _img_stride(dz), 0, _ptr(db), _ptr(ws), nbytes)
-    if split:
+    if split and ks == 1:  # the 1x1 GEMM is too cheap to pay for a reduction pass: split only with both bounds at hand
+        bx, bz = get_bound(x1_in), get_bound(dz_in)
+        split = bx is not None and bz is not None
+        if split and name == 'gemm_nt_kernel':
+            name = 'gemm_nt_split_kernel'
+    elif split:
         bx = input_bound(x1_in, x1)
         if x2 is not None:
             bx = torch.maximum(bx, input_bound(x2_in, x2))
         bz = input_bound(dz_in, dz)
+    if split:
         launch = lambda: _lib.check(L.edvr_conv2d_wgrad_split_f32(*common, _ptr(bx), _ptr(bz), _stream()), 'edvr_conv2d_wgrad_split_f32')
     else:
         launch = lambda: _lib.check(L.edvr_conv2d_wgrad_f32(*common, _stream()), 'edvr_conv2d_wgrad_f32')

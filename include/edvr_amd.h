@@ -249,6 +249,17 @@ int edvr_dcnv2_bwd_f32(const float *x, const float *offset, const float *mask, c
                        int W, int Co, int kh, int kw, int stride, int pad, int dil, int groups, int dg,
                        int64_t offset_bstride, int64_t mask_bstride, int64_t doffset_bstride, int64_t dmask_bstride,
                        int scatter_hint, void *ws, size_t ws_bytes, edvr_stream_t stream);
+/* The same with magnitude bounds: xm_amax / dy_amax = device pointers to ONE float >= max |x| * max(1, max |mask|) and >= max |dy|
+ * (upper BOUNDS, as edvr_conv2d_desc.x_amax).  dW = sum dY col^T (deform_conv_cuda.cpp:664-672) then runs with both operands as f16
+ * (hi, lo) pairs on the f16 matrix pipe (csrc/gemm_nt_s.hip): the fp32 result to within fp32 rounding.  Everything else is
+ * edvr_dcnv2_bwd_f32.  edvr_dcnv2_bwd_split_applies: 1 unless EDVR_GEMM_SPLIT=0. */
+int edvr_dcnv2_bwd_split_f32(const float *x, const float *offset, const float *mask, const float *weight, const float *dy,
+                             float *dx, float *doffset, float *dmask, float *dweight, float *dbias, int B, int C, int H,
+                             int W, int Co, int kh, int kw, int stride, int pad, int dil, int groups, int dg,
+                             int64_t offset_bstride, int64_t mask_bstride, int64_t doffset_bstride, int64_t dmask_bstride,
+                             int scatter_hint, void *ws, size_t ws_bytes, const float *xm_amax, const float *dy_amax,
+                             edvr_stream_t stream);
+int edvr_dcnv2_bwd_split_applies(void);
 /* scatter_hint (performance only, like halo_hint of the forward; results are the same up to the summation order of dx):
  * how the four corner contributions per (pixel, tap, channel) are accumulated into dx.
  *   EDVR_DCN_SCATTER_DEVICE (1): fp32 device atomics straight to dx, as the reference's col2im (.cu:688).  Fastest when the

@@ -390,3 +390,61 @@ def test_split_tap_window_kernel_is_scale_invariant(gpu, scale):
     dev = [t.to(gpu) for t in (x, off, m, w)]
     y = ops.dcnv2_forward(*dev, None, 1, 1, 1, 1, 8, halo_hint=ops.DCN_HALO_TAPWIN, xm_bound=ops.amax(dev[0]))
     assert torch.isfinite(y).all() and _rel(y, ref) < FWD_RTOL, _rel(y, ref)
+
+
+# ---- the dW product of the backward with split operands (csrc/gemm_nt_s.hip): every case of the backward's own test, dW against
+#      the fp64 oracle at the fp32 kernel's tolerance and no further from it than the fp32 kernel is
+@pytest.mark.parametrize('case', CASES)
+def test_backward_split_dw_matches_oracle(gpu, case):
+    from edvr_amd import ops
+    from oracle import dcn_oracle as O
+    *dims, kw = case
+    B, C, H, W, Co, k, stride, pad, dil, groups, dg, sigma = dims
+    x, off, m, w, b, dy = _mk(*dims, seed=len(str(case)) + 5, **kw)
+    cfg = (stride, pad, dil, groups, dg)
+    ref = O.c_backward(x.double(), off.double(), m.double(), w.double(), dy.double(), True, *cfg)
+    xg, og, mg, wg, dyg = (t.to(gpu) for t in (x, off, m, w, dy))
+    g32 = ops.dcnv2_backward(xg, og, mg, wg, dyg, True, *cfg)
+    gs = ops.dcnv2_backward(xg, og, mg, wg, dyg, True, *cfg, xm_bound=ops.amax(xg), dy_bound=ops.amax(dyg))
+    torch.cuda.synchronize()
+    e32, es = _rel(g32[3], ref[3]), _rel(gs[3], ref[3])
+    assert es < BWD_RTOL and es < 1.5 * e32 + 2e-7, (es, e32)
+    for a, c in zip(gs[:3] + gs[4:], g32[:3] + g32[4:]):  # everything else is the same code: equal up to the order of the dx atomics
+        assert _rel(a, c.double().cpu()) < 1e-5
+
+
+@pytest.mark.parametrize('scale', [(1e-20, 1e12), (1e-3, 1.0), (1e4, 1e-9), (1e18, 1e-30)])
+def test_backward_split_dw_is_scale_invariant(gpu, scale):
+    from edvr_amd import ops
+    from oracle import dcn_oracle as O
+    sx, sd = scale
+    x, off, m, w, b, dy = _mk(1, 128, 17, 45, 128, 3, 1, 1, 1, 1, 8, 0.4, seed=91)
+    x, dy = x * sx, dy * sd
+    ref = O.c_backward(x.double(), off.double(), m.double(), w.double(), dy.double(), False, 1, 1, 1, 1, 8)
+    xg, og, mg, wg, dyg = (t.to(gpu) for t in (x, off, m, w, dy))
+    # loose bounds (x 1000) are bounds too
+    gs = ops.dcnv2_backward(xg, og, mg, wg, dyg, False, 1, 1, 1, 1, 8, xm_bound=ops.amax(xg) * 1000., dy_bound=ops.amax(dyg) * 1000.)
+    assert torch.isfinite(gs[3]).all() and _rel(gs[3], ref[3]) < BWD_RTOL, _rel(gs[3], ref[3])
+
+
+def test_conv1x1_weight_gradient_split_gemm(gpu):
+    """The 1x1 weight gradient runs the same product: split when both tensors carry a bound, the fp32 kernel otherwise."""
+    from edvr_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for (n, ci, h, w, co) in [(3, 640, 20, 36, 128), (2, 64, 17, 23, 96), (1, 128, 8, 8, 64)]:
+        x = torch.randn(n, ci, h, w, generator=g)
+        dz = torch.randn(n, co, h, w, generator=g) * 1e-3
+        ref = torch.einsum('nohw,nihw->oi', dz.double(), x.double()).reshape(co, ci, 1, 1)
+        xg, dzg = x.to(gpu), dz.to(gpu)
+        seen = []
+        ops.LAUNCH_HOOK = lambda name, flops, launch, *a: (seen.append(name), launch())
+        try:
+            d32 = ops.conv2d_wgrad(xg, None, None, dzg, co, 1, 1)
+            ops.set_bound(xg, ops.amax(xg))
+            ops.set_bound(dzg, ops.amax(dzg))
+            ds = ops.conv2d_wgrad(xg, None, None, dzg, co, 1, 1)
+        finally:
+            ops.LAUNCH_HOOK = None
+        assert 'gemm_nt_kernel' in seen and ('gemm_nt_split_kernel' in seen) == bool(ops.F4S_TRAINING), seen
+        e32, es = _rel(d32, ref), _rel(ds, ref)
+        assert es < 2e-6 and es < 1.5 * e32 + 2e-7, (es, e32)
