@@ -556,3 +556,37 @@ def test_training_trajectory_matches_oracle_adam(gpu):
           f'at {ao[-1][1]}; cached vs uncached HIP arms: median {ab[len(ab) // 2][0]:.2e}, worst {ab[-1][0]:.2e} at {ab[-1][1]}')
     for name, errs in (('A vs B', ab), ('A vs O', ao)):
         assert errs[len(errs) // 2][0] < 0.15 and errs[-1][0] < 0.40, (name, errs[len(errs) // 2], errs[-3:])
+
+
+def test_steady_state_training_reuses_packed_buffers_and_the_job_table(gpu):
+    """ops.prepack_conv_weights rewrites a stale packed layout IN PLACE when the cache is its only owner (`_sole_owner`: a reference
+    count and torch's private use count - interpreter / torch-version dependent; when they disagree the code takes the safe branch
+    and silently allocates ~480 fresh buffers and a new job table every iteration).  This is the assertion that the fast branch is the
+    one that runs: from the second optimizer step on, every packed buffer keeps its address and the ONE job table is reused."""
+    from edvr_amd import EDVR, ops
+    from edvr_amd.autograd import charbonnier_loss
+    from edvr_amd.optim import FusedAdam
+    from util_edvr import randomize_offsets
+    torch.manual_seed(10)
+    ops.invalidate_packed_weights()
+    ops._PACK_TABLES.clear()
+    m = randomize_offsets(EDVR(num_feat=64, num_frame=5, num_reconstruct_block=4, center_frame_idx=2)).train().to(gpu)
+    opt = FusedAdam(m.parameters(), lr=4e-4, betas=(0.9, 0.99))
+    g = torch.Generator().manual_seed(7)
+    x, gt = torch.rand(2, 5, 3, 32, 32, generator=g).to(gpu), torch.rand(2, 3, 128, 128, generator=g).to(gpu)
+
+    def snapshot():
+        ptrs = {(wid, key): hit[1].data_ptr() for wid, ent in ops._PACKED.items() for key, hit in ent[1].items()}
+        return ptrs, {k: v[0].data_ptr() for k, v in ops._PACK_TABLES.items()}
+
+    snaps = []
+    for it in range(4):
+        opt.zero_grad(set_to_none=True)
+        charbonnier_loss(m(x), gt).backward()
+        opt.step()
+        snaps.append(snapshot())
+    torch.cuda.synchronize()
+    assert len(snaps[1][0]) > 100, 'the network should have filled the cache'
+    for later in snaps[2:]:
+        assert later[0] == snaps[1][0], 'packed buffers were re-allocated in steady state'
+        assert later[1] == snaps[1][1] and len(later[1]) <= 2, 'the job table was rebuilt in steady state'  # (<= 2: the first iteration's, which also allocates, may differ)
