@@ -37,6 +37,8 @@ PROTOTYPES = {
     'edvr_conv2d_pack_weight_f4_f32': (i32, [vp, vp, i32, i32, i32, vp]),
     'edvr_conv2d_packed_weight_f4s_elems': (sz, [i32, i32]),
     'edvr_conv2d_pack_weight_f4s_f32': (i32, [vp, vp, i32, i32, i32, vp]),
+    'edvr_conv2d_packed_weight_1x1s_elems': (sz, [i32, i32]),
+    'edvr_conv2d_pack_weight_1x1s_f32': (i32, [vp, vp, i32, i32, vp]),
     'edvr_amax_f32': (i32, [vp, vp, i32, i64, i64, vp]),
     'edvr_pack_job_bytes': (sz, []),
     'edvr_conv2d_pack_weights_multi': (i32, [vp, i32, i32, i32, vp]),

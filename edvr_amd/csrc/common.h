@@ -72,6 +72,9 @@ int wgrad_small_launch(const float *x, const float *dz, float *ws, int ci, int c
 // conv1x1.hip: 1x1 conv as a streaming GEMM (B operand straight from global memory)
 bool conv1x1_eligible(const edvr_conv2d_desc &d);
 int conv1x1_launch(const edvr_conv2d_desc &d, hipStream_t stream);
+// conv1x1_s.hip: the same kernel with split fp32 operands on the f16 matrix pipe (needs d.wpk_f4s = edvr_conv2d_pack_weight_1x1s_f32's buffer and d.x_amax)
+bool conv1x1_split_eligible(const edvr_conv2d_desc &d);
+int conv1x1_split_launch(const edvr_conv2d_desc &d, hipStream_t stream);
 
 // wgrad.hip: out[i] (+)= sum_k ws[k * total + i]
 int reduce_partials_launch(const float *ws, float *out, int64_t total, int parts, int accumulate, hipStream_t stream,

@@ -372,8 +372,8 @@ int conv2d_launch(const edvr_conv2d_desc &d, hipStream_t stream) {
     set_error("conv2d: abs_sum is an epilogue of the F(4x4) Winograd kernel's NCHW store only (ask edvr_conv2d_abs_sum_supported)");
     return EDVR_ERR_UNSUPPORTED;
   }
-  if (d.y_amax && (conv_small_eligible(d) || !winograd_f4s_eligible(d))) {
-    set_error("conv2d: y_amax is an epilogue of the split-operand F(4x4) Winograd kernel only (ask edvr_conv2d_y_amax_supported)");
+  if (d.y_amax && (conv_small_eligible(d) || !(winograd_f4s_eligible(d) || conv1x1_split_eligible(d)))) {
+    set_error("conv2d: y_amax is an epilogue of the split-operand kernels only (ask edvr_conv2d_y_amax_supported)");
     return EDVR_ERR_UNSUPPORTED;
   }
   if (!d.gate && !scaled && conv_small_eligible(d)) return conv_small_launch(d, stream);
@@ -385,6 +385,7 @@ int conv2d_launch(const edvr_conv2d_desc &d, hipStream_t stream) {
   }
   if (d.ks == 3 && d.stride == 1) return launch_mt<3, 1>(a, stream);
   if (d.ks == 3 && d.stride == 2) return launch_mt<3, 2>(a, stream);
+  if (conv1x1_split_eligible(d)) return conv1x1_split_launch(d, stream);
   if (conv1x1_eligible(d)) return conv1x1_launch(d, stream);
   return launch_mt<1, 1>(a, stream);
 }
@@ -432,6 +433,10 @@ int edvr_conv2d_kernel_name(const edvr_conv2d_desc *d, char *buf, size_t buf_len
     snprintf(buf, buf_len, "conv3x3_winograd_kernel");
     return EDVR_OK;
   }
+  if (edvr::conv1x1_split_eligible(*d)) {
+    snprintf(buf, buf_len, "conv1x1_split_kernel");
+    return EDVR_OK;
+  }
   if (edvr::conv1x1_eligible(*d)) {
     snprintf(buf, buf_len, "conv1x1_stream_kernel");
     return EDVR_OK;
@@ -449,6 +454,7 @@ int edvr_conv2d_executed_flops(const edvr_conv2d_desc *d, double *flops) {
   if (!edvr::conv_small_eligible(*d) && edvr::winograd_f4s_eligible(*d)) *flops = edvr::winograd_f4s_executed_flops(*d);
   else if (!edvr::conv_small_eligible(*d) && edvr::winograd_f4_eligible(*d)) *flops = edvr::winograd_f4_executed_flops(*d);
   else if (!edvr::conv_small_eligible(*d) && edvr::winograd_eligible(*d)) *flops = edvr::winograd_executed_flops(*d);
+  else if (edvr::conv1x1_split_eligible(*d)) *flops = 8.0 * d->n * ho * wo * d->co * (d->c1 + d->c2);  // four f16 products per fp32 one
   else *flops = 2.0 * d->n * ho * wo * d->co * (d->c1 + d->c2) * d->ks * d->ks;  // direct algorithm (tile padding not counted)
   return EDVR_OK;
 }
@@ -460,7 +466,7 @@ int edvr_conv2d_abs_sum_supported(const edvr_conv2d_desc *d) {
 
 int edvr_conv2d_y_amax_supported(const edvr_conv2d_desc *d) {
   if (!d) return 0;
-  return (!edvr::conv_small_eligible(*d) && edvr::winograd_f4s_eligible(*d)) ? 1 : 0;
+  return (!edvr::conv_small_eligible(*d) && (edvr::winograd_f4s_eligible(*d) || edvr::conv1x1_split_eligible(*d))) ? 1 : 0;
 }
 
 int edvr_conv2d_gate_supported(const edvr_conv2d_desc *d) {

@@ -50,6 +50,8 @@ def conv(m, x, *, x2=None, x2_map=None, act=ACT_NONE, act_from=0, res1=None, res
     f4s = f4 and ops.F4S_INFERENCE and x.shape[3] % 4 == 0
     wf4 = ops.pack_conv_weight(m.weight, f4=True) if (f4 and not f4s) else None
     wf4s = ops.pack_conv_weight(m.weight, f4s=True) if f4s else None
+    if ops.F4S_INFERENCE and ks == 1 and stride == 1 and cin >= 320 and x.shape[1] % 8 == 0 and cin % 8 == 0:
+        wf4s = ops.pack_conv_weight(m.weight, f4s=True)  # the streaming 1x1 kernel's split form (csrc/conv1x1_s.hip; the C side decides)
     bias = m.bias.detach() if m.bias is not None else None
     r = ops.conv2d(x, wpk, bias, m.out_channels, ks, x2=x2, x2_map=x2_map, stride=stride, act=act, act_from=act_from,
                    res1=res1, res2=res2, out_mode=out_mode, y_scale=y_scale, wpk_f4=wf4, abs_sum_channels=abs_sum_channels,

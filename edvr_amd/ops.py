@@ -94,7 +94,8 @@ _PACKED = {}  # id(parameter) -> (weakref, {transpose_flip: (version, packed, da
 def pack_conv_weight(weight, transpose_flip=False, f4=False, f4s=False):
     """(co, ci, k, k) parameter -> MFMA-friendly [ci_pad][k*k][co_pad] array, cached per parameter version.
     f4: the F(4x4,3x3) Winograd weights of a 3x3 kernel instead (conv2d's `wpk_f4`), a separate buffer with its own cache slot.
-    f4s: the same weights for the split-operand kernel (conv2d's `wpk_f4s`: scaled, split into f16 (hi, lo) pairs; int32 buffer)."""
+    f4s: the same weights for the split-operand kernel (conv2d's `wpk_f4s`: scaled, split into f16 (hi, lo) pairs; int32 buffer); of a
+    1x1 kernel: the split-operand packing of the streaming 1x1 kernel (csrc/conv1x1_s.hip), same field."""
     require_gpu(weight)
     key, wid, ver = (bool(transpose_flip), 2 if f4s else bool(f4)), id(weight), weight._version
     ent = _PACKED.get(wid)
@@ -112,7 +113,11 @@ def pack_conv_weight(weight, transpose_flip=False, f4=False, f4s=False):
     o, i, k, k2 = w.shape
     assert k == k2, 'square kernels only'
     co, ci = (i, o) if transpose_flip else (o, i)
-    if f4s:
+    if f4s and k == 1:  # the split-operand packing of a 1x1 conv (csrc/conv1x1_s.hip)
+        assert not transpose_flip, 'the split 1x1 kernel serves forward convs'
+        out = torch.empty(L.edvr_conv2d_packed_weight_1x1s_elems(co, ci), dtype=torch.int32, device=w.device)
+        _lib.check(L.edvr_conv2d_pack_weight_1x1s_f32(_ptr(w), _ptr(out), co, ci, _stream()), 'edvr_conv2d_pack_weight_1x1s_f32')
+    elif f4s:
         assert k == 3, 'F(4x4,3x3) weights are for 3x3 kernels'
         out = torch.empty(L.edvr_conv2d_packed_weight_f4s_elems(co, ci), dtype=torch.int32, device=w.device)
         _lib.check(L.edvr_conv2d_pack_weight_f4s_f32(_ptr(w), _ptr(out), co, ci, 1 if transpose_flip else 0, _stream()),
@@ -256,6 +261,8 @@ def f4_weight(weight, ks, transpose_flip=False):
 def f4_kwargs(weight, ks, transpose_flip=False):
     """The F(4x4) weights a training-path conv2d() call should get: {'wpk_f4s': ...} (split-operand kernel), {'wpk_f4': ...} (fp32
     kernel) or {} when the F(4x4) path is off / the layer too small."""
+    if ks == 1 and F4S_TRAINING and not transpose_flip and weight.shape[1] >= 320 and weight.shape[1] % 8 == 0:
+        return {'wpk_f4s': pack_conv_weight(weight, f4s=True)}  # the streaming 1x1 kernel's split form (csrc/conv1x1_s.hip; forward only)
     if not F4_TRAINING or ks != 3:
         return {}
     co, ci = (weight.shape[1], weight.shape[0]) if transpose_flip else (weight.shape[0], weight.shape[1])

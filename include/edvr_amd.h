@@ -160,6 +160,13 @@ int edvr_conv2d_pack_weight_f4_f32(const float *w, float *wpk_f4, int co, int ci
  * 16-byte aligned.  Replaces the same cuDNN choice as edvr_conv2d_pack_weight_f4_f32. */
 size_t edvr_conv2d_packed_weight_f4s_elems(int co, int ci);
 int edvr_conv2d_pack_weight_f4s_f32(const float *w, void *wpk_f4s, int co, int ci, int transpose_flip, edvr_stream_t stream);
+/* The split-operand packing of a 1x1 conv's weights (csrc/conv1x1_s.hip): the same 64-byte header followed by [channel quad][co padded
+ * to 128][4 channels] dwords (f16 hi | f16 lo << 16) of w * s_W.  Passed as edvr_conv2d_desc.wpk_f4s of a ks == 1 launch (with x_amax) it
+ * allows the split form of the streaming 1x1 kernel (>= 320 input channels, c1 and c2 multiples of 8; EDVR_CONV1X1_SPLIT=0 switches
+ * it off): the fp32 kernel's result to within fp32 rounding.  Replaces: the cuDNN call under TSAFusion.feat_fusion's nn.Conv2d
+ * (edvr_arch.py:190-193,229).  edvr_conv2d_packed_weight_1x1s_elems(co, ci) dwords, 16-byte aligned. */
+size_t edvr_conv2d_packed_weight_1x1s_elems(int co, int ci);
+int edvr_conv2d_pack_weight_1x1s_f32(const float *w, void *wpk_1x1s, int co, int ci, edvr_stream_t stream);
 /* amax[0] = max(amax[0], max |x|) over n images of per_img contiguous floats, img_stride elements apart (the caller zeroes amax
  * before the first call; several tensors may be folded into one bound).  Feeds edvr_conv2d_desc.x_amax. */
 int edvr_amax_f32(const float *x, float *amax, int n, int64_t per_img, int64_t img_stride, edvr_stream_t stream);

@@ -171,3 +171,97 @@ def test_amax_kernel(gpu):
     both = ops.amax(x[:2])
     ops.amax(x[2:] * 3, out=both)
     assert both.item() == max(x[:2].abs().max().item(), (x[2:] * 3).abs().max().item())
+
+
+# ---- the streaming 1x1 kernel's split form (csrc/conv1x1_s.hip): TSA's feat_fusion shapes and ragged ones
+C1X1_CASES = [
+    # n, c1, c2, h, w, co, act, residuals, x2_map
+    (2, 640, 0, 20, 36, 128, 'lrelu', 0, None),      # feat_fusion (edvr_arch.py:190-193): t * c -> c
+    (1, 896, 0, 17, 23, 128, 'none', 0, None),       # seven frames, ragged pixel count (391 = 3 blocks + 7)
+    (3, 320, 320, 9, 40, 96, 'relu', 1, None),       # two inputs, three output tiles
+    (4, 384, 128, 8, 16, 200, 'lrelu', 2, (2, 1, 0)),  # x2 broadcast through the image map, one full block + three tiles
+    (1, 328, 0, 5, 7, 33, 'sigmoid_from', 0, None),  # channel count not a multiple of the 64-channel slab, two ragged tiles
+]
+
+
+def _c1x1_tensors(case):
+    n, c1, c2, h, w, co, actn, nres, x2map = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x1 = torch.randn(n, c1, h, w, generator=g)
+    n2 = n if x2map is None else (n // x2map[0]) * x2map[1]
+    x2 = torch.randn(n2, c2, h, w, generator=g) if c2 else None
+    wt = torch.randn(co, c1 + c2, 1, 1, generator=g) * 0.05
+    b = torch.randn(co, generator=g)
+    if x2 is None:
+        xin = x1
+    elif x2map is None:
+        xin = torch.cat([x1, x2], 1)
+    else:
+        xin = torch.cat([x1, x2[[(i // x2map[0]) * x2map[1] + x2map[2] for i in range(n)]]], 1)
+    ref = F.conv2d(xin.double(), wt.double(), b.double())
+    act, act_from = {'none': (0, 0), 'relu': (1, 0), 'lrelu': (2, 0), 'sigmoid_from': (3, 2 * co // 3)}[actn]
+    if actn == 'relu':
+        ref = F.relu(ref)
+    elif actn == 'lrelu':
+        ref = F.leaky_relu(ref, 0.1)
+    elif actn == 'sigmoid_from':
+        ref = torch.cat([ref[:, :act_from], torch.sigmoid(ref[:, act_from:])], 1)
+    res = [torch.randn(ref.shape, generator=g) for _ in range(nres)]
+    for r in res:
+        ref = ref + r.double()
+    return x1, x2, wt, b, ref, act, act_from, res
+
+
+@pytest.mark.parametrize('case', C1X1_CASES)
+def test_split_conv1x1_matches_fp64(gpu, case):
+    from edvr_amd import ops
+    n, c1, c2, h, w, co, actn, nres, x2map = case
+    x1, x2, wt, b, ref, act, act_from, res = _c1x1_tensors(case)
+    wg = wt.to(gpu)
+    wpk, wq = ops.pack_conv_weight(wg), ops.pack_conv_weight(wg, f4s=True)
+    x1g, x2g = x1.to(gpu), (x2.to(gpu) if x2 is not None else None)
+    rg = [r.to(gpu) for r in res]
+    kw = dict(x2=x2g, x2_map=x2map, act=act, act_from=act_from, res1=rg[0] if nres > 0 else None, res2=rg[1] if nres > 1 else None)
+    seen = []
+    ops.LAUNCH_HOOK = lambda name, flops, launch, *a: (seen.append(name), launch())
+    try:
+        y32 = ops.conv2d(x1g, wpk, b.to(gpu), co, 1, **kw)
+        ys = ops.conv2d(x1g, wpk, b.to(gpu), co, 1, wpk_f4s=wq, **kw)
+    finally:
+        ops.LAUNCH_HOOK = None
+    assert [k for k in seen if k.startswith('conv')] == ['conv1x1_stream_kernel', 'conv1x1_split_kernel'], seen
+    e32, es = _rel(y32, ref), _rel(ys, ref)
+    assert es < 2e-6 and es < 1.5 * e32 + 2e-7, (es, e32)
+    bound = ops.get_bound(ys)  # the epilogue's max |y|
+    assert bound is not None and abs(bound.item() - ys.abs().max().item()) <= 1e-6 * ys.abs().max().item()
+
+
+@pytest.mark.parametrize('scale', [1e-25, 1e-4, 1.0, 1e6, 1e25])
+def test_split_conv1x1_is_scale_invariant(gpu, scale):
+    from edvr_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 640, 12, 20, generator=g) * scale
+    x[0, 3, 2, 2] *= 300.0  # an outlier sets the bound; everything else sits 2^-8 below it
+    wt = torch.randn(128, 640, 1, 1, generator=g) * 0.05
+    ref = F.conv2d(x.double(), wt.double())
+    xg, wg = x.to(gpu), wt.to(gpu)
+    y = ops.conv2d(xg, ops.pack_conv_weight(wg), None, 128, 1, wpk_f4s=ops.pack_conv_weight(wg, f4s=True), x_amax=ops.amax(xg) * 64.0)  # a loose bound is a bound
+    assert torch.isfinite(y).all() and _rel(y, ref) < 2e-6, _rel(y, ref)
+
+
+def test_split_conv1x1_falls_back_where_it_does_not_apply(gpu):
+    """Fewer than 320 input channels, channel counts that are not multiples of 8, EDVR_CONV_DIRECT: the fp32 kernels, same results."""
+    from edvr_amd import ops
+    g = torch.Generator().manual_seed(6)
+    for (ci, algo) in [(128, None), (324, None), (640, ops.CONV_DIRECT)]:
+        x = torch.randn(1, ci, 8, 16, generator=g).to(gpu)
+        wg = (torch.randn(64, ci, 1, 1, generator=g) * 0.05).to(gpu)
+        ref = F.conv2d(x.double().cpu(), wg.double().cpu())
+        seen = []
+        ops.LAUNCH_HOOK = lambda name, flops, launch, *a: (seen.append(name), launch())
+        try:
+            y = ops.conv2d(x, ops.pack_conv_weight(wg), None, 64, 1, wpk_f4s=ops.pack_conv_weight(wg, f4s=True), algo=algo)
+        finally:
+            ops.LAUNCH_HOOK = None
+        assert 'conv1x1_split_kernel' not in seen, (ci, algo, seen)
+        assert _rel(y, ref) < 2e-6
