@@ -115,7 +115,12 @@ def pack_conv_weight(weight, transpose_flip=False, f4=False, f4s=False):
     co, ci = (i, o) if transpose_flip else (o, i)
     if f4s and k == 1:  # the split-operand packing of a 1x1 conv (csrc/conv1x1_s.hip)
         assert not transpose_flip, 'the split 1x1 kernel serves forward convs'
-        out = torch.empty(L.edvr_conv2d_packed_weight_1x1s_elems(co, ci), dtype=torch.int32, device=w.device)
+        n_el = L.edvr_conv2d_packed_weight_1x1s_elems(co, ci)
+        stale = ent[1].get(key)  # this layout is not part of prepack_conv_weights' table: rewritten in place here under the same rule
+        if stale is not None and stale[1].numel() == n_el and stale[1].device == w.device and _sole_owner(stale):
+            out = stale[1]
+        else:
+            out = torch.empty(n_el, dtype=torch.int32, device=w.device)
         _lib.check(L.edvr_conv2d_pack_weight_1x1s_f32(_ptr(w), _ptr(out), co, ci, _stream()), 'edvr_conv2d_pack_weight_1x1s_f32')
     elif f4s:
         assert k == 3, 'F(4x4,3x3) weights are for 3x3 kernels'
