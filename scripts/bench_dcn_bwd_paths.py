@@ -1,0 +1,33 @@
+"""Which kernels the DCNv2 backward of the training layer (160 x 128 x 64 x 64) spends its time in, for the two dX strategies the step
+uses: the fused kernel on a sub-pixel field (fresh conv_offset) and the LDS-window path on a trained-like one (per-tap constants of
+4 px sigma + smooth motion).  Run under `rocprofv3 --kernel-trace --stats` (scripts/prof_dcn_bwd_paths.sh): the per-kernel table IS
+the output; this script only prints the wall time per call."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+from edvr_amd import ops
+dev = torch.device('cuda')
+g = torch.Generator(device=dev).manual_seed(0)
+B, C, H, W, dg = 160, 128, 64, 64, 8
+x = torch.randn(B, C, H, W, device=dev, generator=g)
+w = torch.randn(C, C, 3, 3, device=dev, generator=g) * 0.05
+m = torch.rand(B, dg * 9, H, W, device=dev, generator=g)
+dy = torch.randn(B, C, H, W, device=dev, generator=g) * 1e-3
+bx, bd = ops.amax(x), ops.amax(dy)
+sub = torch.randn(B, dg * 18, H, W, device=dev, generator=g) * 0.3
+coarse = torch.randn(B, dg * 18, H // 16 + 1, W // 16 + 1, device=dev, generator=g) * 0.5
+trained = (torch.randn(1, dg * 18, 1, 1, device=dev, generator=g) * 4.0 + F.interpolate(coarse, scale_factor=16, mode='bilinear', align_corners=False)[:, :, :H, :W]
+           + torch.randn(B, dg * 18, H, W, device=dev, generator=g) * 0.15).contiguous()
+for name, off, hint in (('sub-pixel field, fused kernel', sub, ops.DCN_SCATTER_STRIP), ('trained-like field, LDS-window path', trained, ops.DCN_SCATTER_LDS)):
+    run = lambda: ops.dcnv2_backward(x, off, m, w, dy, True, 1, 1, 1, 1, dg, scatter_hint=hint, xm_bound=bx, dy_bound=bd)
+    for _ in range(2):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    print(f'{name}: {e0.elapsed_time(e1) / 5:.3f} ms per backward call (mean |offset| {off.abs().mean().item():.2f} px)', flush=True)
