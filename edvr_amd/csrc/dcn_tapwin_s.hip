@@ -313,10 +313,10 @@ __global__ __launch_bounds__(256, 2) void dcn_tapwin_split_fwd_kernel(const DcnT
                            s2 * __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, o2, so, 0)) +
                            s3 * __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, o3, so, 0));
           // this lane's channel of the pair, 2 q + half = 8 kg + 2 i + half: quad 2 kg + half, slot i
-          const unsigned *ap = wb + (((2 * (q >> 2) + half) * MB + j * MT) * 4 + (q & 3));
+          const unsigned *ap = wb + (((2 * (q >> 2) + half) * MB + j) * 4 + (q & 3));
 #pragma unroll
           for (int m2 = 0; m2 < MT; ++m2) {
-            const f16x2t pr = __builtin_bit_cast(f16x2t, ap[m2 * 4]);
+            const f16x2t pr = __builtin_bit_cast(f16x2t, ap[m2 * 128]);
             acc[s][m2] = __builtin_amdgcn_mfma_f32_32x32x2f32((float)pr[0] + (float)pr[1], bv, acc[s][m2], 0, 0, 0);
           }
         }
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void dcn_tapwin_split_fwd_kernel(const DcnT
       for (int kg = 0; kg < KG; ++kg) {
         i32x4 aw[MT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) aw[m] = *reinterpret_cast<const i32x4 *>(wb + ((kg * 2 + half) * MB + j * MT + m) * 4);
+        for (int m = 0; m < MT; ++m) aw[m] = *reinterpret_cast<const i32x4 *>(wb + ((kg * 2 + half) * MB + m * 32 + j) * 4);  // lane stride 16 bytes: conflict-free
         i32x4 bq[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -473,7 +473,9 @@ __global__ __launch_bounds__(1024) void dcn_tapwin_split_scale_kernel(const floa
   }
 }
 
-// [channel quad][tap][co'][4 channels] with the output channels of a launch block reordered [j][m] as in dcn_fused_pack_kernel
+// [channel quad][tap][co][4 channels] (the fp32 kernel's slab has the output channels of a launch block reordered [j][m] for its
+// scalar operand reads; here a lane's A operand is one ds_read_b128 and that order put neighbouring lanes 64 bytes apart: a 4-way
+// bank conflict on every operand read, 54 % of the LDS-active cycles - plain channel order is conflict-free)
 __global__ void dcn_tapwin_split_pack_kernel(const float *__restrict__ w, unsigned *__restrict__ wpk, int Co, int C, int cop) {
   const float s_w = __builtin_bit_cast(float, wpk[0]);
   const int64_t total = (int64_t)(C / 4) * 9 * cop;
@@ -481,8 +483,8 @@ __global__ void dcn_tapwin_split_pack_kernel(const float *__restrict__ w, unsign
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int pos = (int)(i % cop), t = (int)((i / cop) % 9), c4 = (int)(i / ((int64_t)cop * 9));
     const int blk = pos / 128 < full ? pos / 128 : full, start = blk * 128, mt = blk < full ? 4 : rem_tiles;
-    const int r = pos - start, j = r / mt, m = r - j * mt, co = start + m * 32 + j;
-    const bool live = mt > 0 && j < 32 && co < Co;
+    const int r = pos - start, co = pos;  // output channels in their own order inside a launch block: [m][j], a lane's operand 16 bytes from its neighbour's
+    const bool live = mt > 0 && r < 32 * mt && co < Co;
 #pragma unroll
     for (int q = 0; q < 4; ++q) wpk[16 + i * 4 + q] = live ? split_f16x2(w[((int64_t)co * C + 8 * (c4 >> 1) + 2 * q + (c4 & 1)) * 9 + t], s_w) : 0u;  // quad 2 kg + half, slot q = channel 8 kg + 2 q + half
   }
