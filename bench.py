@@ -97,7 +97,8 @@ SPLIT_KERNELS = ('conv3x3_winograd_f4s_kernel', 'conv3x3_winograd_wgrad_split_ke
 # multiplies the algorithm saves against the direct one (F(4x4): 4, F(2x2): 2.25, the DCN GEMM: none); each remaining fp32 product = 4 f16 ones
 SPLIT_SAVING = {'conv3x3_winograd_f4s_kernel': 4.0, 'conv3x3_winograd_wgrad_split_kernel': 2.25, 'dcnv2_fwd[dcn_tapwin_split_fwd_kernel]': 1.0,
                 'gemm_nt_split_kernel': 1.0, 'conv1x1_split_kernel': 1.0}
-DTYPE = ('f32 (3x3 / stride-1 convs and their weight gradients multiply SPLIT fp32 operands - f16 (hi, lo) pairs, all four cross products - on '
+DTYPE = ('f32 (3x3 / stride-1 convs and their weight gradients, the tap-window DCN forward, the dW product of the DCN backward and the 1x1 convs '
+         'from 320 input channels up multiply SPLIT fp32 operands - f16 (hi, lo) pairs, all four cross products - on '
          'the f16 matrix pipe with fp32 accumulation: the fp32 result to within fp32 rounding; everything else fp32 MFMA / VALU).  '
          '`fp32_mfma` beside it = the same run with those kernels on the fp32 matrix pipe')
 
@@ -627,7 +628,7 @@ def train_leg(args, device, rank, world, dist):
         finally:
             _ops.set_f4s(*prev)
         out['fp32_mfma'] = {'iters_per_sec': round(6 / e32, 4), 'ms_per_iter': round(e32 / 6 * 1e3, 2), 'steps': 6,
-                            'what': 'the same step with the split-operand kernels off (EDVR_WINOGRAD_F4S=0): fp32 matrix pipe'}
+                            'what': 'the same step with EVERY split-operand kernel off (ops.set_f4s(False, False) = EDVR_WINOGRAD_F4S=0: convs, weight gradients, DCN forward, dW products, 1x1 convs): fp32 matrix pipe'}
     if not args.no_trained_like:
         # the same training step with the offsets of a TRAINED model (conv_offset.bias ~ N(0, 4^2): every tap its own multi-pixel
         # displacement): the forward's cost does not change (tap-window kernel), the backward's dX leaves the no-scatter kernels
@@ -819,7 +820,7 @@ def main():
         if rank == 0:
             result['fp32_mfma'] = {'value': round(batch * world * 5 / e32, 4), 'unit': 'clips/s', 'ms_per_step': round(e32 / 5 * 1e3, 3), 'steps': 5, 'warmup': 2,
                                    'dtype': 'f32 (every product on v_mfma_f32_32x32x2_f32 / the vector ALUs)',
-                                   'what': 'EDVR_WINOGRAD_F4S=0: conv3x3_winograd_f4_kernel / conv3x3_winograd_wgrad_kernel instead of their split-operand forms',
+                                   'what': 'ops.set_f4s(False, False) = EDVR_WINOGRAD_F4S=0: conv3x3_winograd_f4_kernel, dcn_tapwin_fwd_kernel, conv1x1_stream_kernel (training: + conv3x3_winograd_wgrad_kernel, gemm_nt_kernel) instead of their split-operand forms',
                                    'speedup_of_the_default_path': round(e32 / 5 / (elapsed / args.steps), 4)}
             if args.mode == 'train':
                 result['fp32_mfma']['iters_per_sec'] = round(5 / e32, 4)
