@@ -52,7 +52,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
 PEAK_HBM_GBPS = 8000.0        # same guide: HBM3E ~8 TB/s
 PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_f16, dense (16x the fp32 rate)
-PROFILE_ROUND = 'r5'
+PROFILE_ROUND = 'r6'
 
 L5 = dict(num_feat=128, num_frame=5, num_reconstruct_block=40, center_frame_idx=None)
 WORKLOADS = {
@@ -218,7 +218,7 @@ def measured_traffic(workload, kernel):
     (scripts/prof_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate --pmc passes, calibrated on known-size copies as
     MI355X_MICROARCH.md's HBM section prescribes).  PMC collection serialises kernels, so it is not redone inside the timed run;
     the summary records the hash of the kernel sources it was measured on (`csrc_sha16`), compared with the tree's below."""
-    for rnd in (PROFILE_ROUND, 'r3', 'r2', 'r1'):
+    for rnd in (PROFILE_ROUND, 'r5', 'r4', 'r3', 'r2', 'r1'):
         path = os.path.join(ROOT, 'profiles', rnd, f'traffic_{workload}.json')
         if os.path.exists(path):
             rep = json.load(open(path))
@@ -258,6 +258,7 @@ def split_roofline_object(per, name, steps, step_seconds, workload, default_batc
         'algorithmic_tflops': round(flops / secs / 1e12, 2),
         'launches_per_step': round(n / steps, 1), 'avg_launch_us': round(secs / n * 1e6, 2),
         'gflop_per_launch_algorithmic': round(flops / n / 1e9, 3), 'share_of_step': round(secs / steps / step_seconds, 4),
+        'algorithmic_bytes_per_launch': round(nbytes / n),
         'traffic': round(tr['hbm_bytes_per_launch']) if tr else None,
         'traffic_detail': ({'unit': 'bytes per launch (average over the launches of this kernel in one step)',
                             'fetch': round(tr['fetch_bytes_per_launch']), 'write': round(tr['write_bytes_per_launch']),
@@ -301,6 +302,7 @@ def roofline_object(per, steps, step_seconds, workload, default_batch):
         'algorithmic_over_peak': round(flops / secs / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
         'launches_per_step': round(n / steps, 1), 'avg_launch_us': round(secs / n * 1e6, 2),
         'gflop_per_launch_algorithmic': round(flops / n / 1e9, 3), 'share_of_step': round(secs / steps / step_seconds, 4),
+        'algorithmic_bytes_per_launch': round(nbytes / n),
         'traffic': round(tr['hbm_bytes_per_launch']) if tr else None,
         'traffic_detail': ({'unit': 'bytes per launch (average over the launches of this kernel in one step)',
                             'fetch': round(tr['fetch_bytes_per_launch']), 'write': round(tr['write_bytes_per_launch']),
@@ -339,7 +341,7 @@ def oracle_kw(cfg):
     return dict(center=n.get('center_frame_idx'), hr_in=n.get('hr_in', False), with_predeblur=n.get('with_predeblur', False))
 
 
-def cpu_baseline_and_parity(cfg, device, repeats=3):
+def cpu_baseline_and_parity(cfg, device, repeats=2):
     """Oracle forward of ONE clip of the workload on the host cores (median of `repeats`), and the SAME clip through the HIP
     path: max relative error and PSNR difference against a synthetic ground truth (north_star: within 1e-3 dB)."""
     from oracle import dcn_oracle, edvr_oracle as EO
@@ -732,10 +734,138 @@ def self_spawn(args):
     sys.exit(subprocess.call(spawn_command(args.gpus, port, sys.argv[1:]), env=spawn_env(os.environ)))
 
 
-def emit(result, rank):
-    """Rank 0 prints the ONE JSON line of the run; every other rank prints nothing."""
-    if rank == 0:
-        print(json.dumps(result), flush=True)
+DTYPE_SHORT = 'fp32 emulated as 2xf16 (hi+lo, 22-bit operands, 4 cross products), fp32 accumulate'
+FULL_REPORT = 'bench_full.json'
+COMPACT_LIMIT = 6000  # bytes: the driver reads ONE line; round 5's 24 KB line did not parse
+
+
+def _num(v, nd=4):
+    """A finite float rounded for the compact line; None for anything json.loads could choke on (nan / inf) or that is missing."""
+    if isinstance(v, bool) or v is None:
+        return v
+    if isinstance(v, (int, float)):
+        f = float(v)
+        if f != f or f in (float('inf'), float('-inf')):
+            return None
+        return v if isinstance(v, int) else (round(f, nd) if abs(f) >= 1e-3 or f == 0 else float(f'{f:.3e}'))
+    return v
+
+
+def _pick(src, *keys):
+    return {k: _num(src[k]) for k in keys if isinstance(src, dict) and k in src}
+
+
+def _sanitize(o):
+    """The full report with every non-finite float replaced by None (strict JSON)."""
+    if isinstance(o, dict):
+        return {str(k): _sanitize(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_sanitize(v) for v in o]
+    if isinstance(o, float) and (o != o or o in (float('inf'), float('-inf'))):
+        return None
+    return o
+
+
+def compact_line(full):
+    """The ONE line the driver parses: the contract's fields + `roofline` and `cpu_baseline` objects in numbers only, one short
+    record per optional leg.  Kernel tables, definitions, per-config records and witnesses stay in FULL_REPORT."""
+    c = {k: _num(full.get(k)) for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
+                                        'scaling', 'vs_baseline')}
+    c['dtype'] = DTYPE_SHORT if full.get('dtype') == DTYPE else str(full.get('dtype'))[:100]
+    c['data'] = 'synthetic'
+    cfg = full.get('config', {})
+    c['config'] = {'workload': str(cfg.get('workload', ''))[:120], 'clips_per_gpu': cfg.get('clips_per_gpu'),
+                   'global_clips': cfg.get('global_clips'), 'parallelism': str(cfg.get('parallelism', ''))[:60],
+                   'world_size': cfg.get('world_size'), 'backend': str(cfg.get('backend', ''))[:40]}
+    if 'iters_per_sec' in full:
+        c['iters_per_sec'] = _num(full['iters_per_sec'])
+    r = full.get('roofline')
+    if isinstance(r, dict):
+        c['roofline'] = _pick(r, 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'launches_per_step', 'avg_launch_us',
+                              'share_of_step', 'algorithmic_bytes_per_launch', 'algorithmic_tflops')
+        c['roofline'].setdefault('traffic', None)
+        if isinstance(r.get('f16_mfma'), dict):
+            c['roofline']['f16_mfma_frac'] = _num(r['f16_mfma'].get('frac'))
+        if isinstance(r.get('traffic_detail'), dict):
+            c['roofline']['traffic_stale'] = r['traffic_detail'].get('stale')
+    b = full.get('cpu_baseline')
+    if isinstance(b, dict):
+        c['cpu_baseline'] = _pick(b, 'value', 'unit', 'cores', 'kind', 'seconds')
+        c['cpu_baseline']['sample'] = str(b.get('sample', ''))[:110]
+    if isinstance(full.get('parity'), dict):
+        c['parity'] = _pick(full['parity'], 'max_rel_err', 'd_psnr', 'ok', 'error')
+        c['parity']['against'] = 'CPU oracle, same clip and weights'
+    if isinstance(full.get('fp32_mfma'), dict):
+        c['fp32_mfma'] = _pick(full['fp32_mfma'], 'value', 'ms_per_step', 'iters_per_sec')
+    if isinstance(full.get('stock_rocm_baseline'), dict):
+        c['stock_rocm'] = _pick(full['stock_rocm_baseline'], 'value', 'max_rel_err_vs_ours', 'error')
+    t = full.get('train')
+    if isinstance(t, dict):
+        c['train'] = _pick(t, 'iters_per_sec', 'ms_per_iter', 'clips_per_sec', 'global_batch', 'steps')
+        if isinstance(t.get('fp32_mfma'), dict):
+            c['train']['fp32_mfma'] = _pick(t['fp32_mfma'], 'iters_per_sec')
+        if isinstance(t.get('parity'), dict):
+            c['train']['parity'] = _pick(t['parity'], 'ok', 'grad_rel_err_max', 'loss_rel_err', 'error')
+        for leg in ('trained_like', 'motion'):
+            if isinstance(t.get(leg), dict):
+                c['train'][leg] = _pick(t[leg], 'iters_per_sec', 'vs_sub_pixel_offsets')
+                if isinstance(t[leg].get('parity'), dict):
+                    c['train'][leg]['parity_ok'] = t[leg]['parity'].get('ok')
+    t4 = full.get('target_4k')
+    if isinstance(t4, dict):
+        c['target_4k'] = _pick(t4, 'value', 'ms_per_clip')
+        if isinstance(t4.get('parity'), dict):
+            c['target_4k']['parity_ok'] = t4['parity'].get('ok')
+    tl = full.get('trained_like')
+    if isinstance(tl, dict):
+        c['trained_like'] = {}
+        for k, rec in tl.items():
+            if isinstance(rec, dict):
+                c['trained_like'][k] = _pick(rec, 'value', 'vs_headline', 'offset_roughness_px_mean')
+                if isinstance(rec.get('parity'), dict):
+                    c['trained_like'][k]['parity_ok'] = rec['parity'].get('ok')
+    if isinstance(full.get('batch4'), dict):
+        c['batch4'] = _pick(full['batch4'], 'value')
+    cf = full.get('configs')
+    if isinstance(cf, dict):
+        c['configs'] = {}
+        for k, rec in cf.items():
+            short = k.split(',')[0].replace('configs', 'c')[:40] + (' train' if 'backward' in k else '')
+            if isinstance(rec, dict):
+                c['configs'][short] = _num(rec.get('clips_per_sec')) if 'clips_per_sec' in rec else str(rec.get('error', ''))[:60]
+    k = full.get('kernels')
+    if isinstance(k, dict):  # the five largest rows only: share of the step and fraction of the roofline that bounds each
+        top = sorted(k.items(), key=lambda kv: -kv[1].get('ms_per_step', 0.0))[:5]
+        c['top_kernels'] = {n[:48]: [_num(v.get('share_of_step')), v.get('bound'),
+                                     _num(v.get('frac_of_hbm_peak', v.get('frac_of_mfma_peak')))] for n, v in top}
+    for key in ('csrc_sha16', 'library'):
+        if key in full:
+            c[key] = full[key]
+    c['full_report'] = FULL_REPORT
+    line = json.dumps(c, allow_nan=False, separators=(',', ':'))
+    if len(line) > COMPACT_LIMIT:  # never let an optional object endanger the parse: drop them, least important first
+        for key in ('top_kernels', 'configs', 'batch4', 'trained_like', 'stock_rocm', 'target_4k'):
+            c.pop(key, None)
+            line = json.dumps(c, allow_nan=False, separators=(',', ':'))
+            if len(line) <= COMPACT_LIMIT:
+                break
+    return line
+
+
+def emit(result, rank, path=None):
+    """Rank 0 writes the full report to FULL_REPORT (beside this script; stderr says where) and prints the ONE compact JSON line of
+    the run as the LAST line of stdout; every other rank prints nothing."""
+    if rank != 0:
+        return
+    path = path or os.path.join(ROOT, FULL_REPORT)
+    try:
+        with open(path, 'w') as f:
+            json.dump(_sanitize(result), f, indent=1, allow_nan=False)
+        print(f'[bench] full report: {path}', file=sys.stderr, flush=True)
+    except OSError as e:  # (a read-only tree must not take the measurement down)
+        print(f'[bench] could not write {path}: {e}', file=sys.stderr, flush=True)
+    sys.stderr.flush()
+    print(compact_line(result), flush=True)
 
 
 def main():

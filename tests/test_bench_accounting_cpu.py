@@ -71,3 +71,69 @@ def test_measured_traffic_aggregates_template_instantiations():
     assert len(hits) >= 1 and tr['launches'] == sum(v['launches'] for v in hits)
     want = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in hits) / tr['launches']
     assert abs(tr['hbm_bytes_per_launch'] - want) < 1.0
+
+
+# ------------------------------------------------------------------ the ONE line the driver parses (round 5's 24 KB line did not)
+def _full_result(b):
+    """A full report of the shape the default run produces: round 5's committed one with every optional leg present."""
+    full = json.load(open(os.path.join(ROOT, 'profiles', 'r5', 'bench_default_run.json')))
+    full['dtype'] = b.DTYPE
+    return full
+
+
+def test_compact_line_is_small_strict_json_with_the_contract_fields():
+    b = _bench()
+    full = _full_result(b)
+    line = b.compact_line(full)
+    assert '\n' not in line and len(line.encode()) < 6000, len(line)
+    got = json.loads(line, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))  # NaN / Infinity would raise
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in got, k
+    assert got['value'] == full['value'] and got['ms_per_step'] == full['ms_per_step'] and got['vs_baseline'] is None
+    assert len(got['dtype']) <= 100 and 'workload' in got['config'] and 'model' not in got['config']
+    r = got['roofline']
+    assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s') and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
+    assert 'traffic' in r and r['kernel'] == full['roofline']['kernel']
+    c = got['cpu_baseline']
+    assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0 and c['sample']
+    assert got['parity']['ok'] is True and got['fp32_mfma']['value'] == full['fp32_mfma']['value']
+    assert got['train']['iters_per_sec'] == full['train']['iters_per_sec'] and got['train']['parity']['ok'] is True
+    assert got['train']['fp32_mfma']['iters_per_sec'] == full['train']['fp32_mfma']['iters_per_sec']
+    assert got['target_4k']['value'] == full['target_4k']['value']
+
+
+def test_compact_line_survives_non_finite_numbers_and_oversized_legs():
+    b = _bench()
+    full = _full_result(b)
+    full['parity']['max_rel_err'] = float('nan')
+    full['train']['parity']['grad_rel_err_max'] = float('inf')
+    full['configs'] = {f'configs[{i}] a very long description of a configuration, number {i}': {'clips_per_sec': float(i)} for i in range(400)}
+    line = b.compact_line(full)
+    assert len(line.encode()) < 6000
+    got = json.loads(line, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))
+    assert got['parity']['max_rel_err'] is None and got['train']['parity']['grad_rel_err_max'] is None
+    assert 'configs' not in got and 'roofline' in got and 'cpu_baseline' in got  # optional legs go first, never the contract
+
+
+def test_emit_prints_the_compact_line_last_and_writes_the_full_report(tmp_path, capsys):
+    b = _bench()
+    full = _full_result(b)
+    full['train']['parity']['grad_rel_err_max'] = float('nan')
+    path = str(tmp_path / 'bench_full.json')
+    b.emit(full, 1, path)
+    assert capsys.readouterr().out == '' and not os.path.exists(path)  # ranks other than 0 print nothing
+    b.emit(full, 0, path)
+    out = capsys.readouterr().out
+    lines = out.strip().split('\n')
+    assert len(lines) == 1 and json.loads(lines[-1])['value'] == full['value']
+    rep = json.load(open(path), parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))
+    assert rep['kernels'] and rep['train']['parity']['grad_rel_err_max'] is None
+
+
+def test_training_mode_line_carries_iters_per_sec():
+    b = _bench()
+    full = _full_result(b)
+    full.update(metric='EDVR-L x4 training clips/sec (= iters/sec x global batch)', iters_per_sec=9.44)
+    got = json.loads(b.compact_line(full))
+    assert got['iters_per_sec'] == 9.44

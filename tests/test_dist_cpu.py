@@ -104,7 +104,7 @@ def _bench_worker(rank, world, port, q):
     elapsed = b.timed(step, 5, 2, dist, torch.device('cpu'))
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
-        b.emit({'value': 1.0, 'n_gpus': world}, rank)
+        b.emit({'value': 1.0, 'n_gpus': world}, rank, os.path.join(os.environ.get('TMPDIR', '/tmp'), f'bench_full_test_{os.getpid()}.json'))
     q.put((rank, elapsed, len(calls), buf.getvalue()))
     dist.barrier()
     dist.destroy_process_group()
@@ -125,5 +125,6 @@ def test_bench_timing_is_max_over_ranks_and_only_rank0_prints():
     (_, e0, n0, out0), (_, e1, n1, out1) = got
     assert n0 == n1 == 7                      # 2 warm-up + exactly 5 timed steps
     assert e0 == e1 and e0 >= 5 * 0.06 * 0.9  # both ranks report the slow rank's time (5 x 60 ms)
-    assert json.loads(out0) == {'value': 1.0, 'n_gpus': 2} and out0.count('\n') == 1
+    line = json.loads(out0)                   # the compact contract line: one line, rank 0 only
+    assert line['value'] == 1.0 and line['n_gpus'] == 2 and out0.count('\n') == 1
     assert out1 == ''                         # rank > 0 prints nothing
