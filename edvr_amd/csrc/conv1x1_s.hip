@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_split_kernel(const Conv1x1SArg
   float *y = d.y + (int64_t)img * d.y_img_stride;
   const float *q1 = d.res1 ? d.res1 + (int64_t)img * d.res1_img_stride : nullptr;
   const float *q2 = d.res2 ? d.res2 + (int64_t)img * d.res2_img_stride : nullptr;
-  float vmax = 0.f;
+  unsigned vmax = 0u;  // max |y| as a bit pattern: non-negative floats order as integers, NaNs above +inf (sticky for the host's overflow guard)
   if (p_ok) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -169,14 +169,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_split_kernel(const Conv1x1SArg
           if (q1) v += q1[off];
           if (q2) v += q2[off];
           y[off] = v;
-          vmax = fmaxf(vmax, fabsf(v));
+          vmax = max(vmax, __builtin_bit_cast(unsigned, v) & 0x7fffffffu);
         }
       }
   }
   if (d.y_amax) {  // max |y| for the next layer's bound: one atomic per wave (non-negative floats order as their bit patterns)
 #pragma unroll
-    for (int sh = 32; sh > 0; sh >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, sh));
-    if (lane == 0) atomicMax(reinterpret_cast<unsigned *>(d.y_amax), __builtin_bit_cast(unsigned, vmax));
+    for (int sh = 32; sh > 0; sh >>= 1) vmax = max(vmax, (unsigned)__shfl_xor((int)vmax, sh));
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned *>(d.y_amax), vmax);
   }
 }
 

@@ -30,6 +30,18 @@
 #include "common.h"
 #include "pack.h"
 
+// experiment switch (removed once settled): 0 = round-5 multiplying loop (six A sets a chunk ahead, B single-buffered); 1 = V stays fp32 in LDS and the
+// multiplying waves split it (A three positions ahead, operand reads double-buffered); 2 = as 1 but the staging waves still split
+#ifndef F4S_MODE
+#define F4S_MODE 0
+#endif
+#ifndef F4S_STAGE_PRIO
+#define F4S_STAGE_PRIO 3
+#endif
+#ifndef F4S_PLAIN
+#define F4S_PLAIN 1
+#endif
+
 namespace edvr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -167,7 +179,7 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
 
   if (wave < 4) {
     // =========================================================================================== staging waves
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(F4S_STAGE_PRIO);
     const float s_v = f4s_input_scale(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *d.x_amax))));
     const float s_u_inv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane((int)a.U[1]));
     const float unscale = s_u_inv * (1.f / s_v);  // M = M' / (s_U s_V): an exact power of two
@@ -224,6 +236,39 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and in registers: the region may be overwritten
     };
+#if F4S_PLAIN
+    // experiment: the same arithmetic on plain fp32 instructions (v_fma_f32 / v_add_f32 overlap with the f16 matrix pipe of the other
+    // waves where v_pk_*_f32 do not - profiles/r5/micro_mfma16_prices.log), built with -fno-slp-vectorize
+    float tq[6][6];
+    auto transform_cols = [&](int cp) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float d0 = pp[0][cp][e], d1 = pp[1][cp][e], d2 = pp[2][cp][e], d3 = pp[3][cp][e], d4 = pp[4][cp][e], d5 = pp[5][cp][e];
+        const float p_ = d4 - 4.f * d2, q_ = d3 - 4.f * d1, r_ = d4 - d2, s_ = d3 - d1;
+        tq[0][2 * cp + e] = 4.f * d0 + (d4 - 5.f * d2);
+        tq[1][2 * cp + e] = p_ + q_;
+        tq[2][2 * cp + e] = p_ - q_;
+        tq[3][2 * cp + e] = r_ + 2.f * s_;
+        tq[4][2 * cp + e] = r_ - 2.f * s_;
+        tq[5][2 * cp + e] = 4.f * d1 + (d5 - 5.f * d3);
+      }
+    };
+    auto commit_row = [&](unsigned *Vd, int r) {
+      const float d0 = tq[r][0], d1 = tq[r][1], d2 = tq[r][2], d3 = tq[r][3], d4 = tq[r][4], d5 = tq[r][5];
+      const float p_ = d4 - 4.f * d2, q_ = d3 - 4.f * d1, r_ = d4 - d2, s_ = d3 - d1;
+      const float t[6] = {4.f * d0 + (d4 - 5.f * d2), p_ + q_, p_ - q_, r_ + 2.f * s_, r_ - 2.f * s_, 4.f * d1 + (d5 - 5.f * d3)};
+      unsigned *dst = Vd + ((2 * wave + half) * 36 + r * 6) * 32 + j;
+#if F4S_MODE == 1
+#pragma unroll
+      for (int c = 0; c < 6; ++c) dst[c * 32] = __builtin_bit_cast(unsigned, t[c]);
+#else
+      unsigned pk[6];
+      split6_f16x2(t, s_v, pk);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) dst[c * 32] = pk[c];
+#endif
+    };
+#else
     auto transform_cols = [&](int cp) {  // 1-D input transform B^T (Lavin & Gray), 12 packed operations
       const f32x2 d0 = pp[0][cp], d1 = pp[1][cp], d2 = pp[2][cp], d3 = pp[3][cp], d4 = pp[4][cp], d5 = pp[5][cp];
       const f32x2 p_ = d4 - 4.f * d2, q_ = d3 - 4.f * d1, r_ = d4 - d2, s_ = d3 - d1;
@@ -245,11 +290,17 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
       const f32x2 t24 = pr_ - f32x2{1.f, 2.f} * qs_;
       unsigned *dst = Vd + ((2 * wave + half) * 36 + r * 6) * 32 + j;
       const float t[6] = {t05[0], t13[0], t24[0], t13[1], t24[1], t05[1]};
+#if F4S_MODE == 1
+#pragma unroll
+      for (int c = 0; c < 6; ++c) dst[c * 32] = __builtin_bit_cast(unsigned, t[c]);  // fp32: the multiplying waves split (their three streams per SIMD interleave; this lone wave issues one instruction per ~8 cycles)
+#else
       unsigned pk[6];
       split6_f16x2(t, s_v, pk);
 #pragma unroll
       for (int c = 0; c < 6; ++c) dst[c * 32] = pk[c];
+#endif
     };
+#endif
     auto advance = [&]() {  // the load cursor moves one chunk; at an item boundary the geometry switches
       if (++l_k == n_chunks) {
         l_k = 0;
@@ -284,8 +335,20 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
       if (lane == 0 && asum_img >= 0 && s != 0.f) atomicAdd(d.abs_sum + asum_img, s);
       asum = 0.f;
     };
-    float amx = 0.f;  // y_amax epilogue: max |y| of everything this thread stores (rows below the image included: still a bound)
-    auto amax4 = [&](const f32x4 &v) { amx = fmaxf(fmaxf(fmaxf(amx, fabsf(v[0])), fmaxf(fabsf(v[1]), fabsf(v[2]))), fabsf(v[3])); };
+    // y_amax epilogue: max |y| of everything this thread stores (rows below the image included: still a bound), kept as a BIT PATTERN
+    // (non-negative floats order as unsigned integers, and every NaN orders above +inf): a non-finite output is STICKY where
+    // v_max_f32 would drop a NaN - the host's overflow guard reads these slots (ops.split_guard_submit).
+    unsigned amx = 0u;
+    auto abits = [](float v) { return __builtin_bit_cast(unsigned, v) & 0x7fffffffu; };
+    // max |.| of one 4x4 output tile.  Y[0][0], Y[0][3], Y[3][0], Y[3][3] together depend on all 36 positions of M (A^T rows 0 and 3
+    // cover columns 0..4 and 1..5), and 0 * (inf or NaN) = NaN: four fmas see an overflow anywhere in the tile's products
+    auto amax16 = [&](const f32x4 (&Y)[4]) {
+      float m = fmaxf(fmaxf(fabsf(Y[0][0]), fabsf(Y[0][1])), fmaxf(fabsf(Y[0][2]), fabsf(Y[0][3])));
+#pragma unroll
+      for (int i = 1; i < 4; ++i) m = fmaxf(fmaxf(fmaxf(m, fabsf(Y[i][0])), fmaxf(fabsf(Y[i][1]), fabsf(Y[i][2]))), fabsf(Y[i][3]));
+      const float chk = __builtin_fmaf(Y[0][0], 0.f, __builtin_fmaf(Y[0][3], 0.f, __builtin_fmaf(Y[3][0], 0.f, Y[3][3] * 0.f)));
+      amx = max(max(amx, __builtin_bit_cast(unsigned, m)), abits(chk));
+    };
     for (int item = item_first; item < item_end; item += xcd_wgs) {
       int e_co_blk, e_img, e_ty0, e_tx0;
       decode(item, e_co_blk, e_img, e_ty0, e_tx0);
@@ -297,13 +360,20 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
       for (int k = 0; k < n_chunks; ++k) {
         unsigned *Vd = Vst + (par ^ 1) * VSLAB;
         read_patch();
+        F4S_POS_STAMP(0);
         advance();
         load_begin(l_k * CK);
         dma_issue();
+        F4S_POS_STAMP(1);
 #pragma unroll
         for (int cp = 0; cp < 3; ++cp) transform_cols(cp);
+        F4S_POS_STAMP(2);
 #pragma unroll
-        for (int r = 0; r < 6; ++r) commit_row(Vd, r);
+        for (int r = 0; r < 3; ++r) commit_row(Vd, r);
+        F4S_POS_STAMP(3);
+#pragma unroll
+        for (int r = 3; r < 6; ++r) commit_row(Vd, r);
+        F4S_POS_STAMP(4);
         F4S_BARRIER();
         par ^= 1;
       }
@@ -382,6 +452,7 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
             Y[3][2 * jp] = y3[0]; Y[3][2 * jp + 1] = y3[1];
           }
           if (sig && co >= d.act_from) {
+            if (d.y_amax) amx = max(amx, abits(__builtin_fmaf(Y[0][0], 0.f, __builtin_fmaf(Y[0][3], 0.f, __builtin_fmaf(Y[3][0], 0.f, Y[3][3] * 0.f)))));  // (a sigmoid maps +-inf to finite values)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -389,10 +460,7 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
           }
           if (SHF) {
             prefetch(min(p + 1, 7));
-            if (d.y_amax) {
-#pragma unroll
-              for (int i = 0; i < 4; ++i) amax4(Y[i]);
-            }
+            if (d.y_amax) amax16(Y);
             if ((p & 1) == 0) {
 #pragma unroll
               for (int i = 0; i < 4; ++i) Yprev[i] = Y[i];
@@ -423,10 +491,7 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
                 for (int jj = 0; jj < 4; ++jj) Y[i][jj] = __builtin_fmaf(Y[i][jj], a.ys, rr[i][jj]);
             }
             prefetch(min(p + 1, 7));
-            if (d.y_amax) {
-#pragma unroll
-              for (int i = 0; i < 4; ++i) amax4(Y[i]);
-            }
+            if (d.y_amax) amax16(Y);
             if (co < d.co) {
               float *q = y + (int64_t)co * plane + pix;
 #pragma unroll
@@ -445,7 +510,7 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
                   if (d.abs_sum && co < d.abs_sum_channels) asum += fabsf(o);
                   if (gt) o *= gt[off + jj] > 0.f ? a.ys : a.ys_gs;
                   else if (r1) o = __builtin_fmaf(o, a.ys, r1[off + jj] + (r2 ? r2[off + jj] : 0.f));
-                  amx = fmaxf(amx, fabsf(o));
+                  amx = max(amx, abits(o));
                   if (shuffle)
                     y[(int64_t)(co >> 2) * plane * 4 + (2 * (oy + i) + ((co >> 1) & 1)) * (2 * d.w) + 2 * (ox + jj) + (co & 1)] = o;
                   else
@@ -466,8 +531,8 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
     if (d.abs_sum) asum_flush();
     if (d.y_amax) {
 #pragma unroll
-      for (int sh = 32; sh > 0; sh >>= 1) amx = fmaxf(amx, __shfl_xor(amx, sh));
-      if (lane == 0 && amx > 0.f) atomicMax(reinterpret_cast<unsigned *>(d.y_amax), __builtin_bit_cast(unsigned, amx));  // non-negative floats order as integers
+      for (int sh = 32; sh > 0; sh >>= 1) amx = max(amx, (unsigned)__shfl_xor((int)amx, sh));
+      if (lane == 0 && amx > 0u) atomicMax(reinterpret_cast<unsigned *>(d.y_amax), amx);  // non-negative floats order as integers, NaNs above them
     }
     F4S_TRACE_FLUSH();
   } else {
@@ -476,6 +541,91 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
     const __amdgpu_buffer_rsrc_t u_rsrc = uniform_rsrc(a.U, 64 + a.cop * a.ci * 36 * 4);
     const int voff = lane * 16;
     f32x16 acc[6];
+#if F4S_MODE >= 1
+    // V arrives as fp32; THIS wave splits the four channels of its B operand (8 v_fma_mix per position - the two co halves of a row
+    // both do it: redundant, but on three interleaved instruction streams per SIMD instead of the lone staging wave's).  The
+    // registers come from the weights: three positions of A in flight (half a chunk ahead) instead of six.
+    const float s_v = f4s_input_scale(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *d.x_amax))));
+    i32x4 A[3];
+    int u_base = 0, u_next = 0;
+    auto item_base = [&](int co_blk) { return 64 + ((((co_blk >> 6) * n_chunks) * 6 + row) * 2 + wm) * (6 * 1024); };
+    auto load_a = [&](int buf, int soff) { A[buf] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, voff, soff, 0)); };
+    int co_blk, img_, ty_, tx_;
+    decode(item_first, co_blk, img_, ty_, tx_);
+    u_base = item_base(co_blk);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) load_a(c, u_base + c * 1024);
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    F4S_BARRIER();
+
+    int par = 0;
+    const unsigned *const Vst = reinterpret_cast<const unsigned *>(smem);
+    unsigned v_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned *)(Vst + 4 * half * 36 * 32 + row * 6 * 32 + j);
+    int v_step = __builtin_amdgcn_readfirstlane(VSLAB * 4);
+    float X[2][4];
+#define F4S_READ4(xs, c)                                                                                                              \
+  asm volatile("ds_read_b32 %0, %4 offset:%5\n\tds_read_b32 %1, %4 offset:%6\n\tds_read_b32 %2, %4 offset:%7\n\tds_read_b32 %3, %4 offset:%8" \
+               : "=&v"(xs[0]), "=&v"(xs[1]), "=&v"(xs[2]), "=&v"(xs[3])                                                              \
+               : "v"(v_addr), "n"((c) * 128), "n"(36 * 128 + (c) * 128), "n"(2 * 36 * 128 + (c) * 128), "n"(3 * 36 * 128 + (c) * 128)   \
+               : "memory")
+    for (int item = item_first; item < item_end; item += xcd_wgs) {
+      {
+        const int nx = item + xcd_wgs;
+        decode(nx < item_end ? nx : item, co_blk, img_, ty_, tx_);
+        u_next = item_base(co_blk);
+      }
+#pragma unroll 1
+      for (int k = 0; k < n_chunks; ++k) {
+        const int soff_cur = u_base + k * UCHUNK;
+        const int soff_nxt = k + 1 < n_chunks ? soff_cur + UCHUNK : u_next;  // (at the end: the next item's first chunk)
+        F4S_READ4(X[0], 0);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          float(&xc)[4] = X[c & 1];
+          if (c < 5) {
+            float(&xn)[4] = X[(c + 1) & 1];
+            if (c == 0) F4S_READ4(xn, 1);
+            if (c == 1) F4S_READ4(xn, 2);
+            if (c == 2) F4S_READ4(xn, 3);
+            if (c == 3) F4S_READ4(xn, 4);
+            if (c == 4) F4S_READ4(xn, 5);
+            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(xc[0]), "+v"(xc[1]), "+v"(xc[2]), "+v"(xc[3])::"memory");
+          } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xc[0]), "+v"(xc[1]), "+v"(xc[2]), "+v"(xc[3])::"memory");
+          }
+          int b0, b1, b2, b3;
+#if F4S_MODE == 2
+          b0 = __builtin_bit_cast(int, xc[0]), b1 = __builtin_bit_cast(int, xc[1]), b2 = __builtin_bit_cast(int, xc[2]), b3 = __builtin_bit_cast(int, xc[3]);
+#else
+          asm volatile(
+              "v_fma_mixlo_f16 %0, %4, %8, 0\n\tv_fma_mixlo_f16 %1, %5, %8, 0\n\tv_fma_mixlo_f16 %2, %6, %8, 0\n\tv_fma_mixlo_f16 %3, %7, %8, 0\n\t"
+              "v_fma_mixhi_f16 %0, %4, %8, -%0 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %1, %5, %8, -%1 op_sel_hi:[0,0,1]\n\t"
+              "v_fma_mixhi_f16 %2, %6, %8, -%2 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %3, %7, %8, -%3 op_sel_hi:[0,0,1]"
+              : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
+              : "v"(xc[0]), "v"(xc[1]), "v"(xc[2]), "v"(xc[3]), "s"(s_v));
+#endif
+          const f16x8 B = __builtin_bit_cast(f16x8, i32x4{b0, b1, b2, b3});
+          i32x4 &Ac = A[c % 3];
+          acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Ac), B, acc[c], 0, 0, 0);
+          // (hi, lo) -> (lo, hi) IN PLACE (no second register set), then the set is re-requested three positions ahead
+          asm volatile("v_alignbit_b32 %0, %0, %0, 16\n\tv_alignbit_b32 %1, %1, %1, 16\n\tv_alignbit_b32 %2, %2, %2, 16\n\tv_alignbit_b32 %3, %3, %3, 16"
+                       : "+v"(Ac[0]), "+v"(Ac[1]), "+v"(Ac[2]), "+v"(Ac[3]));
+          acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Ac), B, acc[c], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          load_a(c % 3, c < 3 ? soff_cur + (c + 3) * 1024 : soff_nxt + (c - 3) * 1024);
+          F4S_POS_STAMP(c);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        v_addr += v_step;  // the other stage
+        v_step = -v_step;
+        F4S_BARRIER();
+        par ^= 1;
+      }
+#undef F4S_READ4
+#else
     i32x4 A[6];  // A operand of position (row, c): 4 channels x (hi, lo); a set is re-requested right after its use, one chunk ahead
     int u_base = 0, u_next = 0;  // byte offsets of (co block, chunk 0, row, wm) of this item and of the next
     auto item_base = [&](int co_blk) { return 64 + ((((co_blk >> 6) * n_chunks) * 6 + row) * 2 + wm) * (6 * 1024); };
@@ -533,6 +683,7 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
         F4S_BARRIER();
         par ^= 1;
       }
+#endif
       u_base = u_next;
       // ---- row pass T = M A (6 -> 4) and hand-over to the staging waves: 8 phases of two accumulator registers.  The store address
       //      is derived HERE from an opaque copy of the lane index: hoisted out of the item loop it stays live across the chunk loop,
@@ -557,9 +708,11 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
         }
         F4S_BARRIER();
       }
+#if F4S_MODE == 0
       // the next item's first chunk of U: requested here, not from the last chunk step - 24 registers live across the row pass do not fit
 #pragma unroll
       for (int c = 0; c < 6; ++c) load_a(c, u_base);
+#endif
 #pragma unroll
       for (int c = 0; c < 6; ++c)
 #pragma unroll
@@ -595,10 +748,14 @@ __global__ void winograd_f4s_weight_kernel(const float *__restrict__ w, unsigned
     pack_f4s_elem(w, U, i, co, ci, cop, cip, transpose_flip, s_u);
 }
 
-// out[0] = max(out[0], max |x|) over n images of `per_img` contiguous elements (bit pattern compare: non-negative floats order as
-// integers).  16-byte loads, four in flight per thread; contiguous batches are folded into one long image by the launcher.
+// out[0] = max(out[0], max |x|) over n images of `per_img` contiguous elements, as BIT PATTERNS: non-negative floats order as unsigned
+// integers and every NaN orders above +inf, so a non-finite element is sticky (v_max_f32 would drop a NaN) - a consumer's scale
+// then falls back to a harmless one (f4s_input_scale) and the host's overflow guard sees the slot.  16-byte loads, four in flight
+// per thread; contiguous batches are folded into one long image by the launcher.
 __global__ __launch_bounds__(256) void amax_kernel(const float *__restrict__ x, unsigned *__restrict__ out, int n, int64_t per_img, int64_t img_stride) {
-  float m = 0.f;
+  unsigned m = 0u;
+  auto ab = [](float v) { return __builtin_bit_cast(unsigned, v) & 0x7fffffffu; };
+  auto ab4 = [&](const f32x4 &v) { return max(max(ab(v[0]), ab(v[1])), max(ab(v[2]), ab(v[3]))); };
   const int64_t quads = per_img >> 2;
   const int64_t step = (int64_t)gridDim.x * 256;
   for (int img = blockIdx.y; img < n; img += gridDim.y) {
@@ -608,22 +765,17 @@ __global__ __launch_bounds__(256) void amax_kernel(const float *__restrict__ x, 
       int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
       for (; i + 3 * step < quads; i += 4 * step) {
         const f32x4 a = q[i], b = q[i + step], c = q[i + 2 * step], e = q[i + 3 * step];
-        const f32x4 ab = {fmaxf(fabsf(a[0]), fabsf(b[0])), fmaxf(fabsf(a[1]), fabsf(b[1])), fmaxf(fabsf(a[2]), fabsf(b[2])), fmaxf(fabsf(a[3]), fabsf(b[3]))};
-        const f32x4 ce = {fmaxf(fabsf(c[0]), fabsf(e[0])), fmaxf(fabsf(c[1]), fabsf(e[1])), fmaxf(fabsf(c[2]), fabsf(e[2])), fmaxf(fabsf(c[3]), fabsf(e[3]))};
-        m = fmaxf(m, fmaxf(fmaxf(fmaxf(ab[0], ce[0]), fmaxf(ab[1], ce[1])), fmaxf(fmaxf(ab[2], ce[2]), fmaxf(ab[3], ce[3]))));
+        m = max(m, max(max(ab4(a), ab4(b)), max(ab4(c), ab4(e))));
       }
-      for (; i < quads; i += step) {
-        const f32x4 v = q[i];
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-      }
-      for (int64_t t = quads * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; t < per_img; t += step) m = fmaxf(m, fabsf(p[t]));
+      for (; i < quads; i += step) m = max(m, ab4(q[i]));
+      for (int64_t t = quads * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; t < per_img; t += step) m = max(m, ab(p[t]));
     } else {
-      for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < per_img; t += step) m = fmaxf(m, fabsf(p[t]));
+      for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < per_img; t += step) m = max(m, ab(p[t]));
     }
   }
 #pragma unroll
-  for (int sh = 32; sh > 0; sh >>= 1) m = fmaxf(m, __shfl_xor(m, sh));
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __builtin_bit_cast(unsigned, m));
+  for (int sh = 32; sh > 0; sh >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, sh));
+  if ((threadIdx.x & 63) == 0 && m > 0u) atomicMax(out, m);
 }
 
 bool winograd_f4s_enabled() {

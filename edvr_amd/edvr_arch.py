@@ -233,6 +233,8 @@ class EDVR(nn.Module):
         x = x.contiguous()
         ctr = self.center_frame_idx
         self.check_offsets(wait=False)  # offset statistics of earlier forwards whose copy has landed: no synchronisation
+        if x.is_cuda:
+            F_.ops.split_guard_check(wait=False)  # overflow flags of earlier forwards (split-operand kernels), likewise
         if torch.is_grad_enabled() and x.is_cuda:
             # training: the optimizer has rewritten every weight - all packed layouts of all conv layers in one launch (ops.py)
             if self._conv_weights is None:
@@ -284,6 +286,7 @@ class EDVR(nn.Module):
         else:
             out = F_.upsample4x_add(F_.conv(self.conv_last, out), x_center)
         self._queue_offset_check(sink, b, t)
+        F_.ops.split_guard_submit(x.device)
         return out
 
     def _queue_offset_check(self, sink, b, t):

@@ -14,7 +14,8 @@ of ~170 short kernels (>= 15 us each), which a graph replays as it is.
 What a replay freezes: shapes, the packed weights (replays keep using the layouts packed at capture time - the graph holds those
 buffers and pins them against the training path's in-place re-packing: call `refresh()` after changing parameters - `__call__`
 checks the parameters' version counters and refuses to replay stale weights), and the per-layer
-performance hints (halo class of the fused DCN kernel): results do not depend on them.
+performance hints (halo class of the fused DCN kernel: a replay keeps the class of capture time, so replays are bit-identical
+to each other; the classes agree with one another to fp32 rounding, not bit for bit - include/edvr_amd.h `halo_hint`).
 """
 import torch
 
@@ -47,9 +48,14 @@ class GraphedEDVR:
             for _ in range(max(1, warmup)):  # on the capture stream: its workspace (ops.workspace is per stream) exists before the capture
                 net(self.static_in)
             net.check_offsets()  # flush: nothing pending may be examined inside the capture
+            ops.split_guard_check(wait=True)
+            ops.reserve_amax_slots(self.static_in.device)  # a fresh block of bound slots: no allocation / zero-fill inside the graph
+            arena = ops._arena(self.static_in.device)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=s):
                 self.static_out = net(self.static_in)
+            # the slots the captured launches write: folded into the overflow guard after every replay (nothing inside the graph)
+            self._guard_slots = arena.take_unexamined()
         torch.cuda.current_stream().wait_stream(s)
         # the captured launches read the packed weight layouts of THIS moment: hold them and keep the training path's in-place
         # re-packing (ops.prepack_conv_weights) off them - a later optimizer step then packs into fresh buffers
@@ -68,8 +74,11 @@ class GraphedEDVR:
             raise ValueError(f'graph captured for {tuple(self.static_in.shape)} {self.static_in.dtype}, got {tuple(x.shape)} {x.dtype}')
         if self.check_weights and self._versions() != self._ver:
             raise RuntimeError('parameters changed since the capture: call refresh() (replays would use stale packed weights)')
+        from . import ops
+        ops.split_guard_check(wait=False)
         self.static_in.copy_(x, non_blocking=True)
         self.graph.replay()
+        ops.split_guard_submit(self.static_in.device, list(self._guard_slots))
         return self.static_out.clone() if self.clone else self.static_out
 
     def check_offsets(self):

@@ -281,8 +281,10 @@ def f4_kwargs(weight, ks, transpose_flip=False):
 def invalidate_packed_weights():
     """Drop every cached packed weight.  The cache follows a parameter's autograd version and storage pointer, which in-place
     torch ops, optimizers and load_state_dict maintain; a write through `.data` (or through a raw pointer that does not call
-    torch.autograd.graph.increment_version afterwards) does not - call this after such a write."""
+    torch.autograd.graph.increment_version afterwards) does not - call this after such a write.  The cached weight norms behind
+    linear_bound() (the magnitude bounds of the split-operand kernels) follow the same key and are dropped with them."""
     _PACKED.clear()
+    _W_L1.clear()
 
 
 # ------------------------------------------------------------------------------------------------ conv
@@ -326,37 +328,147 @@ def set_f4s(inference=None, training=None):
 
 
 class _AmaxArena:
-    """One-element device slots for the `y_amax` epilogue of the split-operand conv kernel: zeroed in blocks of 2048, each slot
-    handed out once (a slot captured by a hipGraph keeps accumulating maxima over replays: still a bound)."""
+    """One-element device slots for the `y_amax` epilogue of the split-operand kernels and for the reduction passes: zeroed in blocks of
+    2048, each slot handed out once (a slot captured by a hipGraph keeps accumulating maxima over replays: still a bound).  One
+    arena per (device, stream): a block is zero-filled on the stream that uses it.  The slots handed out since the last
+    guard_submit() are what the overflow guard examines (a non-finite maximum = non-finite values left a split-operand kernel)."""
+
+    BLOCK = 2048
 
     def __init__(self):
-        self.buf, self.i = None, 0
+        self.buf, self.i, self.mark, self.retired = None, 0, 0, []
+
+    def fresh(self, device):
+        """Start a new block now (GraphedEDVR: BEFORE a capture, so that no allocation / zero-fill is recorded into the graph)."""
+        if self.buf is not None and self.i > self.mark:
+            self.retired.append(self.buf[self.mark:self.i])
+        self.buf, self.i, self.mark = torch.zeros(self.BLOCK, dtype=torch.float32, device=device), 0, 0
 
     def slot(self, device):
-        if self.buf is None or self.i >= self.buf.numel() or self.buf.device != device:
-            self.buf, self.i = torch.zeros(2048, dtype=torch.float32, device=device), 0
+        if self.buf is None or self.i >= self.buf.numel():
+            if self.buf is not None and device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('edvr_amd: the magnitude-bound arena ran out of slots inside a hipGraph capture (more than '
+                                   f'{self.BLOCK} split-operand launches in one captured region); capture a smaller region')
+            self.fresh(device)
         self.i += 1
         return self.buf[self.i - 1:self.i]
 
+    def take_unexamined(self):
+        out, self.retired = self.retired, []
+        if self.buf is not None and self.i > self.mark:
+            out.append(self.buf[self.mark:self.i])
+            self.mark = self.i
+        return out
 
-_AMAX_ARENA = _AmaxArena()
+
+_AMAX_ARENAS = {}  # (device index, stream handle) -> _AmaxArena
+
+
+def _arena(device):
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    a = _AMAX_ARENAS.get(key)
+    if a is None:
+        a = _AMAX_ARENAS[key] = _AmaxArena()
+    return a
+
+
+def reserve_amax_slots(device):
+    """A fresh, zero-filled block of bound slots for the current stream of `device`: call before a hipGraph capture."""
+    _arena(device).fresh(device)
+
+
 BOUND_CHECK = os.environ.get('EDVR_BOUND_CHECK', '0') == '1'  # verify every x_amax against the data (tests / debugging)
 BOUND_CHECK_LOG = []  # (shape, bound / true maximum) of every checked conv input
 AMAX_LOG = None  # a list: every reduction pass of input_bound() is recorded there (shape, calling functions)
 AMAX_PASSES = 0  # how often input_bound() had to run the reduction kernel (measurement: bench.py reports it per forward)
 
 
+# ---- overflow guard of the split-operand path.  The split kernels place their operands in the f16 range from magnitude BOUNDS; a bound
+# that is too small (a stale one: a raw-pointer write behind torch's back) overflows f16 to inf and the products to NaN - silently.
+# Every split conv leaves max |y| in an arena slot with non-finite values STICKY (NaN bits order above every finite number), the
+# reduction kernel does the same, so one 2048-element max per forward says whether anything non-finite passed through a split
+# kernel.  It is read like the offset statistics: copy to pinned memory behind an event, examined when the next forward starts (or by
+# split_guard_check(wait=True)); no forward waits for the GPU.
+class SplitOperandOverflow(RuntimeError):
+    pass
+
+
+SPLIT_GUARD = os.environ.get('EDVR_SPLIT_GUARD', 'raise')  # 'raise' | 'fallback' (warn once, continue on the fp32 kernels) | 'off'
+_GUARD_PENDING = []  # (pinned 1-element host tensor, copy-done event)
+GUARD_TRIPS = 0
+
+
+def split_guard_submit(device, parts=None):
+    """Fold the bound slots handed out on the current stream since the last call (or `parts`: the slots of a replayed hipGraph) into
+    one flag and send it to the host (no wait)."""
+    if SPLIT_GUARD == 'off' or device.type != 'cuda' or torch.cuda.is_current_stream_capturing():
+        return
+    if parts is None:
+        parts = _arena(device).take_unexamined()
+    if not parts:
+        return
+    with torch.no_grad():
+        worst = (parts[0] if len(parts) == 1 else torch.cat(parts)).max().reshape(1)  # torch.max propagates NaN
+    host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+    host.copy_(worst, non_blocking=True)
+    done = torch.cuda.Event()
+    done.record()
+    _GUARD_PENDING.append((host, done))
+    if len(_GUARD_PENDING) > 64:
+        split_guard_check(wait=True)
+
+
+def split_guard_check(wait=False):
+    """Examine the flags that have arrived (wait=True: all of them, one synchronisation).  Non-finite -> SplitOperandOverflow, or with
+    EDVR_SPLIT_GUARD=fallback a warning and the fp32 kernels from here on."""
+    global GUARD_TRIPS
+    while _GUARD_PENDING:
+        host, done = _GUARD_PENDING[0]
+        if wait:
+            done.synchronize()
+        elif not done.query():
+            return
+        _GUARD_PENDING.pop(0)
+        v = float(host[0])
+        if v != v or v == float('inf'):
+            GUARD_TRIPS += 1
+            msg = ('edvr_amd: non-finite values left a split-operand kernel (max |y| = %r): either the input holds inf / NaN, or a '
+                   'magnitude bound was stale (a tensor rewritten through a raw pointer after its bound was taken: see '
+                   'ops.void_bound).  EDVR_WINOGRAD_F4S=0 runs the fp32 kernels.' % v)
+            if SPLIT_GUARD == 'fallback':
+                import warnings
+                warnings.warn(msg + '  Continuing on the fp32 kernels.')
+                set_f4s(False, False)
+            else:
+                raise SplitOperandOverflow(msg)
+
+
+def _ver(t):
+    """The autograd version counter a bound is tied to; inference tensors (torch.inference_mode) do not have one - and cannot be
+    written in place outside inference mode: None."""
+    return None if t.is_inference() else t._version
+
+
 def set_bound(t, bound, depth=0):
     """Remember `bound` (1-element device tensor >= max |t|) on the tensor object; valid while t is not written again.
     depth: 0 = measured (the split-operand kernel's y_amax epilogue, the reduction kernel), 1 = derived from a measured one through the
     weights' norms (linear_bound) - typically 10-50x the true maximum, which the split costs nothing (it has 2^18 of slack); a SECOND
-    derivation on top would multiply the looseness (1e10 after a few layers), so it is refused and the consumer measures instead."""
-    t._edvr_amax = (bound, t._version, depth)
+    derivation on top would multiply the looseness (1e10 after a few layers), so it is refused and the consumer measures instead.
+    Every function of this module that writes into a caller's tensor through a raw pointer replaces or voids its bound (void_bound):
+    the version counter does not see those writes."""
+    t._edvr_amax = (bound, _ver(t), depth)
 
 
 def get_bound(t):
     b = getattr(t, '_edvr_amax', None)
-    return b[0] if (b is not None and b[1] == t._version and b[0].device == t.device) else None
+    return b[0] if (b is not None and b[1] == _ver(t) and b[0].device == t.device) else None
+
+
+def void_bound(*ts):
+    """Forget the bounds of tensors a kernel has just rewritten through raw pointers (`out=` buffers, in-place kernels)."""
+    for t in ts:
+        if t is not None and hasattr(t, '_edvr_amax'):
+            del t._edvr_amax
 
 
 def _bound_depth(t):
@@ -443,7 +555,7 @@ def amax(x, out=None):
     x = _as_planes(x)
     n, c, h, w = x.shape
     if out is None:
-        out = torch.zeros(1, dtype=torch.float32, device=x.device)
+        out = _arena(x.device).slot(x.device)  # (zeroed; examined by the overflow guard: the kernel keeps non-finite values sticky)
     _run('amax', lambda: _lib.check(_lib.lib().edvr_amax_f32(_ptr(x), _ptr(out), n, c * h * w, _img_stride(x), _stream()), 'edvr_amax_f32'),
          0, _nb(x))
     return out
@@ -529,7 +641,7 @@ def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NON
                 BOUND_CHECK_LOG.append((tuple(x1.shape), x_amax.item() / max(true, 1e-30)))
             d.x_amax = _ptr(x_amax)
             if want_y_amax:
-                y_bound = _AMAX_ARENA.slot(x1.device)
+                y_bound = _arena(x1.device).slot(x1.device)
                 d.y_amax = _ptr(y_bound)
         else:
             d.wpk_f4s, d.x_amax = None, None
@@ -552,8 +664,8 @@ def conv2d(x1, wpk, bias, co, ks, *, x2=None, x2_map=None, stride=1, act=ACT_NON
     _run(name, lambda: _lib.check(L.edvr_conv2d_f32(ctypes.byref(d), _stream()), 'edvr_conv2d_f32'), flops, nbytes, executed)
     if y_bound is not None:
         set_bound(out, y_bound)
-    elif hasattr(out, '_edvr_amax'):
-        del out._edvr_amax  # a caller-provided buffer rewritten by a kernel without the epilogue: its old bound is void
+    else:
+        void_bound(out)  # a caller-provided buffer rewritten by a kernel without the epilogue: its old bound is void
     if abs_sum_channels > 0:
         if sums is None:
             return out, abs_stats_per_image(out[:, :abs_sum_channels])
@@ -604,6 +716,7 @@ def dcnv1_forward(x, offset, weight, stride, pad, dil, groups, dg, halo_hint=0, 
     _run('dcnv1_fwd', lambda: _lib.check(L.edvr_dcnv1_fwd_f32(_ptr(x), _ptr(offset), _ptr(weight), _ptr(y), *dims, _bstride(offset), halo_hint, _ptr(ws), nbytes,
                                     _stream()),
                                        'edvr_dcnv1_fwd_f32'), 2.0 * B * Co * ho * wo * weight.shape[1] * kh * kw, _nb(x, offset, weight, y))
+    void_bound(y)  # (a caller's `out` buffer: whatever bound it carried described its old contents)
     return y
 
 
@@ -654,6 +767,8 @@ def _bstride(t):
 def dcnv2_forward(x, offset, mask, weight, bias, stride, pad, dil, groups, dg, act=ACT_NONE, halo_hint=0, out=None, xm_bound=None):
     """out: optional preallocated (B, Co, Ho, Wo) contiguous tensor the kernels write in place (the reference's `output` argument,
     deform_conv_cuda.cpp:530-568).
+    halo_hint: which kernel class runs (performance only).  The classes compute the same operator in different summation orders:
+    their results agree to fp32 rounding (<= 2e-5 of the output scale, tests/test_gpu_dcn.py), NOT bit for bit.
     xm_bound: 1-element device tensor >= max |x| * max(1, max |mask|) (for sigmoid masks: a bound of |x|, `input_bound(x)`): allows the
     split-operand form of the tap-window kernel (csrc/dcn_tapwin_s.hip) where that kernel applies; None = the fp32 kernels."""
     dt = require_gpu(x, offset, mask, weight, bias, dtypes=tuple(DCN_DTYPES))
@@ -687,6 +802,7 @@ def dcnv2_forward(x, offset, mask, weight, bias, stride, pad, dil, groups, dg, a
         ws = workspace(nbytes, x.device)
         _lib.check(L.edvr_dcnv2_fwd_any(DCN_DTYPES[dt], _ptr(x), _ptr(offset), _ptr(mask), _ptr(weight), _ptr(bias), _ptr(y), *dims,
                                         _bstride(offset), _bstride(mask), _ptr(ws), nbytes, _stream()), 'edvr_dcnv2_fwd_any')
+        void_bound(y)
         return y
     nbytes = L.edvr_dcnv2_fwd_ws_bytes(*dims)
     ws = workspace(nbytes, x.device)
@@ -703,6 +819,7 @@ def dcnv2_forward(x, offset, mask, weight, bias, stride, pad, dil, groups, dg, a
     else:
         launch = lambda: _lib.check(L.edvr_dcnv2_fwd_f32(*common, _stream()), 'edvr_dcnv2_fwd_f32')
     _run(name, launch, 2.0 * B * Co * Ho * Wo * weight.shape[1] * kh * kw, _nb(x, offset, mask, weight, y))
+    void_bound(y)  # (a caller's `out` buffer: its old bound is void; the module path attaches the new one, dcn.py)
     return y
 
 
@@ -729,6 +846,7 @@ def dcnv2_backward(x, offset, mask, weight, dy, with_bias, stride, pad, dil, gro
         _lib.check(L.edvr_dcnv2_bwd_any(DCN_DTYPES[dt], _ptr(x), _ptr(offset), _ptr(mask), _ptr(weight), _ptr(dy), _ptr(dx), _ptr(doff),
                                         _ptr(dmsk), _ptr(dw), _ptr(db), *dims, _bstride(offset), _bstride(mask), _bstride(doff),
                                         _bstride(dmsk), _ptr(ws), nbytes, _stream()), 'edvr_dcnv2_bwd_any')
+        void_bound(doff, dmsk)
         return dx, doff, dmsk, dw, db
     nbytes = L.edvr_dcnv2_bwd_ws_bytes(*dims)
     ws = workspace(nbytes, x.device)
@@ -741,6 +859,7 @@ def dcnv2_backward(x, offset, mask, weight, dy, with_bias, stride, pad, dil, gro
         launch = lambda: _lib.check(L.edvr_dcnv2_bwd_f32(*common, _stream()), 'edvr_dcnv2_bwd_f32')
     _run('dcnv2_bwd' + _SCATTER_NAMES.get(int(scatter_hint), ''), launch, 4.0 * dy.numel() * weight[0].numel(),
          _nb(x, offset, mask, weight, dy, dx, doff, dmsk, dw))
+    void_bound(doff, dmsk)
     return dx, doff, dmsk, dw, db
 
 
@@ -799,8 +918,13 @@ def upsample4x_add_(y, base):
     base = base.contiguous()
     n, c, h, w = base.shape
     assert y.is_contiguous() and tuple(y.shape) == (n, c, 4 * h, 4 * w)
+    by, bb = get_bound(y), get_bound(base)  # before the write: |y + up(base)| <= bound(y) + bound(base) (bilinear weights sum to one)
+    depth = max(_bound_depth(y), _bound_depth(base)) if (by is not None and bb is not None) else 0
     _run('upsample4x_add', lambda: _lib.check(_lib.lib().edvr_upsample4x_add_f32(_ptr(base), _ptr(y), n * c, h, w, _stream()),
                                        'edvr_upsample4x_add_f32'), 0, _nb(base, y, y))
+    void_bound(y)  # the raw-pointer write does not move y's version counter: the old bound must not survive it
+    if by is not None and bb is not None:
+        set_bound(y, by + bb, depth)
     return y
 
 
@@ -943,6 +1067,7 @@ def frame_reduce_add_(src, dst, t, center):
     assert dst.is_contiguous() and src.shape == dst.shape and src.shape[0] % t == 0
     _run('frame_reduce_add', lambda: _lib.check(_lib.lib().edvr_frame_reduce_add_f32(_ptr(src), _ptr(dst), src.shape[0] // t, t, center, src[0].numel(), _stream()),
                                        'edvr_frame_reduce_add_f32'), 0, _nb(src) + 8.0 * src.numel() / t)
+    void_bound(dst)  # rewritten in place through a raw pointer: the consumer measures
     return dst
 
 

@@ -35,3 +35,6 @@ rel5 = min(u(buf[(5 * 16 + wv) * 2 + 1]) for wv in range(16))
 print('positions of the chunk step after barrier 5 (cycles after its release), per multiplying wave:')
 for wv in range(4, 16):
     print(f'  wave {wv:2d} (SIMD {wv % 4}): ' + ' '.join(f'{u(buf[16 * 2 * SL + wv * 8 + c]) - rel5:6d}' for c in range(6)))
+print('the same chunk step in the staging waves: patch in registers | next DMA issued | column transform | rows 0-2 committed | rows 3-5 committed')
+for wv in range(4):
+    print(f'  wave {wv:2d} (SIMD {wv % 4}): ' + ' '.join(f'{u(buf[16 * 2 * SL + wv * 8 + c]) - rel5:6d}' for c in range(5)))

@@ -1,4 +1,6 @@
 """-m gpu: the fp32 MFMA conv kernel (through the C ABI) against torch's CPU conv in fp64."""
+import zlib
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -50,7 +52,7 @@ def test_conv2d_matches_fp64(gpu, case, algo):
     from edvr_amd import ops
     algo = {'direct': ops.CONV_DIRECT, 'winograd': ops.CONV_WINOGRAD, 'auto': ops.CONV_AUTO}[algo]  # winograd falls back where not applicable
     n, c1, c2, h, w, co, ks, stride, actn, nres, out_mode = case
-    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    g = torch.Generator().manual_seed(zlib.crc32(repr(case).encode()))  # (hash() of a tuple holding strings changes from process to process)
     x1 = torch.randn(n, c1, h, w, generator=g)
     x2 = torch.randn(n, c2, h, w, generator=g) if c2 else None
     wt = torch.randn(co, c1 + c2, ks, ks, generator=g) * 0.1

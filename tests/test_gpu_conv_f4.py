@@ -2,6 +2,7 @@
 in fp64.  Tolerance: F(4x4) transforms hold coefficients up to 8 (F(2x2): 1), so fp32 rounding is ~1e-6 of the output scale at
 128 channels instead of ~2e-7; the bound below is 3e-5 of the output scale (the path's specification is 1e-3 dB PSNR)."""
 import ctypes
+import zlib
 
 import pytest
 import torch
@@ -45,7 +46,7 @@ CASES = [
 def test_f4_conv_matches_fp64(gpu, case):
     from edvr_amd import _lib, ops
     n, c1, c2, h, w, co, actn, nres, out_mode, x2map, gate = case
-    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    g = torch.Generator().manual_seed(zlib.crc32(repr(case).encode()))  # (hash() of a tuple holding strings changes from process to process)
     x1 = torch.randn(n, c1, h, w, generator=g)
     n2 = n if x2map is None else (n // x2map[0]) * x2map[1]
     x2 = torch.randn(n2, c2, h, w, generator=g) if c2 else None

@@ -3,6 +3,7 @@ matrix pipe, all four cross products, fp32 accumulation) through the C ABI again
 fp32 F(4x4) kernel's test at THE SAME tolerance (3e-5 of the output scale), and against that kernel's own error on the same input:
 the split may not be the less accurate of the two by more than rounding noise."""
 import ctypes
+import zlib
 
 import pytest
 import torch
@@ -15,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 def _case_tensors(case):
     n, c1, c2, h, w, co, actn, nres, out_mode, x2map, gate = case
-    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    g = torch.Generator().manual_seed(zlib.crc32(repr(case).encode()))  # (hash() of a tuple holding strings changes from process to process)
     x1 = torch.randn(n, c1, h, w, generator=g)
     n2 = n if x2map is None else (n // x2map[0]) * x2map[1]
     x2 = torch.randn(n2, c2, h, w, generator=g) if c2 else None
@@ -186,7 +187,7 @@ C1X1_CASES = [
 
 def _c1x1_tensors(case):
     n, c1, c2, h, w, co, actn, nres, x2map = case
-    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    g = torch.Generator().manual_seed(zlib.crc32(repr(case).encode()))  # (hash() of a tuple holding strings changes from process to process)
     x1 = torch.randn(n, c1, h, w, generator=g)
     n2 = n if x2map is None else (n // x2map[0]) * x2map[1]
     x2 = torch.randn(n2, c2, h, w, generator=g) if c2 else None

@@ -230,3 +230,139 @@ def test_magnitude_bounds_reaching_the_split_kernel_are_bounds(gpu, cfg):
     assert n_infer >= 10 and len(ops.BOUND_CHECK_LOG) >= 3 * n_infer - 4  # (forward + data gradient in training; the split 1x1 conv has no data-gradient form)
     worst = max(r for _, r in ops.BOUND_CHECK_LOG)
     assert worst < 4096.0, sorted(ops.BOUND_CHECK_LOG, key=lambda r: -r[1])[:5]
+
+
+# ------------------------------------------------------------------------------------------------ the split path's guards
+def test_forward_under_inference_mode(gpu):
+    """inference tensors have no version counter; the bound bookkeeping must not read it."""
+    from oracle import edvr_oracle as EO
+    net, x, kwargs = build('M_T5')
+    with torch.no_grad():
+        ref = EO.edvr_forward(net.state_dict(), x, **oracle_kwargs(kwargs))
+    net = net.to(gpu)
+    with torch.inference_mode():
+        out = net(x.to(gpu))
+        out2 = net(x.to(gpu))  # (the second forward examines the first one's guard flag)
+    assert _rel(out, ref.double()) < INTERMEDIATE_RTOL and torch.equal(out, out2)
+
+
+def test_heavy_tailed_input_and_weights_stay_inside_the_bounds(gpu):
+    """One 1e4 outlier pixel in the clip and every conv weight x30 (activations grow by orders of magnitude from layer to layer): every
+    bound that reaches a split kernel still bounds its data (BOUND_CHECK compares each with the tensor), nothing overflows (the
+    guard stays quiet) and the output matches the fp64 oracle at the whole-network tolerance."""
+    from edvr_amd import ops
+    from oracle import edvr_oracle as EO
+    net, x, kwargs = build('M_T5')
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if p.dim() == 4 and 'conv_offset' not in n:
+                p.mul_(30.0)
+    x = x.clone()
+    x[0, 2, 1, 7, 9] = 1e4
+    sd64 = {k: v.double() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        ref = EO.edvr_forward(sd64, x.double(), **oracle_kwargs(kwargs))
+    net = net.to(gpu)
+    trips = ops.GUARD_TRIPS
+    ops.BOUND_CHECK, ops.BOUND_CHECK_LOG[:] = True, []
+    try:
+        with torch.no_grad():
+            out = net(x.to(gpu))
+    finally:
+        ops.BOUND_CHECK = False
+    ops.split_guard_check(wait=True)
+    assert ops.GUARD_TRIPS == trips and len(ops.BOUND_CHECK_LOG) >= 10
+    assert torch.isfinite(out).all() and ref.abs().max() > 1e6  # (the weights really did blow the activations up)
+    assert _rel(out, ref) < INTERMEDIATE_RTOL
+
+
+def test_batch_composition_changes_a_clip_only_within_the_conv_tolerance(gpu):
+    """The split kernels scale by max |x| over the WHOLE (b t) tensor, so the low bits of clip A's output depend on which clips share
+    its batch (the reference has no such coupling).  Clip A alone vs clip A beside a 100x brighter clip B: equal
+    within the conv tolerance, and the brighter neighbour costs clip A no accuracy against the oracle."""
+    from oracle import edvr_oracle as EO
+    net, x, kwargs = build('M_T5')
+    xb = torch.rand(x.shape, generator=torch.Generator().manual_seed(5)) * 100.0
+    with torch.no_grad():
+        ref = EO.edvr_forward({k: v.double() for k, v in net.state_dict().items()}, x.double(), **oracle_kwargs(kwargs))
+    net = net.to(gpu)
+    with torch.no_grad():
+        alone = net(x.to(gpu))
+        both = net(torch.cat([x, xb]).to(gpu))
+    scale = ref.abs().max().item()
+    assert (alone - both[:1]).abs().max().item() / scale < 3e-5  # the F(4x4) conv tolerance (tests/test_gpu_conv_f4s.py)
+    assert _rel(alone, ref) < INTERMEDIATE_RTOL and _rel(both[:1], ref) < INTERMEDIATE_RTOL
+
+
+def test_overflow_guard_catches_a_stale_bound(gpu):
+    """A bound that is too small overflows the f16 operands to inf / NaN.  The conv's own y_amax slot keeps a non-finite maximum
+    sticky, and the guard reads the slots without stalling the forward: the error surfaces at the next check."""
+    from edvr_amd import ops
+    ops.split_guard_check(wait=True)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 64, 16, 64, generator=g).to(gpu)
+    w = (torch.randn(64, 64, 3, 3, generator=g) * 0.1).to(gpu)
+    wpk, wf4s = ops.pack_conv_weight(w), ops.pack_conv_weight(w, f4s=True)
+    ops.split_guard_submit(gpu)  # (whatever earlier tests left)
+    ops.split_guard_check(wait=True)
+    good = ops.conv2d(x, wpk, None, 64, 3, wpk_f4s=wf4s, x_amax=ops.amax(x), algo=ops.CONV_WINOGRAD_F4S)
+    ops.split_guard_submit(gpu)
+    ops.split_guard_check(wait=True)  # quiet
+    assert torch.isfinite(good).all() and torch.isfinite(ops.get_bound(good)).all()
+    stale = torch.full((1,), 1e-4, device=gpu)  # "max |x|" 1e4 times too small
+    bad = ops.conv2d(x, wpk, None, 64, 3, wpk_f4s=wf4s, x_amax=stale, algo=ops.CONV_WINOGRAD_F4S)
+    assert not torch.isfinite(bad).all()
+    assert not torch.isfinite(ops.get_bound(bad)).all()  # sticky in the slot although v_max_f32 would have dropped the NaNs
+    ops.split_guard_submit(gpu)
+    with pytest.raises(ops.SplitOperandOverflow):
+        ops.split_guard_check(wait=True)
+    # the reduction kernel is sticky too: a consumer measuring a tensor with NaNs does not get a finite "bound"
+    assert not torch.isfinite(ops.amax(bad)).all()
+    ops.split_guard_submit(gpu)
+    with pytest.raises(ops.SplitOperandOverflow):
+        ops.split_guard_check(wait=True)
+    # EDVR_SPLIT_GUARD=fallback: a warning, and the fp32 kernels from there on
+    prev = (ops.F4S_INFERENCE, ops.F4S_TRAINING)
+    ops.SPLIT_GUARD = 'fallback'
+    try:
+        ops.amax(bad)
+        ops.split_guard_submit(gpu)
+        with pytest.warns(UserWarning, match='fp32 kernels'):
+            ops.split_guard_check(wait=True)
+        assert (ops.F4S_INFERENCE, ops.F4S_TRAINING) == (False, False)
+    finally:
+        ops.SPLIT_GUARD = 'raise'
+        ops.set_f4s(*prev)
+
+
+def test_out_buffers_and_in_place_kernels_void_stale_bounds(gpu):
+    """kernels write through raw pointers (no version bump), so every function that rewrites a caller's tensor must drop
+    or replace the bound attached to it: dcnv2_forward(out=), dcnv1_forward(out=), upsample4x_add_, frame_reduce_add_."""
+    from edvr_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 16, 8, 8, generator=g).to(gpu)
+    off = (torch.randn(1, 18, 8, 8, generator=g) * 0.5).to(gpu)
+    msk = torch.rand(1, 9, 8, 8, generator=g).to(gpu)
+    w = torch.randn(8, 16, 3, 3, generator=g).to(gpu)
+    out = torch.zeros(1, 8, 8, 8, device=gpu)
+    ops.set_bound(out, torch.zeros(1, device=gpu))
+    ops.dcnv2_forward(x, off, msk, w, None, 1, 1, 1, 1, 1, out=out)
+    assert ops.get_bound(out) is None and out.abs().max() > 0
+    ops.set_bound(out, torch.zeros(1, device=gpu))
+    ops.dcnv1_forward(x, off, w, 1, 1, 1, 1, 1, out=out)
+    assert ops.get_bound(out) is None
+    y = torch.randn(1, 3, 16, 16, generator=g).to(gpu)
+    base = torch.randn(1, 3, 4, 4, generator=g).to(gpu) * 5
+    ops.set_bound(y, ops.amax(y))
+    ops.upsample4x_add_(y, base)  # base has no bound: y must lose its own
+    assert ops.get_bound(y) is None
+    y2 = torch.randn(1, 3, 16, 16, generator=g).to(gpu)
+    ops.set_bound(y2, ops.amax(y2))
+    ops.set_bound(base, ops.amax(base))
+    ops.upsample4x_add_(y2, base)
+    assert float(ops.get_bound(y2)) >= float(y2.abs().max())  # replaced by bound(y) + bound(base)
+    src = torch.randn(6, 4, 8, 8, generator=g).to(gpu)
+    dst = torch.randn(6, 4, 8, 8, generator=g).to(gpu)
+    ops.set_bound(dst, ops.amax(dst))
+    ops.frame_reduce_add_(src, dst, 3, 1)
+    assert ops.get_bound(dst) is None
