@@ -503,11 +503,21 @@ def train_parity(cfg, device, clips=2, offset_bias_sigma=0.5):
 
 
 def trained_like_leg(cfg, batch, args, device, rank, world, dist, sigmas=(4.0, 10.0)):
-    """The headline workload with the offsets of a trained model: conv_offset.bias ~ N(0, sigma^2) per channel."""
+    """The headline workload with the offsets of a trained model.  bias_sigma_S: conv_offset.bias ~ N(0, S^2) per channel on white-noise
+    frames (every tap its own multi-pixel displacement, constant in space).  motion: structured clips (smooth drifting background, moving
+    rectangles, a little texture: tests/util_edvr.py motion_frames) and offset convs rescaled until the offsets vary IN SPACE like a
+    trained model's - per-tap displacements of sigma 3 px plus a field that is smooth inside objects and jumps at their edges, mean
+    |horizontal neighbour difference| ~0.5 px per DCN layer (arch_util.py:243-257)."""
+    from util_edvr import motion_frames, motion_like_offsets
     out = {}
-    for sigma in sigmas:
-        net = build_net(cfg, device, offset_bias_sigma=sigma)
-        x = torch.rand(batch, *cfg['shape'], generator=torch.Generator().manual_seed(rank)).to(device)
+    for sigma in tuple(sigmas) + ('motion',):
+        if sigma == 'motion':
+            net = build_net(cfg, device, offset_bias_sigma=3.0)
+            x = motion_frames(batch, cfg['shape'], seed=rank).to(device)
+            motion_like_offsets(net, x, target_rough=0.5, bias_sigma=3.0)
+        else:
+            net = build_net(cfg, device, offset_bias_sigma=sigma)
+            x = torch.rand(batch, *cfg['shape'], generator=torch.Generator().manual_seed(rank)).to(device)
 
         def step():
             with torch.no_grad():
@@ -518,33 +528,23 @@ def trained_like_leg(cfg, batch, args, device, rank, world, dist, sigmas=(4.0, 1
         if rank == 0:
             net.check_offsets()
             dcns = net.pcd_align.dcn_modules()
+            rough = [m.last_offset_rough for m in dcns]
             rec = {'value': round(batch * world * steps / elapsed, 4), 'unit': 'clips/s', 'ms_per_step': round(elapsed / steps * 1e3, 3), 'steps': steps,
-                   'clips_per_gpu': batch, 'offset_bias_sigma': sigma,
+                   'clips_per_gpu': batch, 'offset_bias_sigma': 3.0 if sigma == 'motion' else sigma,
+                   'frames': 'structured (tests/util_edvr.py motion_frames)' if sigma == 'motion' else 'torch.rand',
                    'mean_abs_offset_px': [round(m.last_offset_absmean, 3) for m in dcns],
-                   'offset_roughness_px': [None if m.last_offset_rough is None else round(m.last_offset_rough, 3) for m in dcns]}
+                   'offset_roughness_px': [None if r is None else round(r, 3) for r in rough],
+                   'offset_roughness_px_mean': round(sum(r or 0.0 for r in rough) / len(rough), 3)}
             if not args.no_roofline:
                 per = instrumented_pass(step, 1)
                 tab = kernel_table(per, 1, elapsed / steps)
                 for k, v in tab.items():
                     if k.startswith('dcnv2_fwd'):
                         rec[k] = v
+                rec['dcn_kernel_classes'] = sorted(k for k in tab if k.startswith('dcnv2'))
             if world == 1 and not args.no_stock_baseline:
-                from oracle import dcn_oracle, edvr_oracle as EO
-                try:
-                    x1 = x[:1].contiguous()
-                    sc = cfg.get('scale', 4)
-                    gt = torch.rand(1, 3, sc * cfg['shape'][2], sc * cfg['shape'][3], generator=torch.Generator().manual_seed(1)).to(device)
-                    with torch.no_grad():
-                        ours = net(x1)
-                        ref = EO.edvr_forward(net.state_dict(), x1, dcn=dcn_oracle.dcnv2_torch, conv_impl='unfold', **oracle_kw(cfg))
-                    err = _rel_err(ours, ref)
-                    p_ours, p_ref = EO.psnr(ours, gt), EO.psnr(ref, gt)
-                    rec['parity'] = dict(against='stock PyTorch-ROCm fp32 ops (F.unfold + GEMM convs, pure-torch DCNv2) on this GPU, one clip, same weights',
-                                         max_rel_err=err, d_psnr=round(abs(p_ours - p_ref), 8), tolerance={'max_rel_err': 2e-4, 'd_psnr_db': 1e-3},
-                                         ok=bool(err < 2e-4 and abs(p_ours - p_ref) <= 1e-3))
-                except Exception as e:  # (a witness arm must never take the measurement down)
-                    rec['parity'] = {'error': f'{type(e).__name__}: {str(e)[:200]}'}
-            out[f'bias_sigma_{sigma:g}'] = rec
+                rec['parity'] = one_clip_parity(net, cfg, x, device)
+            out['motion' if sigma == 'motion' else f'bias_sigma_{sigma:g}'] = rec
         del net, x, step
         torch.cuda.empty_cache()
     return out if rank == 0 else None
@@ -652,6 +652,25 @@ def train_leg(args, device, rank, world, dist):
             except Exception as e:
                 tl['parity'] = {'error': f'{type(e).__name__}: {str(e)[:300]}'}
         out['trained_like'] = tl
+        # ... and with offsets that vary in SPACE as a trained model's do (structured crops, offset convs rescaled to ~0.5 px of
+        # neighbour difference per DCN layer: trained_like_leg's `motion`), which is what decides the backward's dX strategy per layer
+        del step, net
+        torch.cuda.empty_cache()
+        from util_edvr import motion_frames, motion_like_offsets
+        net = build_net(cfg, device, offset_bias_sigma=3.0)
+        xm = motion_frames(cfg['batch'], cfg['shape'], seed=rank).to(device)
+        motion_like_offsets(net, xm, target_rough=0.5, bias_sigma=3.0)
+        step = make_train_step(net, cfg, cfg['batch'], device, rank, 'fused', x=xm)
+        e3 = timed(step, tsteps, 3, dist, device)  # all ranks
+        mo = {'offset_bias_sigma': 3.0, 'frames': 'structured (tests/util_edvr.py motion_frames)', 'iters_per_sec': round(tsteps / e3, 4),
+              'ms_per_iter': round(e3 / tsteps * 1e3, 2), 'steps': tsteps, 'vs_sub_pixel_offsets': round((tsteps / e3) / (args.train_steps / elapsed), 4)}
+        if rank == 0 and not args.no_roofline and world == 1:
+            tab = kernel_table(instrumented_pass(step, 1), 1, e3 / tsteps)
+            mo['dcn_kernels'] = {k: v for k, v in tab.items() if k.startswith('dcnv2')}
+            dcns = net.pcd_align.dcn_modules()
+            mo['mean_abs_offset_px'] = [round(m.last_offset_absmean, 3) for m in dcns]
+            mo['offset_roughness_px'] = [None if m.last_offset_rough is None else round(m.last_offset_rough, 3) for m in dcns]
+        out['motion'] = mo
     if rank == 0 and world == 1 and not args.no_stock_baseline:
         del step, net
         step = None

@@ -30,14 +30,8 @@
 #include "common.h"
 #include "pack.h"
 
-// experiment switch (removed once settled): 0 = round-5 multiplying loop (six A sets a chunk ahead, B single-buffered); 1 = V stays fp32 in LDS and the
-// multiplying waves split it (A three positions ahead, operand reads double-buffered); 2 = as 1 but the staging waves still split
-#ifndef F4S_MODE
-#define F4S_MODE 0
-#endif
-#ifndef F4S_STAGE_PRIO
-#define F4S_STAGE_PRIO 3
-#endif
+// experiment switch: 1 = the input transform on plain fp32 instructions (v_fma_f32 / v_add_f32 overlap with the f16 matrix pipe of the
+// other waves where v_pk_*_f32 do not - profiles/r5/micro_mfma16_prices.log; -3.5 % on the trunk layer), 0 = packed fp32
 #ifndef F4S_PLAIN
 #define F4S_PLAIN 1
 #endif
@@ -78,47 +72,64 @@ struct WinoF4SArgs {
 
 #define F4S_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-#ifdef F4S_TRACE /* measurement build (scripts/build_variant.sh f4strace -DF4S_TRACE): cycle stamps of workgroup 0, per wave, at every
-                    barrier (arrival / release) and after every position of one chunk step of the multiplying waves.  The stamps are
-                    kept in LDS (32 bits) and copied out at the end: a global store per stamp would sit in the vector-memory counter
-                    between the weight loads and turn their waits into waits for everything. */
-#define F4S_TRACE_SLOTS 48
-#define F4S_TRACE_WORDS (16 * 2 * F4S_TRACE_SLOTS + 16 * 8)
-__device__ unsigned f4s_trace[F4S_TRACE_WORDS];
-#define F4S_STAMP_AT(idx)                                                                   \
-  do {                                                                                      \
-    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {                                       \
-      unsigned long long t_;                                                                \
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
-      f4s_tr[idx] = (unsigned)t_;                                                           \
-    }                                                                                       \
+#ifdef F4S_PROF /* measurement build (scripts/exp/f4s_flags.py prof "-DF4S_PROF"): per wave, cycles (s_memtime) spent waiting at the chunk
+                   barriers [0] and the epilogue barriers [1], in the chunk loops [2] and the epilogues [3], and (staging waves) waiting
+                   for the LDS-DMA [4]; everything stays in scalar registers (the multiplying waves have no vector register to
+                   spare) and is added to f4s_prof[wave][.] once, at the end.  Two s_memtime per barrier: ~3 % on the launch. */
+__device__ unsigned long long f4s_prof[16 * 8];
+#define F4S_NOW(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
+#define F4S_BARRIER_AT(slot)                                        \
+  do {                                                              \
+    unsigned long long a_, b_;                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              \
+    F4S_NOW(a_);                                                    \
+    asm volatile("s_barrier" ::: "memory");                         \
+    F4S_NOW(b_);                                                    \
+    f4s_pc[slot] += (unsigned)(b_ - a_);                            \
   } while (0)
-#define F4S_BARRIER()                                                                        \
-  do {                                                                                       \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                       \
-    if (f4s_slot < F4S_TRACE_SLOTS) F4S_STAMP_AT((f4s_slot * 16 + (threadIdx.x >> 6)) * 2);   \
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                          \
-    if (f4s_slot < F4S_TRACE_SLOTS) F4S_STAMP_AT((f4s_slot * 16 + (threadIdx.x >> 6)) * 2 + 1); \
-    ++f4s_slot;                                                                              \
+#define F4S_SPAN_BEGIN() F4S_NOW(f4s_t0)
+#define F4S_SPAN_END(slot)                                          \
+  do {                                                              \
+    unsigned long long b_;                                          \
+    F4S_NOW(b_);                                                    \
+    f4s_pc[slot] += (unsigned)(b_ - f4s_t0);                        \
+    f4s_t0 = b_;                                                    \
   } while (0)
-#define F4S_POS_STAMP(c)                                                                       \
-  do {                                                                                        \
-    if (f4s_slot == 6) F4S_STAMP_AT(16 * 2 * F4S_TRACE_SLOTS + (threadIdx.x >> 6) * 8 + (c));   \
+#define F4S_WAIT_DMA()                                              \
+  do {                                                              \
+    unsigned long long a_, b_;                                      \
+    F4S_NOW(a_);                                                    \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                \
+    F4S_NOW(b_);                                                    \
+    f4s_pc[4] += (unsigned)(b_ - a_);                               \
   } while (0)
-#define F4S_TRACE_FLUSH()                                                                      \
-  do {                                                                                        \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
-    if (blockIdx.x == 0)                                                                      \
-      for (int i_ = (threadIdx.x & 63); i_ < F4S_TRACE_WORDS; i_ += 64) {                      \
-        const int w_ = i_ < 16 * 2 * F4S_TRACE_SLOTS ? (i_ >> 1) & 15 : (i_ - 16 * 2 * F4S_TRACE_SLOTS) >> 3; \
-        if (w_ == (int)(threadIdx.x >> 6)) f4s_trace[i_] = f4s_tr[i_];                          \
-      }                                                                                       \
+#define F4S_PROF_FLUSH()                                                                                         \
+  do {                                                                                                          \
+    if ((threadIdx.x & 63) == 0)                                                                                \
+      for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&f4s_prof[(threadIdx.x >> 6) * 8 + i_], (unsigned long long)f4s_pc[i_]); \
   } while (0)
 #else
-#define F4S_BARRIER() F4S_LDS_BARRIER()
-#define F4S_POS_STAMP(c)
-#define F4S_TRACE_FLUSH()
+#define F4S_BARRIER_AT(slot) F4S_LDS_BARRIER()
+#define F4S_SPAN_BEGIN()
+#define F4S_SPAN_END(slot)
+#define F4S_WAIT_DMA() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define F4S_PROF_FLUSH()
 #endif
+#if defined(F4S_PROF) && F4S_PROF >= 2
+#define F4S_POS_T0() unsigned long long pa_, pb_, pc_; F4S_NOW(pa_)
+#define F4S_POS_T1()                                                \
+  do {                                                              \
+    F4S_NOW(pb_);                                                   \
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                \
+    F4S_NOW(pc_);                                                   \
+    f4s_pc[5] += (unsigned)(pb_ - pa_);                             \
+    f4s_pc[6] += (unsigned)(pc_ - pb_);                             \
+  } while (0)
+#else
+#define F4S_POS_T0()
+#define F4S_POS_T1()
+#endif
+#define F4S_BARRIER() F4S_BARRIER_AT(7)
 
 // s_V = 2^e, the largest power of two with 100 * amax * s_V < 65504 (|B^T d B| <= 100 max|d|): amax = m 2^k, m in [1, 2) -> e = 8 - k.
 // Zero / tiny bounds stop at 2^100 (inputs below 2^-92 lose relative accuracy gradually; the unscaling factor stays a normal number), infinities and NaNs give a harmless 2^-120.
@@ -165,9 +176,9 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
   const int item_end = min(a.items, (xcd + 1) * span);
   const int item_first = xcd * span + xcd_rank;
   if (item_first >= item_end) return;
-#ifdef F4S_TRACE
-  __shared__ unsigned f4s_tr[F4S_TRACE_WORDS];
-  int f4s_slot = 0;
+#ifdef F4S_PROF
+  unsigned f4s_pc[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  unsigned long long f4s_t0 = 0;
 #endif
   auto decode = [&](int item, int &co_blk, int &img, int &ty0, int &tx0) {
     co_blk = __builtin_amdgcn_readfirstlane((item % co_blocks) * 64);
@@ -179,7 +190,7 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
 
   if (wave < 4) {
     // =========================================================================================== staging waves
-    __builtin_amdgcn_s_setprio(F4S_STAGE_PRIO);
+    __builtin_amdgcn_s_setprio(3);
     const float s_v = f4s_input_scale(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *d.x_amax))));
     const float s_u_inv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane((int)a.U[1]));
     const float unscale = s_u_inv * (1.f / s_v);  // M = M' / (s_U s_V): an exact power of two
@@ -226,7 +237,7 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
     f32x2 tp[6][3];  // B^T d, same pairing
     const float *patch = Rw + ((half * RROWS + 4 * p_ty) * RPIECES + p_tx) * 4 + 4;  // patch row r, column c: patch[r * 4 RPIECES + c]
     auto read_patch = [&]() {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the requested chunk is in the region
+      F4S_WAIT_DMA();  // s_waitcnt vmcnt(0): the requested chunk is in the region
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
         const f32x4 m = *reinterpret_cast<const f32x4 *>(patch + r * (4 * RPIECES));
@@ -258,15 +269,10 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
       const float p_ = d4 - 4.f * d2, q_ = d3 - 4.f * d1, r_ = d4 - d2, s_ = d3 - d1;
       const float t[6] = {4.f * d0 + (d4 - 5.f * d2), p_ + q_, p_ - q_, r_ + 2.f * s_, r_ - 2.f * s_, 4.f * d1 + (d5 - 5.f * d3)};
       unsigned *dst = Vd + ((2 * wave + half) * 36 + r * 6) * 32 + j;
-#if F4S_MODE == 1
-#pragma unroll
-      for (int c = 0; c < 6; ++c) dst[c * 32] = __builtin_bit_cast(unsigned, t[c]);
-#else
       unsigned pk[6];
       split6_f16x2(t, s_v, pk);
 #pragma unroll
       for (int c = 0; c < 6; ++c) dst[c * 32] = pk[c];
-#endif
     };
 #else
     auto transform_cols = [&](int cp) {  // 1-D input transform B^T (Lavin & Gray), 12 packed operations
@@ -290,15 +296,10 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
       const f32x2 t24 = pr_ - f32x2{1.f, 2.f} * qs_;
       unsigned *dst = Vd + ((2 * wave + half) * 36 + r * 6) * 32 + j;
       const float t[6] = {t05[0], t13[0], t24[0], t13[1], t24[1], t05[1]};
-#if F4S_MODE == 1
-#pragma unroll
-      for (int c = 0; c < 6; ++c) dst[c * 32] = __builtin_bit_cast(unsigned, t[c]);  // fp32: the multiplying waves split (their three streams per SIMD interleave; this lone wave issues one instruction per ~8 cycles)
-#else
       unsigned pk[6];
       split6_f16x2(t, s_v, pk);
 #pragma unroll
       for (int c = 0; c < 6; ++c) dst[c * 32] = pk[c];
-#endif
     };
 #endif
     auto advance = [&]() {  // the load cursor moves one chunk; at an item boundary the geometry switches
@@ -349,6 +350,7 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
       const float chk = __builtin_fmaf(Y[0][0], 0.f, __builtin_fmaf(Y[0][3], 0.f, __builtin_fmaf(Y[3][0], 0.f, Y[3][3] * 0.f)));
       amx = max(max(amx, __builtin_bit_cast(unsigned, m)), abits(chk));
     };
+    F4S_SPAN_BEGIN();
     for (int item = item_first; item < item_end; item += xcd_wgs) {
       int e_co_blk, e_img, e_ty0, e_tx0;
       decode(item, e_co_blk, e_img, e_ty0, e_tx0);
@@ -360,23 +362,17 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
       for (int k = 0; k < n_chunks; ++k) {
         unsigned *Vd = Vst + (par ^ 1) * VSLAB;
         read_patch();
-        F4S_POS_STAMP(0);
         advance();
         load_begin(l_k * CK);
         dma_issue();
-        F4S_POS_STAMP(1);
 #pragma unroll
         for (int cp = 0; cp < 3; ++cp) transform_cols(cp);
-        F4S_POS_STAMP(2);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) commit_row(Vd, r);
-        F4S_POS_STAMP(3);
-#pragma unroll
-        for (int r = 3; r < 6; ++r) commit_row(Vd, r);
-        F4S_POS_STAMP(4);
-        F4S_BARRIER();
+        for (int r = 0; r < 6; ++r) commit_row(Vd, r);
+        F4S_BARRIER_AT(0);
         par ^= 1;
       }
+      F4S_SPAN_END(2);
 
       // ---- column pass Y = A^T T + epilogue + stores: 8 phases of 8 output channels, one (channel, tile) per thread and phase.
       const int plane = hw;
@@ -417,7 +413,7 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
         prefetch(0);
 #pragma unroll 1
         for (int p = 0; p < 8; ++p) {
-          F4S_BARRIER();  // T of this phase is in its half of the exchange area
+          F4S_BARRIER_AT(1);  // T of this phase is in its half of the exchange area
           const float *Xb = Xs + (p & 1) * (XSZ / 2) + (cl8 * 32 + tile) * 4;
           f32x4 T[6];
 #pragma unroll
@@ -527,6 +523,7 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
       if (vec && shuffle) column_pass(std::true_type{}, std::true_type{});
       else if (vec) column_pass(std::true_type{}, std::false_type{});
       else column_pass(std::false_type{}, std::false_type{});
+      F4S_SPAN_END(3);
     }
     if (d.abs_sum) asum_flush();
     if (d.y_amax) {
@@ -534,98 +531,13 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
       for (int sh = 32; sh > 0; sh >>= 1) amx = max(amx, (unsigned)__shfl_xor((int)amx, sh));
       if (lane == 0 && amx > 0u) atomicMax(reinterpret_cast<unsigned *>(d.y_amax), amx);  // non-negative floats order as integers, NaNs above them
     }
-    F4S_TRACE_FLUSH();
+    F4S_PROF_FLUSH();
   } else {
     // =========================================================================================== multiplying waves
     const int q = wave - 4, wm = q & 1, row = q >> 1;
     const __amdgpu_buffer_rsrc_t u_rsrc = uniform_rsrc(a.U, 64 + a.cop * a.ci * 36 * 4);
     const int voff = lane * 16;
     f32x16 acc[6];
-#if F4S_MODE >= 1
-    // V arrives as fp32; THIS wave splits the four channels of its B operand (8 v_fma_mix per position - the two co halves of a row
-    // both do it: redundant, but on three interleaved instruction streams per SIMD instead of the lone staging wave's).  The
-    // registers come from the weights: three positions of A in flight (half a chunk ahead) instead of six.
-    const float s_v = f4s_input_scale(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *d.x_amax))));
-    i32x4 A[3];
-    int u_base = 0, u_next = 0;
-    auto item_base = [&](int co_blk) { return 64 + ((((co_blk >> 6) * n_chunks) * 6 + row) * 2 + wm) * (6 * 1024); };
-    auto load_a = [&](int buf, int soff) { A[buf] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, voff, soff, 0)); };
-    int co_blk, img_, ty_, tx_;
-    decode(item_first, co_blk, img_, ty_, tx_);
-    u_base = item_base(co_blk);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) load_a(c, u_base + c * 1024);
-#pragma unroll
-    for (int c = 0; c < 6; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-    F4S_BARRIER();
-
-    int par = 0;
-    const unsigned *const Vst = reinterpret_cast<const unsigned *>(smem);
-    unsigned v_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned *)(Vst + 4 * half * 36 * 32 + row * 6 * 32 + j);
-    int v_step = __builtin_amdgcn_readfirstlane(VSLAB * 4);
-    float X[2][4];
-#define F4S_READ4(xs, c)                                                                                                              \
-  asm volatile("ds_read_b32 %0, %4 offset:%5\n\tds_read_b32 %1, %4 offset:%6\n\tds_read_b32 %2, %4 offset:%7\n\tds_read_b32 %3, %4 offset:%8" \
-               : "=&v"(xs[0]), "=&v"(xs[1]), "=&v"(xs[2]), "=&v"(xs[3])                                                              \
-               : "v"(v_addr), "n"((c) * 128), "n"(36 * 128 + (c) * 128), "n"(2 * 36 * 128 + (c) * 128), "n"(3 * 36 * 128 + (c) * 128)   \
-               : "memory")
-    for (int item = item_first; item < item_end; item += xcd_wgs) {
-      {
-        const int nx = item + xcd_wgs;
-        decode(nx < item_end ? nx : item, co_blk, img_, ty_, tx_);
-        u_next = item_base(co_blk);
-      }
-#pragma unroll 1
-      for (int k = 0; k < n_chunks; ++k) {
-        const int soff_cur = u_base + k * UCHUNK;
-        const int soff_nxt = k + 1 < n_chunks ? soff_cur + UCHUNK : u_next;  // (at the end: the next item's first chunk)
-        F4S_READ4(X[0], 0);
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          float(&xc)[4] = X[c & 1];
-          if (c < 5) {
-            float(&xn)[4] = X[(c + 1) & 1];
-            if (c == 0) F4S_READ4(xn, 1);
-            if (c == 1) F4S_READ4(xn, 2);
-            if (c == 2) F4S_READ4(xn, 3);
-            if (c == 3) F4S_READ4(xn, 4);
-            if (c == 4) F4S_READ4(xn, 5);
-            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(xc[0]), "+v"(xc[1]), "+v"(xc[2]), "+v"(xc[3])::"memory");
-          } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xc[0]), "+v"(xc[1]), "+v"(xc[2]), "+v"(xc[3])::"memory");
-          }
-          int b0, b1, b2, b3;
-#if F4S_MODE == 2
-          b0 = __builtin_bit_cast(int, xc[0]), b1 = __builtin_bit_cast(int, xc[1]), b2 = __builtin_bit_cast(int, xc[2]), b3 = __builtin_bit_cast(int, xc[3]);
-#else
-          asm volatile(
-              "v_fma_mixlo_f16 %0, %4, %8, 0\n\tv_fma_mixlo_f16 %1, %5, %8, 0\n\tv_fma_mixlo_f16 %2, %6, %8, 0\n\tv_fma_mixlo_f16 %3, %7, %8, 0\n\t"
-              "v_fma_mixhi_f16 %0, %4, %8, -%0 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %1, %5, %8, -%1 op_sel_hi:[0,0,1]\n\t"
-              "v_fma_mixhi_f16 %2, %6, %8, -%2 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %3, %7, %8, -%3 op_sel_hi:[0,0,1]"
-              : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
-              : "v"(xc[0]), "v"(xc[1]), "v"(xc[2]), "v"(xc[3]), "s"(s_v));
-#endif
-          const f16x8 B = __builtin_bit_cast(f16x8, i32x4{b0, b1, b2, b3});
-          i32x4 &Ac = A[c % 3];
-          acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Ac), B, acc[c], 0, 0, 0);
-          // (hi, lo) -> (lo, hi) IN PLACE (no second register set), then the set is re-requested three positions ahead
-          asm volatile("v_alignbit_b32 %0, %0, %0, 16\n\tv_alignbit_b32 %1, %1, %1, 16\n\tv_alignbit_b32 %2, %2, %2, 16\n\tv_alignbit_b32 %3, %3, %3, 16"
-                       : "+v"(Ac[0]), "+v"(Ac[1]), "+v"(Ac[2]), "+v"(Ac[3]));
-          acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Ac), B, acc[c], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          load_a(c % 3, c < 3 ? soff_cur + (c + 3) * 1024 : soff_nxt + (c - 3) * 1024);
-          F4S_POS_STAMP(c);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        v_addr += v_step;  // the other stage
-        v_step = -v_step;
-        F4S_BARRIER();
-        par ^= 1;
-      }
-#undef F4S_READ4
-#else
     i32x4 A[6];  // A operand of position (row, c): 4 channels x (hi, lo); a set is re-requested right after its use, one chunk ahead
     int u_base = 0, u_next = 0;  // byte offsets of (co block, chunk 0, row, wm) of this item and of the next
     auto item_base = [&](int co_blk) { return 64 + ((((co_blk >> 6) * n_chunks) * 6 + row) * 2 + wm) * (6 * 1024); };
@@ -646,6 +558,7 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
     // B operand: channels 4 half .. + 3, position (row, c), tile j of the current stage (LDS byte address; smem is the first allocation)
     unsigned v_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned *)(Vst + 4 * half * 36 * 32 + row * 6 * 32 + j);
     int v_step = __builtin_amdgcn_readfirstlane(VSLAB * 4);
+    F4S_SPAN_BEGIN();
     for (int item = item_first; item < item_end; item += xcd_wgs) {
       {
         const int nx = item + xcd_wgs;
@@ -662,11 +575,13 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
           // 96 accumulators + 24 registers of A + 4 of B leave exactly four); single-buffered, the two other waves of the SIMD
           // cover the LDS latency.
           int b0, b1, b2, b3;
+          F4S_POS_T0();
           asm volatile("ds_read_b32 %0, %4 offset:%5\n\tds_read_b32 %1, %4 offset:%6\n\tds_read_b32 %2, %4 offset:%7\n\tds_read_b32 %3, %4 offset:%8\n\t"
                        "s_waitcnt lgkmcnt(0)"
                        : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
                        : "v"(v_addr), "n"(c * 128), "n"(36 * 128 + c * 128), "n"(2 * 36 * 128 + c * 128), "n"(3 * 36 * 128 + c * 128)
                        : "memory");
+          F4S_POS_T1();  // (second-level measurement build only: B wait [5], then the wait for this position's A [6])
           const f16x8 B = __builtin_bit_cast(f16x8, i32x4{b0, b1, b2, b3});
           acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[c]), B, acc[c], 0, 0, 0);
           // (hi, lo) -> (lo, hi) IN PLACE (no second register set), then the set is re-requested for the next chunk
@@ -675,16 +590,15 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
           acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[c]), B, acc[c], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
           load_a(c, soff_nxt);  // the same position of the next chunk: a whole chunk step to arrive
-          F4S_POS_STAMP(c);
           __builtin_amdgcn_sched_barrier(0);
         }
         v_addr += v_step;  // the other stage
         v_step = -v_step;
-        F4S_BARRIER();
+        F4S_BARRIER_AT(0);
         par ^= 1;
       }
-#endif
       u_base = u_next;
+      F4S_SPAN_END(2);
       // ---- row pass T = M A (6 -> 4) and hand-over to the staging waves: 8 phases of two accumulator registers.  The store address
       //      is derived HERE from an opaque copy of the lane index: hoisted out of the item loop it stays live across the chunk loop,
       //      whose 96 + 24 + 4 registers leave no room for it (it was spilled and reloaded once per item)
@@ -706,19 +620,18 @@ __global__ __launch_bounds__(1024, 1) void conv3x3_winograd_f4s_kernel(const Win
           T[3] = __builtin_fmaf(8.f, d2, d1) + m5;
           *reinterpret_cast<f32x4 *>(Xb + rr * 32 * 4) = T;
         }
-        F4S_BARRIER();
+        F4S_BARRIER_AT(1);
       }
-#if F4S_MODE == 0
       // the next item's first chunk of U: requested here, not from the last chunk step - 24 registers live across the row pass do not fit
 #pragma unroll
       for (int c = 0; c < 6; ++c) load_a(c, u_base);
-#endif
 #pragma unroll
       for (int c = 0; c < 6; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+      F4S_SPAN_END(3);
     }
-    F4S_TRACE_FLUSH();
+    F4S_PROF_FLUSH();
   }
 }
 
@@ -856,9 +769,15 @@ int winograd_f4s_launch(const edvr_conv2d_desc &d, hipStream_t stream) {
 
 extern "C" {
 
-#ifdef F4S_TRACE
-int edvr_f4s_trace_read(unsigned *host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(edvr::f4s_trace), sizeof(unsigned) * n); }
-int edvr_f4s_trace_slots(void) { return F4S_TRACE_SLOTS; }
+#ifdef F4S_PROF
+int edvr_f4s_prof_read(unsigned long long *host, int reset) {  // host[16 * 8]
+  int rc = (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(edvr::f4s_prof), sizeof(unsigned long long) * 128);
+  if (rc == 0 && reset) {
+    static unsigned long long zero[128];
+    rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(edvr::f4s_prof), zero, sizeof(zero));
+  }
+  return rc;
+}
 #endif
 
 size_t edvr_conv2d_packed_weight_f4s_elems(int co, int ci) { return 16 + (size_t)((co + 63) / 64 * 64) * ((ci + 7) / 8 * 8) * 36; }

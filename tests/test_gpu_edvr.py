@@ -366,3 +366,25 @@ def test_out_buffers_and_in_place_kernels_void_stale_bounds(gpu):
     ops.set_bound(dst, ops.amax(dst))
     ops.frame_reduce_add_(src, dst, 3, 1)
     assert ops.get_bound(dst) is None
+
+
+def test_motion_like_offset_field_varies_in_space_and_matches_the_oracle(gpu):
+    """bench.py's `motion` legs: structured clips + rescaled offset convs give every DCN layer offsets of a few
+    pixels whose mean |horizontal neighbour difference| is ~0.5 px (a trained model's offsets follow objects, arch_util.py:243-257;
+    white-noise frames with constant biases give 0.00-0.01) - and on that field the forward still equals the oracle."""
+    from oracle import edvr_oracle as EO
+    from util_edvr import motion_frames, motion_like_offsets
+    kwargs = dict(num_feat=64, num_frame=5, num_reconstruct_block=4, center_frame_idx=2)
+    torch.manual_seed(10)
+    from edvr_amd import EDVR
+    net = EDVR(**kwargs).eval().to(gpu)
+    x = motion_frames(2, (5, 3, 64, 64), seed=3)
+    stats = motion_like_offsets(net, x.to(gpu), target_rough=0.5, bias_sigma=3.0)
+    for absmean, rough in stats:
+        assert 0.25 < rough < 1.0, stats
+        assert 1.0 < absmean < 50.0, stats
+    sd64 = {k: v.double().cpu() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        ref = EO.edvr_forward(sd64, x.double(), **oracle_kwargs(kwargs))
+        out = net(x.to(gpu))
+    assert _rel(out, ref) < INTERMEDIATE_RTOL

@@ -119,3 +119,61 @@ class DecisionRecorder:
     def oracle_kwargs(self):
         offs = {k: om[:, :2 * om.shape[1] // 3] for k, om in zip(('l3', 'l2', 'l1', 'cas'), self.oms)}
         return dict(pool_inputs=self.pool_inputs or None, dcn_offsets=offs or None, act_sides=self.sides)
+
+
+def motion_frames(batch, shape, seed=0):
+    """Synthetic clips with image STRUCTURE instead of white noise: a smooth background (low-resolution noise, bilinearly enlarged) that
+    drifts by (1.5, 0.75) px per frame, rectangles of constant intensity moving at their own speeds over it (object boundaries), and a
+    little pixel noise (texture).  shape = (t, c, h, w); values in [0, 1].  The offset convs of a network see features that are smooth
+    inside objects and jump at their edges - the spatial statistics of a trained model's offsets (arch_util.py:243-257), which follow
+    objects, where torch.rand frames give spatially constant offsets + noise."""
+    import torch.nn.functional as F
+    t, c, h, w = shape
+    g = torch.Generator().manual_seed(1000 + seed)
+    pad = 16
+    bg = torch.rand(batch, c, (h + 2 * pad) // 16 + 2, (w + 2 * pad) // 16 + 2, generator=g)
+    bg = F.interpolate(bg, size=(h + 2 * pad, w + 2 * pad), mode='bilinear', align_corners=False)
+    ys = torch.arange(h, dtype=torch.float32).view(1, h, 1).expand(batch, h, w)
+    xs = torch.arange(w, dtype=torch.float32).view(1, 1, w).expand(batch, h, w)
+    n_obj = max(2, (h * w) // 2500)
+    ox, oy = torch.rand(batch, n_obj, generator=g) * w, torch.rand(batch, n_obj, generator=g) * h
+    ow, oh = 6 + torch.rand(batch, n_obj, generator=g) * w / 6, 6 + torch.rand(batch, n_obj, generator=g) * h / 4
+    vx, vy = (torch.rand(batch, n_obj, generator=g) - 0.5) * 6, (torch.rand(batch, n_obj, generator=g) - 0.5) * 4
+    col = torch.rand(batch, n_obj, c, generator=g)
+    frames = []
+    for f in range(t):
+        gx = (xs + pad + 1.5 * (f - t // 2)) / (w + 2 * pad - 1) * 2 - 1
+        gy = (ys + pad + 0.75 * (f - t // 2)) / (h + 2 * pad - 1) * 2 - 1
+        img = F.grid_sample(bg, torch.stack([gx, gy], -1), mode='bilinear', align_corners=True)
+        for k in range(n_obj):
+            cx, cy = (ox[:, k] + vx[:, k] * (f - t // 2)).view(-1, 1, 1), (oy[:, k] + vy[:, k] * (f - t // 2)).view(-1, 1, 1)
+            inside = ((xs - cx).abs() < ow[:, k].view(-1, 1, 1) / 2) & ((ys - cy).abs() < oh[:, k].view(-1, 1, 1) / 2)
+            img = torch.where(inside.unsqueeze(1), col[:, k].view(batch, c, 1, 1).expand(-1, -1, h, w), img)
+        frames.append(img)
+    x = torch.stack(frames, 1) + (torch.rand(batch, t, c, h, w, generator=g) - 0.5) * 0.04
+    return x.clamp_(0, 1)
+
+
+def motion_like_offsets(net, x, target_rough=0.5, bias_sigma=3.0, rounds=3, seed=123):
+    """Give `net` (on the GPU) the offset statistics of a trained model on the clips `x`: per-tap displacements of a few pixels
+    (conv_offset.bias ~ N(0, bias_sigma^2)) PLUS a spatially varying part that follows the input's structure - conv_offset.weight is
+    rescaled, per DCN module, until the mean |horizontal neighbour difference| of its offsets on `x` is `target_rough` px (the
+    difference is linear in the weights; the cascade of the pyramid makes a few rounds necessary).  Returns the per-module
+    (mean |offset|, roughness) of the last round."""
+    randomize_offsets(net, seed=seed, bias_sigma=bias_sigma)
+    dcns = net.pcd_align.dcn_modules()
+    stats = []
+    for _ in range(rounds):
+        with torch.no_grad():
+            net(x)
+        net.check_offsets()
+        stats = [(m.last_offset_absmean, m.last_offset_rough) for m in dcns]
+        with torch.no_grad():
+            for m, (_, rough) in zip(dcns, stats):
+                if rough and rough > 0:
+                    n_off = 2 * m.conv_offset.weight.shape[0] // 3
+                    m.conv_offset.weight[:n_off].mul_(min(max(target_rough / rough, 0.05), 200.0))
+    with torch.no_grad():
+        net(x)
+    net.check_offsets()
+    return [(m.last_offset_absmean, m.last_offset_rough) for m in dcns]
