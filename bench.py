@@ -887,6 +887,27 @@ def emit(result, rank, path=None):
     print(compact_line(result), flush=True)
 
 
+def leg_plan(args, world, batch):
+    """Which legs of the report run where: 'all' = every rank calls it (it holds barriers / collectives, so NO rank may skip it), 'rank0' =
+    rank 0 alone and collective-free, None = not at this N.  Legs that can fail on one rank alone (out of memory in `configs`) or
+    that use the host's cores (the CPU oracle, the stock-ops arm) run at N = 1 only: a rank that stopped there would leave the others
+    waiting in the next collective (tests/test_dist_cpu.py)."""
+    infer = args.mode == 'infer'
+    headline = infer and args.workload == 'edvr_l_x4_t5_180x320'
+    single = world == 1
+    return {
+        'fp32_mfma': None if args.no_fp32_leg else 'all',
+        'batch4': 'all' if (headline and batch != 4 and not args.no_batch4) else None,
+        'roofline': 'rank0' if (not args.no_roofline and (infer or single)) else None,
+        'target_4k': 'all' if (headline and not args.no_target_4k) else None,
+        'trained_like': 'all' if (headline and not args.no_trained_like) else None,
+        'configs': 'all' if (headline and not args.no_configs and single) else None,
+        'train': 'all' if (infer and not args.no_train_leg) else None,
+        'cpu_baseline': 'rank0' if (infer and single and not args.no_cpu_baseline) else None,
+        'stock_rocm_baseline': 'rank0' if (infer and single and not args.no_stock_baseline) else None,
+    }
+
+
 def main():
     args = parse()
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -957,7 +978,8 @@ def main():
             result['optimizer'] = ('edvr_amd.optim.FusedAdam (one HIP launch for all tensors; arithmetic of torch.optim.Adam)'
                                    if args.optimizer == 'fused' else 'torch.optim.Adam')
     # ---- everything below is outside the timed region
-    if not args.no_fp32_leg:
+    plan = leg_plan(args, world, batch)
+    if plan['fp32_mfma']:
         # the same step with the 3x3 convs (and, in training, their weight gradients) on the fp32 matrix pipe - the exact-fp32-product
         # kernels of rounds 2-4 - timed the same way (all ranks: barriers inside)
         from edvr_amd import ops as _ops
@@ -973,7 +995,7 @@ def main():
                                    'speedup_of_the_default_path': round(e32 / 5 / (elapsed / args.steps), 4)}
             if args.mode == 'train':
                 result['fp32_mfma']['iters_per_sec'] = round(5 / e32, 4)
-    if args.workload == 'edvr_l_x4_t5_180x320' and args.mode == 'infer' and batch != 4 and not args.no_batch4:
+    if plan['batch4']:
         x4 = x[:4].contiguous()
 
         def step4():
@@ -984,13 +1006,13 @@ def main():
             result['batch4'] = {'clips_per_gpu': 4, 'value': round(4 * world * 5 / e4, 4), 'ms_per_step': round(e4 / 5 * 1e3, 3), 'steps': 5,
                                 'note': 'same network and clips at 4 clips per GPU (round-1 setting): 7.19 rounds of trunk items run as 8'}
         del x4
-    if rank == 0 and not args.no_roofline and (args.mode == 'infer' or world == 1):
+    if rank == 0 and plan['roofline']:
         isteps = 1 if args.mode == 'train' else max(1, min(args.steps, 3))
         per = instrumented_pass(step, isteps)
         result['roofline'] = roofline_object(per, isteps, elapsed / args.steps, args.workload, batch == cfg['batch'])
         result['kernels'] = kernel_table(per, isteps, elapsed / args.steps)
     del step
-    if args.workload == 'edvr_l_x4_t5_180x320' and args.mode == 'infer' and not args.no_target_4k:
+    if plan['target_4k']:
         del x
         torch.cuda.empty_cache()
         x = None
@@ -998,20 +1020,20 @@ def main():
         torch.cuda.empty_cache()
         if rank == 0:
             result['target_4k'] = t4k
-    if args.workload == 'edvr_l_x4_t5_180x320' and args.mode == 'infer' and not args.no_trained_like:
+    if plan['trained_like']:
         tl = trained_like_leg(cfg, batch, args, device, rank, world, dist)  # all ranks (barriers inside)
         if rank == 0:
             result['trained_like'] = tl
             for rec in tl.values():
                 rec['vs_headline'] = round(rec['value'] / result['value'], 4)
-    if args.workload == 'edvr_l_x4_t5_180x320' and args.mode == 'infer' and not args.no_configs and world == 1:
+    if plan['configs']:
         # (N = 1 only: a configuration that fails on ONE rank - out of memory - must not leave the others waiting in a collective)
         net = None  # (the headline network is not needed any more: the remaining legs build their own)
         torch.cuda.empty_cache()
         cf = configs_leg(args, device, rank, world, dist)  # all ranks
         if rank == 0:
             result['configs'] = cf
-    if args.mode == 'infer' and not args.no_train_leg:
+    if plan['train']:
         del net, x
         torch.cuda.empty_cache()
         tr, tstep = train_leg(args, device, rank, world, dist)  # all ranks: DDP collectives
@@ -1019,11 +1041,11 @@ def main():
         torch.cuda.empty_cache()
         if rank == 0:
             result['train'] = tr
-    if rank == 0 and args.mode == 'infer' and world == 1:  # the CPU / stock legs run at N = 1 only (rank 0's host cores)
+    if rank == 0:  # the CPU / stock legs run at N = 1 only (rank 0's host cores)
         ours = None
-        if not args.no_cpu_baseline:
+        if plan['cpu_baseline']:
             result['cpu_baseline'], result['parity'], ours = cpu_baseline_and_parity(cfg, device)
-        if not args.no_stock_baseline:
+        if plan['stock_rocm_baseline']:
             try:
                 result['stock_rocm_baseline'] = stock_rocm_baseline(cfg, device, ours)
             except Exception as e:  # a baseline arm must never take the measurement down (e.g. MIOpen workspace failure)

@@ -88,6 +88,34 @@ def test_bench_gpus_8_builds_the_torchrun_launch():
     assert b.spawn_env({'A': '1'}) == {'A': '1', 'HSA_ENABLE_IPC_MODE_LEGACY': '0'}
 
 
+def test_bench_leg_plan_never_lets_one_rank_skip_a_collective_leg():
+    """The legs beside the timed region (bench.leg_plan): at N > 1 the legs that hold barriers run on EVERY rank, the legs that can fail on
+    one rank alone (`configs`: out of memory) or use the host's cores (CPU oracle, stock-ops arm) do not run at all, and nothing is
+    'rank0'-only unless it is collective-free - so no rank can be left waiting in a collective."""
+    import sys
+    from unittest import mock
+    b = _bench()
+    with mock.patch.object(sys, 'argv', ['bench.py']):
+        args = b.parse()
+    args.workload = 'edvr_l_x4_t5_180x320'
+    one, eight = b.leg_plan(args, 1, 10), b.leg_plan(args, 8, 10)
+    assert all(one[k] for k in one), one  # the default run at N = 1: every leg
+    assert one['cpu_baseline'] == one['stock_rocm_baseline'] == one['roofline'] == 'rank0'
+    for leg in ('fp32_mfma', 'batch4', 'target_4k', 'trained_like', 'train'):  # barriers / DDP collectives inside: all ranks or none
+        assert one[leg] == eight[leg] == 'all', (leg, one[leg], eight[leg])
+    assert eight['configs'] is None and eight['cpu_baseline'] is None and eight['stock_rocm_baseline'] is None
+    assert eight['roofline'] == 'rank0'  # inference: an instrumented forward has no collective
+    args.mode, args.workload = 'train', 'edvr_l_train_t5_64x64'
+    t8 = b.leg_plan(args, 8, 32)
+    assert t8['roofline'] is None  # an extra DDP step on rank 0 alone would wait for its peers
+    assert t8['fp32_mfma'] == 'all' and t8['train'] is None and t8['configs'] is None and t8['cpu_baseline'] is None
+    # the compact line of an N = 8 run carries the world size and the backend
+    line = __import__('json').loads(b.compact_line({'metric': 'm', 'value': 1.0, 'unit': 'clips/s', 'n_gpus': 8, 'steps': 1, 'warmup': 0, 'ms_per_step': 1.0,
+                                                    'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': b.DTYPE, 'data': 'synthetic',
+                                                    'config': {'workload': 'w', 'world_size': 8, 'backend': 'RCCL (torch.distributed nccl)'}}))
+    assert line['n_gpus'] == 8 and line['config']['world_size'] == 8 and 'RCCL' in line['config']['backend']
+
+
 def _bench_worker(rank, world, port, q):
     import contextlib
     import io
