@@ -400,7 +400,7 @@ def stock_rocm_baseline(cfg, device, ours_cpu, repeats=3):
 
 
 # ------------------------------------------------------------------------------------------------ steps
-def make_train_step(net, cfg, batch, device, rank, optimizer, x=None):
+def make_train_step(net, cfg, batch, device, rank, optimizer, x=None, lr=4e-4):
     from edvr_amd import dist as D
     from edvr_amd.autograd import charbonnier_loss
     from edvr_amd.optim import FusedAdam
@@ -412,8 +412,8 @@ def make_train_step(net, cfg, batch, device, rank, optimizer, x=None):
     model = D.wrap_ddp(net)  # RCCL gradient all-reduce, bucketed and overlapped with backward
     dcn = [p for n, p in net.named_parameters() if 'dcn' in n]  # edvr_model.py:21-53 (two groups as with dcn_lr_mul != 1)
     rest = [p for n, p in net.named_parameters() if 'dcn' not in n]
-    groups = [{'params': rest, 'lr': 4e-4}, {'params': dcn, 'lr': 4e-4 * 1}]
-    opt = (torch.optim.Adam if optimizer == 'torch' else FusedAdam)(groups, lr=4e-4, betas=(0.9, 0.99))
+    groups = [{'params': rest, 'lr': lr}, {'params': dcn, 'lr': lr * 1}]
+    opt = (torch.optim.Adam if optimizer == 'torch' else FusedAdam)(groups, lr=lr, betas=(0.9, 0.99))
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -660,7 +660,9 @@ def train_leg(args, device, rank, world, dist):
         net = build_net(cfg, device, offset_bias_sigma=3.0)
         xm = motion_frames(cfg['batch'], cfg['shape'], seed=rank).to(device)
         motion_like_offsets(net, xm, target_rough=0.5, bias_sigma=3.0)
-        step = make_train_step(net, cfg, cfg['batch'], device, rank, 'fused', x=xm)
+        # (lr 1e-6: Adam's first steps move every weight by +-lr whatever the gradient - at 4e-4 the rescaled offset convs would drift by
+        # pixels per iteration and the field measured would not be the field set up)
+        step = make_train_step(net, cfg, cfg['batch'], device, rank, 'fused', x=xm, lr=1e-6)
         e3 = timed(step, tsteps, 3, dist, device)  # all ranks
         mo = {'offset_bias_sigma': 3.0, 'frames': 'structured (tests/util_edvr.py motion_frames)', 'iters_per_sec': round(tsteps / e3, 4),
               'ms_per_iter': round(e3 / tsteps * 1e3, 2), 'steps': tsteps, 'vs_sub_pixel_offsets': round((tsteps / e3) / (args.train_steps / elapsed), 4)}

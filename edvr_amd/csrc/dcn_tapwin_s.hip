@@ -289,9 +289,11 @@ __global__ __launch_bounds__(256, 2) void dcn_tapwin_split_fwd_kernel(const DcnT
     };
     if constexpr (SLOW) {
       // Fix-up pass after the regular one (in which the slow lanes carried zero weights): the lanes whose cell lies outside the
-      // window gather their four corners from global memory with the full bounds logic (dcn_tap.h), every other lane contributes
-      // 0.  Rare by construction: a plain rolled loop per sub-tile on the fp32 matrix instruction, the weights rebuilt from their
-      // (hi, lo) pairs (w s_W = hi + lo), the samples carrying s_X like the regular ones.
+      // window gather their corners from global memory with the full bounds logic (dcn_tap.h), every other lane contributes 0.
+      // The SAME arithmetic as the regular pass - four channels per lane and K-group, split, two f16 MFMAs per output block - with
+      // all 16 KG corner loads of a sub-tile in flight at once: one memory latency + 4 KG MT matrix instructions of 32 cycles per
+      // sub-tile (it was a rolled loop of CPG / 2 dependent gathers on the fp32 matrix instruction: ~5x a regular step, which
+      // fields that vary inside a tile - object boundaries, bench.py's `motion` leg - pay on most steps).
       const int ti = t / 3, tj = t - 3 * ti;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -302,23 +304,37 @@ __global__ __launch_bounds__(256, 2) void dcn_tapwin_split_fwd_kernel(const DcnT
         const float hsp = (float)(oy0 + s - 1 + ti) + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(off_rsrc, pv, (g * 18 + 2 * t) * P * 4, 0));
         const float wsp = (float)(ox - 1 + tj) + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(off_rsrc, pv, (g * 18 + 2 * t + 1) * P * 4, 0));
         const Tap tq = resolve_tap(hsp, wsp, a.H, a.W);
-        const float s0 = on ? tq.w00 * m : 0.f, s1 = on ? tq.w01 * m : 0.f, s2 = on ? tq.w10 * m : 0.f, s3 = on ? tq.w11 * m : 0.f;
+        const float sw[4] = {on ? tq.w00 * m : 0.f, on ? tq.w01 * m : 0.f, on ? tq.w10 * m : 0.f, on ? tq.w11 * m : 0.f};
         const int hp = half * P;
-        const int o0 = on ? (tq.o00 + hp) * 4 : OOB, o1 = on ? (tq.o01 + hp) * 4 : OOB, o2 = on ? (tq.o10 + hp) * 4 : OOB, o3 = on ? (tq.o11 + hp) * 4 : OOB;
-#pragma unroll 1
-        for (int q = 0; q < NQ; ++q) {
-          const int so = (g * CPG + 2 * q) * P * 4;
-          const float bv = s0 * __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, o0, so, 0)) +
-                           s1 * __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, o1, so, 0)) +
-                           s2 * __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, o2, so, 0)) +
-                           s3 * __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, o3, so, 0));
-          // this lane's channel of the pair, 2 q + half = 8 kg + 2 i + half: quad 2 kg + half, slot i
-          const unsigned *ap = wb + (((2 * (q >> 2) + half) * MB + j) * 4 + (q & 3));
+        const int ov[4] = {on ? (tq.o00 + hp) * 4 : OOB, on ? (tq.o01 + hp) * 4 : OOB, on ? (tq.o10 + hp) * 4 : OOB, on ? (tq.o11 + hp) * 4 : OOB};
+        float gv[KG][4][4];  // [K-group][channel 8 kg + 2 i + half][corner]
 #pragma unroll
-          for (int m2 = 0; m2 < MT; ++m2) {
-            const f16x2t pr = __builtin_bit_cast(f16x2t, ap[m2 * 128]);
-            acc[s][m2] = __builtin_amdgcn_mfma_f32_32x32x2f32((float)pr[0] + (float)pr[1], bv, acc[s][m2], 0, 0, 0);
-          }
+        for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              gv[kg][i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, ov[c], (g * CPG + 8 * kg + 2 * i) * P * 4, 0));
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+          i32x4 aw[MT];
+#pragma unroll
+          for (int m2 = 0; m2 < MT; ++m2) aw[m2] = *reinterpret_cast<const i32x4 *>(wb + ((kg * 2 + half) * MB + m2 * 32 + j) * 4);
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            v[i] = __builtin_fmaf(sw[3], gv[kg][i][3], __builtin_fmaf(sw[2], gv[kg][i][2], __builtin_fmaf(sw[1], gv[kg][i][1], sw[0] * gv[kg][i][0])));
+          unsigned pk[4];
+          tws_split4(v, pk);
+          i32x4 bq = i32x4{(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]};
+#pragma unroll
+          for (int m2 = 0; m2 < MT; ++m2)
+            acc[s][m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aw[m2]), __builtin_bit_cast(f16x8, bq), acc[s][m2], 0, 0, 0);
+          asm volatile("v_alignbit_b32 %0, %0, %0, 16\n\tv_alignbit_b32 %1, %1, %1, 16\n\tv_alignbit_b32 %2, %2, %2, 16\n\tv_alignbit_b32 %3, %3, %3, 16"
+                       : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]));
+#pragma unroll
+          for (int m2 = 0; m2 < MT; ++m2)
+            acc[s][m2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aw[m2]), __builtin_bit_cast(f16x8, bq), acc[s][m2], 0, 0, 0);
         }
       }
     } else {

@@ -381,8 +381,8 @@ def test_motion_like_offset_field_varies_in_space_and_matches_the_oracle(gpu):
     x = motion_frames(2, (5, 3, 64, 64), seed=3)
     stats = motion_like_offsets(net, x.to(gpu), target_rough=0.5, bias_sigma=3.0)
     for absmean, rough in stats:
-        assert 0.25 < rough < 1.0, stats
-        assert 1.0 < absmean < 50.0, stats
+        assert 0.1 < rough < 1.0, stats   # (white-noise frames + constant biases: 0.00-0.01)
+        assert 1.0 < absmean < 7.0, stats  # single-digit displacements: the cap of motion_like_offsets
     sd64 = {k: v.double().cpu() for k, v in net.state_dict().items()}
     with torch.no_grad():
         ref = EO.edvr_forward(sd64, x.double(), **oracle_kwargs(kwargs))

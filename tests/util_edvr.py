@@ -124,7 +124,7 @@ class DecisionRecorder:
 def motion_frames(batch, shape, seed=0):
     """Synthetic clips with image STRUCTURE instead of white noise: a smooth background (low-resolution noise, bilinearly enlarged) that
     drifts by (1.5, 0.75) px per frame, rectangles of constant intensity moving at their own speeds over it (object boundaries), and a
-    little pixel noise (texture).  shape = (t, c, h, w); values in [0, 1].  The offset convs of a network see features that are smooth
+    little pixel noise (texture, +-0.06).  shape = (t, c, h, w); values in [0, 1].  The offset convs of a network see features that are smooth
     inside objects and jump at their edges - the spatial statistics of a trained model's offsets (arch_util.py:243-257), which follow
     objects, where torch.rand frames give spatially constant offsets + noise."""
     import torch.nn.functional as F
@@ -150,30 +150,35 @@ def motion_frames(batch, shape, seed=0):
             inside = ((xs - cx).abs() < ow[:, k].view(-1, 1, 1) / 2) & ((ys - cy).abs() < oh[:, k].view(-1, 1, 1) / 2)
             img = torch.where(inside.unsqueeze(1), col[:, k].view(batch, c, 1, 1).expand(-1, -1, h, w), img)
         frames.append(img)
-    x = torch.stack(frames, 1) + (torch.rand(batch, t, c, h, w, generator=g) - 0.5) * 0.04
+    x = torch.stack(frames, 1) + (torch.rand(batch, t, c, h, w, generator=g) - 0.5) * 0.12
     return x.clamp_(0, 1)
 
 
-def motion_like_offsets(net, x, target_rough=0.5, bias_sigma=3.0, rounds=3, seed=123):
+def motion_like_offsets(net, x, target_rough=0.5, bias_sigma=3.0, rounds=4, seed=123, absmean_cap=6.0):
     """Give `net` (on the GPU) the offset statistics of a trained model on the clips `x`: per-tap displacements of a few pixels
     (conv_offset.bias ~ N(0, bias_sigma^2)) PLUS a spatially varying part that follows the input's structure - conv_offset.weight is
     rescaled, per DCN module, until the mean |horizontal neighbour difference| of its offsets on `x` is `target_rough` px (the
-    difference is linear in the weights; the cascade of the pyramid makes a few rounds necessary).  Returns the per-module
-    (mean |offset|, roughness) of the last round."""
+    difference is linear in the weights; the cascade of the pyramid makes a few rounds necessary) - but never so far that the mean
+    |offset| of the layer exceeds `absmean_cap` px (trained EDVRs stay in single digits; the reference warns at 50,
+    arch_util.py:248-253): where the cap binds the field stays smoother than the target.  Returns the per-module
+    (mean |offset|, roughness) of the final state."""
     randomize_offsets(net, seed=seed, bias_sigma=bias_sigma)
     dcns = net.pcd_align.dcn_modules()
-    stats = []
-    for _ in range(rounds):
+
+    def measure():
         with torch.no_grad():
             net(x)
         net.check_offsets()
-        stats = [(m.last_offset_absmean, m.last_offset_rough) for m in dcns]
+        return [(m.last_offset_absmean, m.last_offset_rough) for m in dcns]
+    for _ in range(rounds):
+        stats = measure()
         with torch.no_grad():
-            for m, (_, rough) in zip(dcns, stats):
+            for m, (absmean, rough) in zip(dcns, stats):
                 if rough and rough > 0:
                     n_off = 2 * m.conv_offset.weight.shape[0] // 3
-                    m.conv_offset.weight[:n_off].mul_(min(max(target_rough / rough, 0.05), 200.0))
-    with torch.no_grad():
-        net(x)
-    net.check_offsets()
-    return [(m.last_offset_absmean, m.last_offset_rough) for m in dcns]
+                    b0 = float(m.conv_offset.bias[:n_off].abs().mean())  # the constant part's share of the mean |offset|
+                    part = max(absmean * absmean - b0 * b0, 1e-8) ** 0.5   # ... and (roughly) the spatially varying part's
+                    room = max(absmean_cap * absmean_cap - b0 * b0, 0.0) ** 0.5
+                    f = min(max(target_rough / rough, 0.05), 200.0, max(room / part, 0.05))
+                    m.conv_offset.weight[:n_off].mul_(f)
+    return measure()
