@@ -92,10 +92,10 @@ WINOGRAD = ('conv3x3_winograd_kernel', 'conv3x3_winograd_wgrad_kernel')  # execu
 WINOGRAD_F4 = ('conv3x3_winograd_f4_kernel',)  # F(4x4,3x3): 36 instead of 144 multiplies per 4x4 tile
 # the split-operand forms (fp32 operands as f16 (hi, lo) pairs on the f16 matrix pipe, 4 cross products, fp32 accumulate): the matrix
 # pipe is no longer what bounds them - the table carries their algorithmic HBM rate AND their share of the f16 matrix peak
-SPLIT_KERNELS = ('conv3x3_winograd_f4s_kernel', 'conv3x3_winograd_wgrad_split_kernel', 'dcnv2_fwd[dcn_tapwin_split_fwd_kernel]', 'gemm_nt_split_kernel',
+SPLIT_KERNELS = ('conv3x3_winograd_f4s_kernel', 'conv3x3_winograd_wgrad_split_kernel', 'conv3x3_wgrad_direct_split_kernel', 'dcnv2_fwd[dcn_tapwin_split_fwd_kernel]', 'gemm_nt_split_kernel',
                  'conv1x1_split_kernel')
 # multiplies the algorithm saves against the direct one (F(4x4): 4, F(2x2): 2.25, the DCN GEMM: none); each remaining fp32 product = 4 f16 ones
-SPLIT_SAVING = {'conv3x3_winograd_f4s_kernel': 4.0, 'conv3x3_winograd_wgrad_split_kernel': 2.25, 'dcnv2_fwd[dcn_tapwin_split_fwd_kernel]': 1.0,
+SPLIT_SAVING = {'conv3x3_winograd_f4s_kernel': 4.0, 'conv3x3_winograd_wgrad_split_kernel': 2.25, 'conv3x3_wgrad_direct_split_kernel': 1.0, 'dcnv2_fwd[dcn_tapwin_split_fwd_kernel]': 1.0,
                 'gemm_nt_split_kernel': 1.0, 'conv1x1_split_kernel': 1.0}
 DTYPE = ('f32 (3x3 / stride-1 convs and their weight gradients, the tap-window DCN forward, the dW product of the DCN backward and the 1x1 convs '
          'from 320 input channels up multiply SPLIT fp32 operands - f16 (hi, lo) pairs, all four cross products - on '

@@ -83,6 +83,7 @@ PROTOTYPES = {
     'edvr_conv2d_wgrad_f32': (i32, [vp] * 4 + [i32] * 8 + [i64, i64, i32, i32, i32, i64, i32, vp, vp, sz, vp]),
     'edvr_conv2d_wgrad_split_f32': (i32, [vp] * 4 + [i32] * 8 + [i64, i64, i32, i32, i32, i64, i32, vp, vp, sz, vp, vp, vp]),
     'edvr_conv2d_wgrad_split_applies': (i32, [i32] * 8),
+    'edvr_conv2d_wgrad_split_is_direct': (i32, [i32] * 2),
     'edvr_channel_sum_f32': (i32, [vp, vp, i32, i32, i64, i64, vp, sz, vp]),
     'edvr_pixel_unshuffle2_f32': (i32, [vp, vp, i32, i32, i32, i32, vp]),
     'edvr_pixel_unshuffle2_act_bwd_f32': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libedvr_amd.so')
 OBJDIR = os.path.join(HERE, 'build')
-SOURCES = ['api.hip', 'pack.hip', 'conv2d.hip', 'dcn.hip', 'dcn_any.hip', 'elementwise.hip', 'wgrad.hip', 'backward.hip', 'dcn_fused.hip', 'dcn_tapwin.hip', 'dcn_tapwin_s.hip', 'dcn_bwd_fused.hip', 'winograd.hip', 'winograd_f4.hip', 'winograd_f4s.hip', 'winograd_wgrad.hip', 'winograd_wgrad_s.hip', 'gemm_nt_s.hip', 'optim.hip', 'metrics.hip', 'conv_small.hip', 'conv1x1.hip', 'conv1x1_s.hip', 'data.hip']
+SOURCES = ['api.hip', 'pack.hip', 'conv2d.hip', 'dcn.hip', 'dcn_any.hip', 'elementwise.hip', 'wgrad.hip', 'backward.hip', 'dcn_fused.hip', 'dcn_tapwin.hip', 'dcn_tapwin_s.hip', 'dcn_bwd_fused.hip', 'winograd.hip', 'winograd_f4.hip', 'winograd_f4s.hip', 'winograd_wgrad.hip', 'winograd_wgrad_s.hip', 'wgrad_direct_s.hip', 'gemm_nt_s.hip', 'optim.hip', 'metrics.hip', 'conv_small.hip', 'conv1x1.hip', 'conv1x1_s.hip', 'data.hip']
 LINK = []  # no library dependencies beyond the HIP runtime: every kernel of the path is in csrc/
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-ffp-contract=fast']
 

@@ -96,6 +96,15 @@ int winograd_wgrad_split_launch(const float *x1, const float *x2, const float *d
                                 int64_t x1_img_stride, int64_t x2_img_stride, int x2_div, int x2_mul, int x2_add, int64_t dz_img_stride,
                                 int splits, int want_db, const float *x_amax, const float *dz_amax, hipStream_t stream);
 
+// wgrad_direct_s.hip: the 3x3 / stride-1 weight gradient as a direct pixel-axis GEMM on split operands (no transforms: the staging
+// streams of the Winograd-domain form are what bounded it); same partial format, same reduction
+bool wgrad_direct_split_enabled();
+bool wgrad_direct_split_supported(const float *x1, const float *x2, const float *dz, int h, int w, int64_t x1_img_stride, int64_t x2_img_stride,
+                                  int64_t dz_img_stride);
+int wgrad_direct_split_launch(const float *x1, const float *x2, const float *dz, float *ws, int c1, int c2, int n, int h, int w, int co,
+                              int64_t x1_img_stride, int64_t x2_img_stride, int x2_div, int x2_mul, int x2_add, int64_t dz_img_stride,
+                              int splits, int want_db, const float *x_amax, const float *dz_amax, hipStream_t stream);
+
 // dcn.hip: geometry of one DCN call, shared with dcn_any.hip
 struct DcnShape {
   int B, C, H, W, Co, kh, kw, stride, pad, dil, groups, dg, Ho, Wo;  // stride / pad / dil: along h

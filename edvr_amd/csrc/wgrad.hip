@@ -366,7 +366,18 @@ static int wgrad_impl(const float *x1, const float *x2, const float *dz, float *
   }
   int wsplits = 0;
   if (winograd_wgrad_plan(n, c1, c2, h, w, co, ks, stride, &wsplits) && ws_bytes >= winograd_wgrad_ws_bytes(co, ci, wsplits)) {
-    // the split-operand form of the same kernel (winograd_wgrad_s.hip) when the caller knows bounds of both tensors' magnitudes
+    // with bounds of both tensors' magnitudes: split operands on the f16 matrix pipe - as a direct pixel-axis GEMM where the rows are
+    // 16-byte aligned (wgrad_direct_s.hip: nothing to transform, the staging streams bounded the Winograd-domain form), else
+    // the split-operand form of the Winograd-domain kernel (winograd_wgrad_s.hip)
+    if (x_amax && dz_amax && winograd_wgrad_split_enabled() && wgrad_direct_split_enabled() && winograd_wgrad_get_algo() == EDVR_CONV_AUTO &&
+        wgrad_direct_split_supported(x1, x2, dz, h, w, x1_img_stride, x2_img_stride, dz_img_stride)) {
+      const int dsplits = std::min(wsplits, n * cdiv(w, 32) * h);
+      int rc = wgrad_direct_split_launch(x1, x2, dz, a.ws, c1, c2, n, h, w, co, x1_img_stride, x2_img_stride, x2_div, x2_mul, x2_add, dz_img_stride,
+                                         dsplits, dbias != nullptr, x_amax, dz_amax, stream);
+      if (rc) return rc;
+      const int64_t total = (int64_t)co * ci * 9;
+      return reduce_partials_launch(a.ws, dw, total, dsplits, accumulate, stream, dbias ? a.ws + (int64_t)dsplits * total : nullptr, dbias, co, dsplits);
+    }
     int rc = (x_amax && dz_amax && winograd_wgrad_split_enabled())
                  ? winograd_wgrad_split_launch(x1, x2, dz, a.ws, c1, c2, n, h, w, co, x1_img_stride, x2_img_stride, x2_div, x2_mul, x2_add,
                                                dz_img_stride, wsplits, dbias != nullptr, x_amax, dz_amax, stream)
@@ -417,6 +428,10 @@ int edvr_conv2d_wgrad_split_applies(int n, int c1, int c2, int h, int w, int co,
   if (edvr::winograd_wgrad_get_algo() == EDVR_CONV_AUTO && edvr::wgrad_small_plan(n, c1, c2, h, w, co, ks, stride, &ssplits)) return 0;
   if (ks == 1 && c2 == 0 && edvr::winograd_wgrad_get_algo() == EDVR_CONV_AUTO) return edvr::gemm_nt_split_enabled() ? 1 : 0;  // the 1x1 GEMM
   return (edvr::winograd_wgrad_split_enabled() && edvr::winograd_wgrad_plan(n, c1, c2, h, w, co, ks, stride, &splits)) ? 1 : 0;
+}
+
+int edvr_conv2d_wgrad_split_is_direct(int h, int w) {  // (of a call edvr_conv2d_wgrad_split_applies() accepts, on 16-byte aligned tensors)
+  return (edvr::wgrad_direct_split_enabled() && edvr::winograd_wgrad_get_algo() == EDVR_CONV_AUTO && (w & 3) == 0 && h >= 1) ? 1 : 0;
 }
 
 int edvr_conv2d_wgrad_kernel_name(int n, int c1, int c2, int h, int w, int co, int ks, int stride, char *buf, size_t buf_len) {

@@ -988,7 +988,7 @@ def conv2d_wgrad(x1, x2, x2_map, dz, co, ks, stride, want_db=False):
         L.edvr_conv2d_wgrad_kernel_name(n, c1, c2, h, w, co, ks, stride, buf, 96)
         name = buf.value.decode()
         if split and name == 'conv3x3_winograd_wgrad_kernel':
-            name = 'conv3x3_winograd_wgrad_split_kernel'
+            name = 'conv3x3_wgrad_direct_split_kernel' if L.edvr_conv2d_wgrad_split_is_direct(h, w) else 'conv3x3_winograd_wgrad_split_kernel'
     pad = ks // 2
     ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
     common = (_ptr(x1), _ptr(x2), _ptr(dz), _ptr(dw), c1, c2, n, h, w, co, ks, stride, _img_stride(x1), _img_stride(x2) if x2 is not None else 0,

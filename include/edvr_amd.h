@@ -360,9 +360,12 @@ int edvr_conv2d_wgrad_f32(const float *x1, const float *x2, const float *dz, flo
                           int co, int ks, int stride, int64_t x1_img_stride, int64_t x2_img_stride, int x2_div, int x2_mul,
                           int x2_add, int64_t dz_img_stride, int accumulate, float *dbias, void *ws, size_t ws_bytes,
                           edvr_stream_t stream);
-/* The same with split fp32 operands on the f16 matrix pipe where the Winograd-domain kernel applies (csrc/winograd_wgrad_s.hip: both
- * GEMM operands as f16 (hi, lo) pairs, all four cross products, fp32 accumulation - the fp32 kernel's result to within its own rounding
- * level, a quarter of its matrix-pipe time); identical to edvr_conv2d_wgrad_f32 everywhere else.  x_amax / dz_amax: device pointers to
+/* The same with split fp32 operands on the f16 matrix pipe where the Winograd-domain kernel applies (both GEMM operands as f16 (hi, lo)
+ * pairs, all four cross products, fp32 accumulation - the fp32 kernel's result to within its own rounding level): the Winograd-domain
+ * form csrc/winograd_wgrad_s.hip; identical to edvr_conv2d_wgrad_f32 everywhere else.  Opt-in alternative (EDVR_WGRAD_DIRECT_SPLIT=1,
+ * rows of 16-byte aligned tensors with w % 4 == 0; edvr_conv2d_wgrad_split_is_direct() says whether it would run): the DIRECT pixel-axis
+ * GEMM csrc/wgrad_direct_s.hip - nothing is transformed, a value is split once and the nine taps are nine reads of the same LDS rows;
+ * same accuracy, 10-15 % slower on MI355X (2.25x the matrix work meets the power-limited matrix clock, see that file).  x_amax / dz_amax: device pointers to
  * ONE float each, upper bounds of max |x1|, |x2| and of max |dz| (edvr_amax_f32 or a producer's statistic; too small = infinities).
  * edvr_conv2d_wgrad_split_applies: 1 if that kernel would run for this layer (callers skip computing the bounds otherwise).
  * EDVR_WGRAD_SPLIT=0 switches it off. */
@@ -371,6 +374,7 @@ int edvr_conv2d_wgrad_split_f32(const float *x1, const float *x2, const float *d
                                 int x2_add, int64_t dz_img_stride, int accumulate, float *dbias, void *ws, size_t ws_bytes,
                                 const float *x_amax, const float *dz_amax, edvr_stream_t stream);
 int edvr_conv2d_wgrad_split_applies(int n, int c1, int c2, int h, int w, int co, int ks, int stride);
+int edvr_conv2d_wgrad_split_is_direct(int h, int w);
 /* Name of the kernel edvr_conv2d_wgrad_f32 would launch for this layer (as rocprofv3 prints it).  Measurement aid only. */
 int edvr_conv2d_wgrad_kernel_name(int n, int c1, int c2, int h, int w, int co, int ks, int stride, char *buf, size_t buf_len);
 /* dbias (nullable): also db[co] = sum_{n,pixel} dz (the bias gradient).  The Winograd-domain kernel holds every dz value in
