@@ -67,3 +67,19 @@ def test_channel_sum_bias_gradient(gpu, shape):
     sl = x.to(gpu)[:, 1:shape[1] - 1] if shape[1] > 8 else None  # channel-sliced view: image stride != c * hw
     if sl is not None:
         assert torch.allclose(ops.channel_sum(sl).cpu().double(), ref[1:-1], rtol=0, atol=2e-5 * max(1.0, ref.abs().max().item()) + 1e-4)
+
+
+def test_direct_split_weight_gradient_opt_in(gpu):
+    """csrc/wgrad_direct_s.hip (EDVR_WGRAD_DIRECT_SPLIT=1, read once per process: a child process): every `auto` case of this file - it
+    takes the ones with w % 4 == 0, concat inputs, the frame map and partial channel blocks included - at the same tolerance."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, EDVR_WGRAD_DIRECT_SPLIT='1')
+    code = ('import ctypes, sys; sys.path.insert(0, "tests"); from edvr_amd import _lib; L = _lib.lib(); '
+            'assert L.edvr_conv2d_wgrad_split_is_direct(64, 64) == 1 and L.edvr_conv2d_wgrad_split_is_direct(7, 9) == 0; '
+            'import pytest; sys.exit(pytest.main(["-q", "-x", "tests/test_gpu_wgrad.py", "-k", "matches_fp64_reference and auto"]))')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout
