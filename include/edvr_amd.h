@@ -137,10 +137,15 @@ typedef struct edvr_conv2d_desc {
   const float *x_amax;    /* device pointer to ONE float >= max |x1|, |x2| (any upper bound: edvr_amax_f32, or a statistic the
                            * producer of x already has).  Read by the split-operand kernel only, to place the transformed input in
                            * the f16 range; a bound that is too SMALL overflows to infinities, one that is 2^k too large costs
-                           * accuracy only for elements below 2^-18 of it. */
+                           * accuracy only for elements below 2^-18 of it.  Two consequences a caller should know: operands carry 22
+                           * significant bits (fp32: 24), and ONE bound covers the whole launch - the low bits of an image's output
+                           * depend on which other images share the launch (within the kernel's 3e-5 tolerance; per-image calls with
+                           * per-image bounds remove the coupling). */
   float *y_amax;          /* optional, split-operand kernel only (EDVR_ERR_UNSUPPORTED elsewhere: ask edvr_conv2d_y_amax_supported): y_amax[0] =
                            * max(y_amax[0], max |y|) over everything the launch stores (residuals / gate applied), with one atomic per
-                           * wave at the end - the `x_amax` of the next conv of a chain for free.  The caller zeroes it (or folds bounds). */
+                           * wave at the end - the `x_amax` of the next conv of a chain for free.  The caller zeroes it (or folds bounds).
+                           * The maximum is kept as a BIT PATTERN (non-negative floats order as integers, every NaN above +inf): a
+                           * non-finite output is sticky in the slot - an overflow sentinel the host can read (edvr_amd/ops.py split_guard_*). */
 } edvr_conv2d_desc;
 
 size_t edvr_conv2d_packed_weight_elems(int co, int ci, int ks);
