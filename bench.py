@@ -7,9 +7,12 @@
 A "step" is one pass of the hot path (EDVR forward, or forward+backward+Adam with --mode train) over one batch of synthetic
 REDS-shaped clips per GPU, inputs resident in HBM before timing.  Clips are independent, so ranks shard them with no data-path
 collective (inference) or with the DDP gradient all-reduce over RCCL (training).  `--gpus N` without a torchrun environment
-re-launches this script as N ranks through torch.distributed.run.  Rank 0 prints ONE JSON line.
+re-launches this script as N ranks through torch.distributed.run.  Rank 0 prints ONE JSON line - the COMPACT line (`compact_line`: the
+contract's fields, `roofline` with the measured `traffic`, `cpu_baseline`, `parity` and the headline number of every leg; < 6 KB,
+strict JSON, the last line of stdout) - and writes the full report described below to `bench_full.json` beside this file.
+`leg_plan()` says which legs run on which ranks (a leg with barriers runs on every rank or on none).
 
-Objects in the line besides the contract's fields (everything below runs OUTSIDE the timed region):
+Objects of the full report besides the contract's fields (everything below runs OUTSIDE the timed region):
   roofline            dominant kernel of the timed step, from an instrumented pass (every launch bracketed by HIP events on the
                       launch stream): `achieved` = flops the matrix cores EXECUTE (MFMA issues x 4096, tile and channel padding
                       included - edvr_conv2d_executed_flops, the quantity SQ_INSTS_VALU_MFMA_MOPS_F32 counts) / time, `frac` =
@@ -27,6 +30,9 @@ Objects in the line besides the contract's fields (everything below runs OUTSIDE
                       channel (every (group, tap) has its own multi-pixel displacement, mean |offset| ~ 3.2 / 8 px) on top of the
                       same N(0, 0.02) weights (spatially coherent field): clips/s, the DCN forward's roofline fraction, parity
                       against the stock-ops arm.  The reference's gather costs the same at any offset (.cu:570-633).
+                      `motion`: the same with offsets that also VARY IN SPACE as a trained model's do (structured clips - smooth
+                      drifting background, moving rectangles, texture - and offset convs rescaled to ~0.5 px of neighbour
+                      difference per DCN layer under a 6 px cap on the mean offset: tests/util_edvr.py); `train.motion` likewise.
   configs             one-line results for the other BASELINE.json configs that fit one GPU: [1] EDVR-M batch 4, [2] EDVR-L T7
                       batch 8 forward and forward+backward+Adam, [4] deblur 720p batch 4.
   parity              the headline workload's output on ONE clip vs the CPU oracle's output on the same clip.
