@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void dcn_tapwin_fwd_kernel(const DcnTapwinA
     if constexpr (SLOW) {
       // Fix-up pass after the regular one (in which the slow lanes carried zero weights): the lanes whose cell lies outside the
       // window gather their four corners from global memory with the full bounds logic (dcn_tap.h), every other lane contributes
-      // 0.  Rare by construction, so this is a plain rolled loop per sub-tile - small code, few registers.
+      // 0.
       const int ti = t / 3, tj = t - 3 * ti;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -308,13 +308,20 @@ __global__ __launch_bounds__(256, 2) void dcn_tapwin_fwd_kernel(const DcnTapwinA
         const float s0 = on ? tq.w00 * m : 0.f, s1 = on ? tq.w01 * m : 0.f, s2 = on ? tq.w10 * m : 0.f, s3 = on ? tq.w11 * m : 0.f;
         const int hp = half * P;
         const int o0 = on ? (tq.o00 + hp) * 4 : OOB, o1 = on ? (tq.o01 + hp) * 4 : OOB, o2 = on ? (tq.o10 + hp) * 4 : OOB, o3 = on ? (tq.o11 + hp) * 4 : OOB;
-#pragma unroll 1
+        // all 4 NQ corner gathers of the sub-tile in flight at once, then the products (round 6: it was a rolled loop of NQ dependent
+        // gathers - fields that vary inside a tile, bench.py's `motion` leg, run this pass on most steps; dcn_tapwin_s.hip likewise)
+        float gv[NQ][4];
+#pragma unroll
         for (int q = 0; q < NQ; ++q) {
           const int so = (g * CPG + 2 * q) * P * 4;
-          const float bv = s0 * __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, o0, so, 0)) +
-                           s1 * __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, o1, so, 0)) +
-                           s2 * __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, o2, so, 0)) +
-                           s3 * __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, o3, so, 0));
+          gv[q][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, o0, so, 0));
+          gv[q][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, o1, so, 0));
+          gv[q][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, o2, so, 0));
+          gv[q][3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, o3, so, 0));
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const float bv = s0 * gv[q][0] + s1 * gv[q][1] + s2 * gv[q][2] + s3 * gv[q][3];
           const float *ap = wb + (2 * q + half) * MB + j * MT;
 #pragma unroll
           for (int m2 = 0; m2 < MT; ++m2) acc[s][m2] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[m2], bv, acc[s][m2], 0, 0, 0);
