@@ -346,12 +346,27 @@ __global__ __launch_bounds__(256, 4) void dcn_bwd_dx_strip_kernel(const float *_
   }
 }
 
+// Float accumulation into LDS.  The hardware's ds_add_f32 runs at 0.4 lane-operations per cycle and CU on gfx950 - 203 G/s device-wide, where
+// ds_add_u32 does 9137 G/s and a plain read-add-write 4877 (scripts/micro/lds_atomics.hip, profiles/r6/micro_lds_atomics.log): 5.4 of the
+// 12.0 ms of the LDS-window backward on the EDVR-L training layer were this one instruction.  A compare-and-swap loop on the integer pipe
+// does the same addition at 4.7 lane-operations per cycle and CU (2.6 when lane pairs share a cell): 12x faster; in the kernel 12.0 -> 8.8 ms
+// per call (the path without any scatter: 6.5).  Batching the sixteen loops of a channel batch (all reads, all swaps, retries) was
+// measured too: 9.5 ms - more registers, no gain.  (Bit patterns are compared, so a NaN cannot spin the loop.)
+__device__ __forceinline__ void lds_add_f32(float *p, float v) {
+  unsigned *q = reinterpret_cast<unsigned *>(p);
+  unsigned old = *q, assumed;
+  do {
+    assumed = old;
+    old = atomicCAS(q, assumed, __builtin_bit_cast(unsigned, __builtin_bit_cast(float, assumed) + v));
+  } while (old != assumed);
+}
+
 // ---------------------------------------------------------------------------------------------
 // backward, tile version for the EDVR signature (3x3, stride 1, pad 1, dil 1, <= 16 channels per deformable group):
 // same arithmetic as dcn_bwd_coord_kernel, but dX is accumulated in LDS.  The grid-stride kernel above issues four
 // device-scope fp32 atomics per (pixel, tap, channel) - 9 GB of fabric write traffic per launch by the PMC counters, and the
 // reason it ran at ~5600 cycles per (tap, channel) iteration.  Here a workgroup owns (image, group, 8 x 32 output pixels):
-// its corner contributions go to a (8 + 2 + 2R) x (32 + 2 + 2R) x 16-channel LDS window with ds_add_f32, and the window is
+// its corner contributions go to a (8 + 2 + 2R) x (32 + 2 + 2R) x 16-channel LDS window (lds_add_f32 above), and the window is
 // flushed once with one global atomic per touched element (windows of neighbouring tiles overlap): ~14x fewer global
 // atomics.  Taps that leave the window (|offset| > R) fall back to the global atomic, per corner.
 template <int R>
@@ -421,10 +436,10 @@ __global__ __launch_bounds__(256) void dcn_bwd_coord_tile_kernel(const float *__
             const float v00 = t.w00 * tt + (mg.take00 ? l01 : 0.f), v10 = t.w10 * tt + (mg.take10 ? l11 : 0.f);
             if (inwin) {
               float *wc = w00 + (cc0 + u) * (LH * LWP);
-              if (ok00) atomicAdd(wc, v00);  // LDS: ds_add_f32
-              if (ok01 && !mg.give01) atomicAdd(wc + 1, v01);
-              if (ok10) atomicAdd(wc + LWP, v10);
-              if (ok11 && !mg.give11) atomicAdd(wc + LWP + 1, v11);
+              if (ok00) lds_add_f32(wc, v00);
+              if (ok01 && !mg.give01) lds_add_f32(wc + 1, v01);
+              if (ok10) lds_add_f32(wc + LWP, v10);
+              if (ok11 && !mg.give11) lds_add_f32(wc + LWP + 1, v11);
             } else {
               float *gq = gp + u * plane;
               if (ok00) unsafeAtomicAdd(gq + t.o00, v00);
@@ -871,8 +886,14 @@ static int dcnv2_bwd_impl(const float *x, const float *offset, const float *mask
       rc = check_launch("dcn_bwd_dx_strip_kernel + dcn_bwd_coord_kernel");
     } else if (use_tile && scatter_hint != EDVR_DCN_SCATTER_DEVICE && scatter_hint != EDVR_DCN_SCATTER_STRIP && edvr_sig && C / dg <= 16) {
       const int tiles_x = cdiv(s.Wo, 32), tiles_y = cdiv(s.Ho, 8);
-      hipLaunchKernelGGL((dcn_bwd_coord_tile_kernel<3>), dim3(tiles_x * tiles_y, dg, B), dim3(256), 0, stream, x, offset, mask, col, dx,
-                         doffset, dmask, s, tiles_x);
+      // window margin beyond the tile's 3x3 footprint (a corner outside the window is a device atomic): 3 px (42 KB of LDS, three workgroups
+      // per CU) or, EDVR_DCN_SCATTER_LDS_WIDE, 6 px (66 KB, two per CU) for fields whose taps sit ~4 px out and more (15.0 -> 11.0 ms per
+      // call at sigma 6 px per tap, 9.7 vs 9.8 at sigma 4, 7.9 vs 9.9 at sigma 2; 8 px = one workgroup per CU: 15-17 ms everywhere:
+      // profiles/r6/dcn_bwd_margin.log)
+      if (scatter_hint == EDVR_DCN_SCATTER_LDS_WIDE)
+        hipLaunchKernelGGL((dcn_bwd_coord_tile_kernel<6>), dim3(tiles_x * tiles_y, dg, B), dim3(256), 0, stream, x, offset, mask, col, dx, doffset, dmask, s, tiles_x);
+      else
+        hipLaunchKernelGGL((dcn_bwd_coord_tile_kernel<3>), dim3(tiles_x * tiles_y, dg, B), dim3(256), 0, stream, x, offset, mask, col, dx, doffset, dmask, s, tiles_x);
       rc = check_launch("dcn_bwd_coord_tile_kernel");
     } else {
       const int64_t total = (int64_t)B * dg * K * P;

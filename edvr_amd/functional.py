@@ -130,6 +130,8 @@ def scatter_hint_from_stats(absmean, rough):
     narrow band where most taps of a ROUGH field are still sub-pixel (a smooth field of that size keeps the no-scatter kernels)."""
     if absmean is None:
         return ops.DCN_SCATTER_LDS
+    if absmean >= 4.0:  # taps several pixels out: the window with the 6 px margin (15.0 -> 11.0 ms at sigma 6 px per tap; equal at sigma 4)
+        return ops.DCN_SCATTER_LDS_WIDE
     if absmean < 0.4:  # white-noise offsets of sigma 0.5 (|mean| 0.4): 9 % of the taps already leave the sub-pixel window
         return ops.DCN_SCATTER_STRIP
     if rough is not None and rough < 0.45:  # smooth: per-tap constants - most taps are still sub-pixel up to ~0.6 (11.9 vs 14.8 ms at 0.5)

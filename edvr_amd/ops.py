@@ -288,8 +288,8 @@ def invalidate_packed_weights():
 
 
 # ------------------------------------------------------------------------------------------------ conv
-DCN_SCATTER_AUTO, DCN_SCATTER_DEVICE, DCN_SCATTER_LDS, DCN_SCATTER_STRIP = 0, 1, 2, 3  # include/edvr_amd.h EDVR_DCN_SCATTER_*
-_SCATTER_NAMES = {0: '[auto]', 1: '[device atomics]', 2: '[lds window]', 3: '[strip / fused]'}  # measurement label of dcnv2_backward's dX strategy
+DCN_SCATTER_AUTO, DCN_SCATTER_DEVICE, DCN_SCATTER_LDS, DCN_SCATTER_STRIP, DCN_SCATTER_LDS_WIDE = 0, 1, 2, 3, 4  # include/edvr_amd.h EDVR_DCN_SCATTER_*
+_SCATTER_NAMES = {0: '[auto]', 1: '[device atomics]', 2: '[lds window]', 3: '[strip / fused]', 4: '[lds window]'}  # measurement label of dcnv2_backward's dX strategy
 DCN_HALO_TAPWIN = _lib.DCN_HALO_TAPWIN  # halo_hint of dcnv2_forward: per-tap shifted windows (csrc/dcn_tapwin.hip)
 LAUNCH_HOOK = None  # callable(kernel_name, algorithmic_flops, launch_fn, algorithmic_bytes) or None
 CONV_ALGO = CONV_AUTO  # default algorithm request of conv2d(); tests flip it to cover both kernels on every shape

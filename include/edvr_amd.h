@@ -65,6 +65,7 @@ int edvr_check_device(void);
 #define EDVR_DCN_SCATTER_DEVICE 1
 #define EDVR_DCN_SCATTER_LDS 2
 #define EDVR_DCN_SCATTER_STRIP 3
+#define EDVR_DCN_SCATTER_LDS_WIDE 4
 #define EDVR_CONV_AUTO 0
 #define EDVR_CONV_DIRECT 1
 #define EDVR_CONV_WINOGRAD 2
@@ -277,8 +278,11 @@ int edvr_dcnv2_bwd_split_applies(void);
  *   EDVR_DCN_SCATTER_DEVICE (1): fp32 device atomics straight to dx, as the reference's col2im (.cu:688).  Fastest when the
  *       offset field is smooth (neighbouring pixels hit neighbouring addresses: 6 ms on the EDVR-L training layer), collapses
  *       when it is not (89 ms with white-noise offsets of 1 px).
- *   EDVR_DCN_SCATTER_LDS (2): per-tile LDS window (ds_add_f32) flushed with one device atomic per touched element: 7 ms /
- *       14 ms on the same two cases.  3x3, stride 1, pad 1, dil 1, <= 16 channels per deformable group; else DEVICE is used.
+ *   EDVR_DCN_SCATTER_LDS (2): per-tile LDS window flushed with one device atomic per touched element: 7 ms /
+ *       14 ms on the same two cases (round 6: the window's float additions are compare-and-swap loops - the hardware's ds_add_f32 runs
+ *       at 0.4 lane-operations per cycle and CU on gfx950 -: 12.0 -> 8.8 ms per call on a trained-like field).  3x3, stride 1, pad 1,
+ *       dil 1, <= 16 channels per deformable group; else DEVICE is used.  The window reaches 3 px beyond the tile's 3x3 footprint;
+ *       EDVR_DCN_SCATTER_LDS_WIDE (4): 6 px, for fields whose taps sit ~4 px out and more (a corner outside the window is a device atomic).
  *   EDVR_DCN_SCATTER_STRIP (3): no scatter at all for sub-pixel offsets - one wave owns whole channel planes, folds the 9 taps of a
  *       pixel into a 5x5 register patch, the patch onto its owner lanes with DPP wave shifts and the rows into a register ring;
  *       one uncontended atomic per dx element.  Taps with |offset| >= 1 fall back to device atomics one by one, so this is the

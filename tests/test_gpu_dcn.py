@@ -56,7 +56,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize('scatter', ['lds', 'device', 'strip'])  # the dx accumulation strategies of the backward (EDVR_DCN_SCATTER_*)
+@pytest.mark.parametrize('scatter', ['lds', 'lds_wide', 'device', 'strip'])  # the dx accumulation strategies of the backward (EDVR_DCN_SCATTER_*)
 @pytest.mark.parametrize('case', CASES)
 def test_dcnv2_forward_backward_vs_oracle(gpu, case, scatter):
     from edvr_amd import ops
@@ -70,7 +70,8 @@ def test_dcnv2_forward_backward_vs_oracle(gpu, case, scatter):
     xg, og, mg, wg, bg, dyg = (t.to(gpu) for t in (x, off, m, w, b, dy))
     y = ops.dcnv2_forward(xg, og, mg, wg, bg, *cfg)
     grads = ops.dcnv2_backward(xg, og, mg, wg, dyg, True, *cfg,
-                               scatter_hint={'lds': ops.DCN_SCATTER_LDS, 'device': ops.DCN_SCATTER_DEVICE, 'strip': ops.DCN_SCATTER_STRIP}[scatter])
+                               scatter_hint={'lds': ops.DCN_SCATTER_LDS, 'lds_wide': ops.DCN_SCATTER_LDS_WIDE, 'device': ops.DCN_SCATTER_DEVICE,
+                                             'strip': ops.DCN_SCATTER_STRIP}[scatter])
     torch.cuda.synchronize()
     assert _rel(y, ref_y) < FWD_RTOL
     # d(offset) is discontinuous where a sampling position sits on an integer: if fp32 rounding of `base + offset` crosses it,
@@ -231,7 +232,7 @@ def test_tap_window_kernel_on_piecewise_constant_motion(gpu, geom, jump):
     dy = torch.randn(B, Co, H, W, generator=g)
     gref = O.c_backward(x.double(), off.double(), m.double(), w.double(), dy.double(), True, 1, 1, 1, 1, dg)
     g32 = O.c_backward(x, off, m, w, dy, True, 1, 1, 1, 1, dg)  # (taps whose fp32 position rounds across an integer: excluded, as above)
-    for scatter in (ops.DCN_SCATTER_AUTO, ops.DCN_SCATTER_LDS, ops.DCN_SCATTER_DEVICE):
+    for scatter in (ops.DCN_SCATTER_AUTO, ops.DCN_SCATTER_LDS, ops.DCN_SCATTER_LDS_WIDE, ops.DCN_SCATTER_DEVICE):
         got = ops.dcnv2_backward(dev[0], dev[1], dev[2], dev[3], dy.to(gpu), True, 1, 1, 1, 1, dg, scatter_hint=scatter)
         for name, a_, r_, r32 in zip(('dx', 'doffset', 'dmask', 'dw', 'db'), got, gref, g32):
             if name == 'doffset':

@@ -98,12 +98,13 @@ def test_kernel_hints_from_offset_statistics():
     assert F_.halo_hint_from_stats(0.8, 1.13) == 7 and F_.halo_hint_from_stats(51.0, 72.0) == -1
     assert F_.halo_hint_from_stats(0.4, None) == 3 and F_.halo_hint_from_stats(8.0, None) == -1
     # backward
-    assert F_.scatter_hint_from_stats(8.0, 0.2) == ops.DCN_SCATTER_LDS and F_.scatter_hint_from_stats(8.0, 1.5) == ops.DCN_SCATTER_LDS
+    assert F_.scatter_hint_from_stats(8.0, 0.2) == ops.DCN_SCATTER_LDS_WIDE and F_.scatter_hint_from_stats(8.0, 1.5) == ops.DCN_SCATTER_LDS_WIDE  # (>= 4 px: the 6 px margin)
+    assert F_.scatter_hint_from_stats(3.9, 0.2) == ops.DCN_SCATTER_LDS
     assert F_.scatter_hint_from_stats(0.1, 0.2) == ops.DCN_SCATTER_STRIP and F_.scatter_hint_from_stats(0.5, 0.17) == ops.DCN_SCATTER_STRIP
     assert F_.scatter_hint_from_stats(0.6, 1.0) == ops.DCN_SCATTER_DEVICE and F_.scatter_hint_from_stats(1.6, 0.17) == ops.DCN_SCATTER_LDS
     st = torch.tensor([[6.0, 2.0], [3.0, 0.0]])  # (2, n) sums of abs_stats_per_image over 16 elements in all
     assert ops.offset_stats(st, 16) == (0.5, 0.25) and ops.offset_stats(torch.tensor([[8.0], [-1.0]]), 16) == (0.5, None)
-    assert (ops.DCN_SCATTER_AUTO, ops.DCN_SCATTER_DEVICE, ops.DCN_SCATTER_LDS, ops.DCN_SCATTER_STRIP) == (0, 1, 2, 3)
+    assert (ops.DCN_SCATTER_AUTO, ops.DCN_SCATTER_DEVICE, ops.DCN_SCATTER_LDS, ops.DCN_SCATTER_STRIP, ops.DCN_SCATTER_LDS_WIDE) == (0, 1, 2, 3, 4)
     hdr = open(os.path.join(os.path.dirname(__file__), '..', 'include', 'edvr_amd.h')).read()
     for name, val in (('AUTO', 0), ('DEVICE', 1), ('LDS', 2), ('STRIP', 3)):
         assert f'#define EDVR_DCN_SCATTER_{name} {val}' in hdr
