@@ -14,7 +14,7 @@ cp bench_full.json $O/bench_full.json 2>/dev/null
 bash scripts/prof_bench.sh r6f/bench_edvr_l_infer > /dev/null 2>&1
 bash scripts/prof_bench.sh r6f/bench_edvr_l_train --mode train > /dev/null 2>&1
 bash scripts/prof_pmc_f4s.sh r6f/pmc_f4s > /dev/null 2>&1
-EDVR_AMD_LIB=edvr_amd/lib/variants/libedvr_amd_prof.so timeout 120 python scripts/f4s_prof.py 2>&1 | grep -v amdgpu.ids > $O/f4s_prof_counters.log
+# (the wave-cycle counters of the split F(4x4) kernel: profiles/r6/f4s_wave_cycle_counters*.log, scripts/f4s_prof.py on a -DF4S_PROF build)
 cut -c1-400 $O/bench_default_run.json; echo
 cut -c1-200 $O/bench_edvr_l_infer/bench.json; echo; cut -c1-200 $O/bench_edvr_l_train/bench.json; echo
 rm -rf $O/bench_edvr_l_infer/*trace*.csv $O/bench_edvr_l_train/*trace*.csv 2>/dev/null
